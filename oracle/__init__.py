@@ -1,0 +1,108 @@
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+
+ctypes front-end of the CPU oracle (oracle/bayer2rgb_oracle.c) plus the NumPy
+closed form (oracle/bayer2rgb_np.py).  Imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from . import bayer2rgb_np as np_oracle  # noqa: F401
+from .bayer2rgb_np import LAYOUTS, PATTERNS, synthetic_frames  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle_bayer.so")
+REF_ROWS_PATH = os.path.join(_HERE, "_ref", "libbayerorc_ref.so")
+_lib = None
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(quiet=True):
+    """Compile the oracle (and oracle/_ref when /root/reference is mounted)."""
+    subprocess.run(["make", "-C", _HERE], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        frame_args = [_u8p, ctypes.c_int, _u8p, ctypes.c_int] + [ctypes.c_int] * 6
+        L.oracle_bayer2rgb.argtypes = frame_args
+        L.oracle_bayer2rgb_refrows.argtypes = frame_args
+        L.oracle_load_ref_rows.argtypes = [ctypes.c_char_p]
+        L.oracle_bayer2rgb_batch.argtypes = [
+            _u8p, ctypes.c_size_t, ctypes.c_int, _u8p, ctypes.c_size_t, ctypes.c_int,
+        ] + [ctypes.c_int] * 9
+        L.oracle_fill_synthetic.argtypes = [
+            _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
+            ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
+        L.oracle_fill_synthetic.restype = None
+        _lib = L
+    return _lib
+
+
+def have_ref_rows():
+    return os.path.exists(REF_ROWS_PATH)
+
+
+def load_ref_rows():
+    if lib().oracle_load_ref_rows(REF_ROWS_PATH.encode()) != 0:
+        raise RuntimeError("cannot load " + REF_ROWS_PATH)
+
+
+def _p(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def bayer2rgb(src, width, pattern, r_off, g_off, b_off, dst_stride=None, ref_rows=False):
+    """src: (H, src_stride) uint8 -> (H, dst_stride) uint8 via the C oracle.
+
+    Bytes of a destination row beyond 4*width keep the 0xA5 guard fill.
+    """
+    if isinstance(pattern, str):
+        pattern = PATTERNS[pattern]
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    H, sstride = src.shape
+    dstride = 4 * width if dst_stride is None else dst_stride
+    dst = np.full((H, dstride), 0xA5, np.uint8)
+    if ref_rows:
+        load_ref_rows()
+        fn = lib().oracle_bayer2rgb_refrows
+    else:
+        fn = lib().oracle_bayer2rgb
+    rc = fn(_p(dst), dstride, _p(src), sstride, width, H, pattern, r_off, g_off, b_off)
+    if rc != 0:
+        raise ValueError("oracle rejected geometry/layout (rc=%d)" % rc)
+    return dst
+
+
+def bayer2rgb_batch(src, width, pattern, r_off, g_off, b_off, nthreads=1, ref_rows=False):
+    """src: (N, H, src_stride) uint8 -> (N, H, 4*width) uint8."""
+    if isinstance(pattern, str):
+        pattern = PATTERNS[pattern]
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    N, H, sstride = src.shape
+    dst = np.empty((N, H, 4 * width), np.uint8)
+    if ref_rows:
+        load_ref_rows()
+    rc = lib().oracle_bayer2rgb_batch(
+        _p(dst), H * 4 * width, 4 * width, _p(src), H * sstride, sstride,
+        width, H, pattern, r_off, g_off, b_off, N, nthreads, int(ref_rows))
+    if rc != 0:
+        raise ValueError("oracle rejected geometry/layout (rc=%d)" % rc)
+    return dst
+
+
+def fill_synthetic(width, height, nframes, seed, first_frame=0, stride=None):
+    stride = width if stride is None else stride
+    buf = np.empty((nframes, height, stride), np.uint8)
+    lib().oracle_fill_synthetic(_p(buf), width, height, stride, height * stride,
+                                first_frame, nframes, seed)
+    return buf

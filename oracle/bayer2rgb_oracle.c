@@ -1,0 +1,394 @@
+/*
+ * TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  See bayer2rgb_oracle.h.
+ *
+ * Plain-C restatement of the reference bayer2rgb frame path.  Every function
+ * cites the reference lines it restates (paths relative to /root/reference).
+ * The structure deliberately follows the reference (two horizontal lines per
+ * source row kept in a ring of four row slots, one merge per output row) so
+ * that the reference's edge behaviour -- in particular the bottom row pairing
+ * with row H-4 -- falls out of the ring arithmetic instead of being
+ * hard-coded; the independent closed form lives in oracle/bayer2rgb_np.py.
+ */
+#define _GNU_SOURCE
+#include "bayer2rgb_oracle.h"
+
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ORC opcode avgub, gstbayerorc-dist.c:225-226: (a + b + 1) >> 1 on uint8 */
+static inline uint8_t
+avgub (uint8_t a, uint8_t b)
+{
+  return (uint8_t) (((unsigned) a + (unsigned) b + 1u) >> 1);
+}
+
+/* ---- horizontal pass -------------------------------------------------- */
+
+/* gst_bayer2rgb_split_and_upsample_horiz, gstbayer2rgb.c:354-381, with the
+ * x86 inner loop bayer_orc_horiz_upsample_unaligned (gstbayerorc.orc:3-19;
+ * C semantics gstbayerorc-dist.c:183-249) folded in.
+ *   ev[x]: the colour sampled at even columns, at every x
+ *   od[x]: the colour sampled at odd columns, at every x */
+static void
+own_row_lines (uint8_t *ev, uint8_t *od, const uint8_t *s, int w)
+{
+  int x, i, npairs;
+
+  /* head, :360-363 */
+  ev[0] = s[0];
+  od[0] = s[1];
+  ev[1] = avgub (s[0], s[2]);
+  od[1] = s[1];
+
+  /* body, :365-367: d0 = ev+2, d1 = od+2, src pointer s+1, (w-4)>>1 pairs.
+   * orc:10-19 with t = s+1: c=t[2i] b=t[2i+1] e'=t[2i+2] d=t[2i+3]
+   *   d0 pair = (b, avg(b,d));  d1 pair = (avg(c,e'), e')   */
+  npairs = (w - 4) >> 1;
+  for (i = 0; i < npairs; i++) {
+    const uint8_t *t = s + 1 + 2 * i;
+    ev[2 + 2 * i] = t[1];
+    ev[3 + 2 * i] = avgub (t[1], t[3]);
+    od[2 + 2 * i] = avgub (t[0], t[2]);
+    od[3 + 2 * i] = t[2];
+  }
+
+  /* tail, :372-380 */
+  for (x = w - 2; x < w; x++) {
+    if ((x & 1) == 0) {
+      ev[x] = s[x];
+      od[x] = s[x - 1];
+    } else {
+      ev[x] = s[x - 1];
+      od[x] = s[x];
+    }
+  }
+}
+
+/* ---- vertical merge ----------------------------------------------------- */
+
+/* bayer_orc_merge_bg_* (gstbayerorc.orc:43-66 and the three layout siblings
+ * :95-118, :147-170, :199-222): output row whose even columns carry the
+ * "b"-named sample.  Lines are (ev,od) of the rows above, at and below.
+ * pr/pg/pb = byte position of the "r"-named, green and "b"-named value in the
+ * 4-byte output pixel; the 4th byte is 255 (orc:65 `mergebw ra, r, 255`). */
+static void
+own_merge_bg (uint8_t *d, const uint8_t *ev_u, const uint8_t *od_u,
+    const uint8_t *ev_c, const uint8_t *od_c, const uint8_t *ev_d,
+    const uint8_t *od_d, int npairs, int pr, int pg, int pb)
+{
+  int i, k, pa = 6 - pr - pg - pb;
+  for (i = 0; i < npairs; i++) {
+    for (k = 0; k < 2; k++) {
+      int x = 2 * i + k;
+      uint8_t r = avgub (od_u[x], od_d[x]);       /* orc:57 */
+      uint8_t g = avgub (avgub (ev_u[x], ev_d[x]), od_c[x]);   /* orc:58-60 */
+      if (k == 1)
+        g = od_c[x];                /* orc:61-63: odd pixel keeps g1 */
+      d[4 * x + pb] = ev_c[x];      /* orc:64 */
+      d[4 * x + pg] = g;
+      d[4 * x + pr] = r;
+      d[4 * x + pa] = 255;
+    }
+  }
+}
+
+/* bayer_orc_merge_gr_* (gstbayerorc.orc:69-92, :121-144, :173-196, :225-248):
+ * output row whose even columns are green. */
+static void
+own_merge_gr (uint8_t *d, const uint8_t *ev_u, const uint8_t *od_u,
+    const uint8_t *ev_c, const uint8_t *od_c, const uint8_t *ev_d,
+    const uint8_t *od_d, int npairs, int pr, int pg, int pb)
+{
+  int i, k, pa = 6 - pr - pg - pb;
+  for (i = 0; i < npairs; i++) {
+    for (k = 0; k < 2; k++) {
+      int x = 2 * i + k;
+      uint8_t b = avgub (ev_u[x], ev_d[x]);       /* orc:83 */
+      uint8_t g = avgub (avgub (od_u[x], od_d[x]), ev_c[x]);   /* orc:84-86 */
+      if (k == 0)
+        g = ev_c[x];                /* orc:87-89: even pixel keeps g1 */
+      d[4 * x + pb] = b;
+      d[4 * x + pg] = g;
+      d[4 * x + pr] = od_c[x];      /* orc:91 */
+      d[4 * x + pa] = 255;
+    }
+  }
+}
+
+/* ---- reference row kernels loaded from oracle/_ref ------------------------ */
+
+typedef void (*ref_upsample_fn) (uint8_t *, uint8_t *, const uint8_t *, int);
+typedef void (*ref_merge_fn) (uint8_t *, const uint8_t *, const uint8_t *,
+    const uint8_t *, const uint8_t *, const uint8_t *, const uint8_t *, int);
+
+static struct
+{
+  void *handle;
+  ref_upsample_fn upsample_unaligned;
+  /* [layout][0=bg,1=gr]; layout order bgra, abgr, argb, rgba as in
+   * gstbayer2rgb.c:409-421 */
+  ref_merge_fn merge[4][2];
+} g_ref;
+
+int
+oracle_load_ref_rows (const char *so_path)
+{
+  static const char *names[4][2] = {
+    {"bayer_orc_merge_bg_bgra", "bayer_orc_merge_gr_bgra"},
+    {"bayer_orc_merge_bg_abgr", "bayer_orc_merge_gr_abgr"},
+    {"bayer_orc_merge_bg_argb", "bayer_orc_merge_gr_argb"},
+    {"bayer_orc_merge_bg_rgba", "bayer_orc_merge_gr_rgba"},
+  };
+  int l, t;
+  if (g_ref.handle)
+    return 0;
+  void *h = dlopen (so_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h)
+    return -1;
+  g_ref.upsample_unaligned =
+      (ref_upsample_fn) dlsym (h, "bayer_orc_horiz_upsample_unaligned");
+  if (!g_ref.upsample_unaligned)
+    goto fail;
+  for (l = 0; l < 4; l++)
+    for (t = 0; t < 2; t++) {
+      g_ref.merge[l][t] = (ref_merge_fn) dlsym (h, names[l][t]);
+      if (!g_ref.merge[l][t])
+        goto fail;
+    }
+  g_ref.handle = h;
+  return 0;
+fail:
+  dlclose (h);
+  return -1;
+}
+
+/* gstbayer2rgb.c:354-381 with the body delegated to the reference's kernel */
+static void
+ref_row_lines (uint8_t *ev, uint8_t *od, const uint8_t *s, int w)
+{
+  int x;
+  ev[0] = s[0];
+  od[0] = s[1];
+  ev[1] = avgub (s[0], s[2]);
+  od[1] = s[1];
+  g_ref.upsample_unaligned (ev + 2, od + 2, s + 1, (w - 4) >> 1);
+  for (x = w - 2; x < w; x++) {
+    if ((x & 1) == 0) {
+      ev[x] = s[x];
+      od[x] = s[x - 1];
+    } else {
+      ev[x] = s[x - 1];
+      od[x] = s[x];
+    }
+  }
+}
+
+/* ---- frame driver --------------------------------------------------------- */
+
+/* layout index per gstbayer2rgb.c:409-421, or -1 */
+static int
+layout_of (int r, int g, int b)
+{
+  if (r == 2 && g == 1 && b == 0)
+    return 0;                   /* bgra */
+  if (r == 3 && g == 2 && b == 1)
+    return 1;                   /* abgr */
+  if (r == 1 && g == 2 && b == 3)
+    return 2;                   /* argb */
+  if (r == 0 && g == 1 && b == 2)
+    return 3;                   /* rgba */
+  return -1;
+}
+
+/* gst_bayer2rgb_process, gstbayer2rgb.c:387-451 */
+static int
+frame_driver (uint8_t *dst, int dst_stride, const uint8_t *src, int src_stride,
+    int w, int h, int pattern, int r_off, int g_off, int b_off, int use_ref)
+{
+  int j, layout, swap_rows;
+  uint8_t *ring;
+
+  if (w < 4 || (w & 1) || h < 3)
+    return -1;
+  if (pattern < 0 || pattern > 3)
+    return -1;
+  if (use_ref && !g_ref.handle)
+    return -1;
+
+  /* :400-407 "For RGGB, we swap the red offset and blue offset" (also GBRG) */
+  if (pattern == ORACLE_BAYER_RGGB || pattern == ORACLE_BAYER_GBRG) {
+    int t = r_off;
+    r_off = b_off;
+    b_off = t;
+  }
+  layout = layout_of (r_off, g_off, b_off);     /* :409-421 */
+  if (layout < 0)
+    return -1;
+  /* :422-427 "For GRBG, we swap the order of the merge functions" (also GBRG) */
+  swap_rows = (pattern == ORACLE_BAYER_GRBG || pattern == ORACLE_BAYER_GBRG);
+
+  /* :429-430 eight w-byte lines = ring of 4 rows x (ev, od) */
+  ring = (uint8_t *) malloc ((size_t) 8 * w);
+  if (!ring)
+    return -1;
+#define SLOT(n) (ring + (size_t) ((n) & 7) * w)
+
+  /* :432-436 prime: row 1 stands in for row -1 (slot 3), then row 0 */
+  if (use_ref) {
+    ref_row_lines (SLOT (6), SLOT (7), src + (size_t) src_stride, w);
+    ref_row_lines (SLOT (0), SLOT (1), src, w);
+  } else {
+    own_row_lines (SLOT (6), SLOT (7), src + (size_t) src_stride, w);
+    own_row_lines (SLOT (0), SLOT (1), src, w);
+  }
+
+  /* :438-448 */
+  for (j = 0; j < h; j++) {
+    int type = (j & 1) ^ swap_rows;     /* 0 = merge_bg, 1 = merge_gr */
+    uint8_t *d = dst + (size_t) j * dst_stride;
+    if (j < h - 1) {
+      const uint8_t *s = src + (size_t) (j + 1) * src_stride;
+      if (use_ref)
+        ref_row_lines (SLOT (2 * j + 2), SLOT (2 * j + 3), s, w);
+      else
+        own_row_lines (SLOT (2 * j + 2), SLOT (2 * j + 3), s, w);
+    }
+    if (use_ref) {
+      g_ref.merge[layout][type] (d, SLOT (2 * j - 2), SLOT (2 * j - 1),
+          SLOT (2 * j), SLOT (2 * j + 1), SLOT (2 * j + 2), SLOT (2 * j + 3),
+          w >> 1);
+    } else if (type == 0) {
+      own_merge_bg (d, SLOT (2 * j - 2), SLOT (2 * j - 1), SLOT (2 * j),
+          SLOT (2 * j + 1), SLOT (2 * j + 2), SLOT (2 * j + 3), w >> 1,
+          r_off, g_off, b_off);
+    } else {
+      own_merge_gr (d, SLOT (2 * j - 2), SLOT (2 * j - 1), SLOT (2 * j),
+          SLOT (2 * j + 1), SLOT (2 * j + 2), SLOT (2 * j + 3), w >> 1,
+          r_off, g_off, b_off);
+    }
+  }
+#undef SLOT
+  free (ring);
+  return 0;
+}
+
+int
+oracle_bayer2rgb (uint8_t *dst, int dst_stride, const uint8_t *src,
+    int src_stride, int width, int height, int pattern, int r_off, int g_off,
+    int b_off)
+{
+  return frame_driver (dst, dst_stride, src, src_stride, width, height,
+      pattern, r_off, g_off, b_off, 0);
+}
+
+int
+oracle_bayer2rgb_refrows (uint8_t *dst, int dst_stride, const uint8_t *src,
+    int src_stride, int width, int height, int pattern, int r_off, int g_off,
+    int b_off)
+{
+  return frame_driver (dst, dst_stride, src, src_stride, width, height,
+      pattern, r_off, g_off, b_off, 1);
+}
+
+/* ---- batch (frame-parallel) ------------------------------------------------ */
+
+struct batch_job
+{
+  uint8_t *dst;
+  size_t dst_frame_bytes;
+  int dst_stride;
+  const uint8_t *src;
+  size_t src_frame_bytes;
+  int src_stride;
+  int w, h, pattern, r, g, b, nframes, nthreads, tid, use_ref, rc;
+};
+
+static void *
+batch_worker (void *arg)
+{
+  struct batch_job *jb = (struct batch_job *) arg;
+  int f;
+  for (f = jb->tid; f < jb->nframes; f += jb->nthreads) {
+    int rc = frame_driver (jb->dst + (size_t) f * jb->dst_frame_bytes,
+        jb->dst_stride, jb->src + (size_t) f * jb->src_frame_bytes,
+        jb->src_stride, jb->w, jb->h, jb->pattern, jb->r, jb->g, jb->b,
+        jb->use_ref);
+    if (rc)
+      jb->rc = rc;
+  }
+  return NULL;
+}
+
+int
+oracle_bayer2rgb_batch (uint8_t *dst, size_t dst_frame_bytes, int dst_stride,
+    const uint8_t *src, size_t src_frame_bytes, int src_stride,
+    int width, int height, int pattern, int r_off, int g_off, int b_off,
+    int nframes, int nthreads, int use_ref_rows)
+{
+  int t, rc = 0;
+  if (nthreads < 1)
+    nthreads = 1;
+  if (nthreads > nframes)
+    nthreads = nframes > 0 ? nframes : 1;
+  struct batch_job *jobs = calloc ((size_t) nthreads, sizeof *jobs);
+  pthread_t *th = calloc ((size_t) nthreads, sizeof *th);
+  if (!jobs || !th) {
+    free (jobs);
+    free (th);
+    return -1;
+  }
+  for (t = 0; t < nthreads; t++) {
+    struct batch_job jb = { dst, dst_frame_bytes, dst_stride, src,
+      src_frame_bytes, src_stride, width, height, pattern, r_off, g_off,
+      b_off, nframes, nthreads, t, use_ref_rows, 0
+    };
+    jobs[t] = jb;
+    if (t > 0)
+      pthread_create (&th[t], NULL, batch_worker, &jobs[t]);
+  }
+  batch_worker (&jobs[0]);
+  for (t = 1; t < nthreads; t++)
+    pthread_join (th[t], NULL);
+  for (t = 0; t < nthreads; t++)
+    if (jobs[t].rc)
+      rc = jobs[t].rc;
+  free (jobs);
+  free (th);
+  return rc;
+}
+
+/* ---- synthetic input --------------------------------- */
+
+static inline uint32_t
+fmix32 (uint32_t z)
+{
+  z ^= z >> 16;
+  z *= 0x85EBCA6Bu;
+  z ^= z >> 13;
+  z *= 0xC2B2AE35u;
+  z ^= z >> 16;
+  return z;
+}
+
+void
+oracle_fill_synthetic (uint8_t *buf, int width, int height, int stride,
+    size_t frame_bytes, uint32_t first_frame, int nframes, uint32_t seed)
+{
+  int f, y, x;
+  for (f = 0; f < nframes; f++) {
+    uint8_t *fr = buf + (size_t) f * frame_bytes;
+    uint32_t base = (first_frame + (uint32_t) f) * (uint32_t) height
+        * (uint32_t) width;
+    for (y = 0; y < height; y++) {
+      uint8_t *row = fr + (size_t) y * stride;
+      uint32_t idx = base + (uint32_t) y * (uint32_t) width;
+      for (x = 0; x < width; x++)
+        row[x] = (uint8_t) (fmix32 ((idx + (uint32_t) x) * 2654435761u
+                + seed * 0x9E3779B9u) & 0xffu);
+      for (; x < stride; x++)
+        row[x] = 0;
+    }
+  }
+}

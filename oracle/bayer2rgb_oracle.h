@@ -1,0 +1,70 @@
+/*
+ * TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+ *
+ * CPU restatement of gst-plugins-bad's bayer2rgb frame path, used only as the
+ * parity checker (tests/, __graft_entry__.smoke()) and as the timed
+ * `cpu_baseline` leg of bench.py.  Nothing under gst-plugins-bad_amd/ may
+ * include, link or dlopen this.
+ *
+ * Reference (v1.19.2, /root/reference):
+ *   gst/bayer/gstbayer2rgb.c:354-381   gst_bayer2rgb_split_and_upsample_horiz
+ *   gst/bayer/gstbayer2rgb.c:387-451   gst_bayer2rgb_process
+ *   gst/bayer/gstbayerorc.orc:3-19     bayer_orc_horiz_upsample_unaligned
+ *   gst/bayer/gstbayerorc.orc:43-248   bayer_orc_merge_{bg,gr}_{bgra,abgr,rgba,argb}
+ *
+ * Parity pin: see oracle/README.md (reference row kernels compiled into
+ * oracle/_ref, the md5 known answers of SURVEY.md Appendix B.3 and the
+ * hand-checkable 4x4 frame of Appendix B.4).
+ */
+#ifndef BAYER2RGB_ORACLE_H
+#define BAYER2RGB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same numbering as the reference enum, gstbayer2rgb.c:95-101 */
+enum {
+  ORACLE_BAYER_BGGR = 0,
+  ORACLE_BAYER_GBRG = 1,
+  ORACLE_BAYER_GRBG = 2,
+  ORACLE_BAYER_RGGB = 3
+};
+
+/* One frame.  Arguments mirror gst_bayer2rgb_process (gstbayer2rgb.c:387-389)
+ * with the GstBayer2RGB fields it reads (width, height, format, r/g/b_off)
+ * passed explicitly.  Returns 0, or -1 for geometry outside the domain in
+ * which the reference is well defined (even width >= 4, height >= 3) or an
+ * (r,g,b) offset triple the reference has no merge function for. */
+int oracle_bayer2rgb (uint8_t *dst, int dst_stride,
+    const uint8_t *src, int src_stride,
+    int width, int height, int pattern, int r_off, int g_off, int b_off);
+
+/* Same driver, but every row is computed by the REFERENCE's own compiled row
+ * kernels (gstbayerorc-dist.c built with -DDISABLE_ORC into
+ * oracle/_ref/libbayerorc_ref.so).  Call oracle_load_ref_rows() first. */
+int oracle_load_ref_rows (const char *so_path);
+int oracle_bayer2rgb_refrows (uint8_t *dst, int dst_stride,
+    const uint8_t *src, int src_stride,
+    int width, int height, int pattern, int r_off, int g_off, int b_off);
+
+/* nframes independent frames, frame f on thread (f mod nthreads).
+ * use_ref_rows != 0 selects the reference row kernels. */
+int oracle_bayer2rgb_batch (uint8_t *dst, size_t dst_frame_bytes, int dst_stride,
+    const uint8_t *src, size_t src_frame_bytes, int src_stride,
+    int width, int height, int pattern, int r_off, int g_off, int b_off,
+    int nframes, int nthreads, int use_ref_rows);
+
+/* Counter-based synthetic frames, SURVEY.md Appendix C:
+ * byte(f,y,x) = fmix32((f*H*W + y*W + x) * 2654435761 + seed*0x9E3779B9) & 0xff.
+ * Padding bytes (x >= W) are written as 0. */
+void oracle_fill_synthetic (uint8_t *buf, int width, int height, int stride,
+    size_t frame_bytes, uint32_t first_frame, int nframes, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
