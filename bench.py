@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""bench.py -- bayer2rgb Mpix/s @4K on MI355X, with the HBM roofline and the CPU baseline beside it.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py
+  --gpus N ...`, one rank per GPU.  Rank 0 prints ONE JSON line.
+
+Workload = BASELINE.json configs[2]: 3840x2160, batch = 64 frames per GPU, all four Bayer orders
+(step i converts the batch as order ORDERS[i % 4] -> BGRx; the kernel is the same for all four, only
+its v_perm selectors / row-type swap differ).  A "step" is one pass of the hot path over one batch:
+ONE kernel launch through the C ABI (mibayer_process_device) on frames already resident in HBM.
+Frames are sharded round-robin over ranks (global frame g -> rank g % N), no collective on the data
+path; per-GPU work is fixed as N grows ("weak").
+
+The JSON line also carries
+  roofline     achieved algorithmic GB/s of the kernel (5 B/pixel: 1 read + 4 written) from HIP
+               events on the launch stream over the timed region, against the 8 TB/s HBM3E peak;
+  cpu_baseline the CPU oracle (a port of the reference algorithm, oracle/) timed on this box's host
+               cores on a bounded sample of the same frames (rank 0, N == 1 only).
+The oracle is imported here ONLY for that baseline leg and the parity spot check.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, BATCH = 3840, 2160, 64
+ORDERS = ("bggr", "rggb", "grbg", "gbrg")
+FORMAT = "BGRx"
+SEED = 2                         # config 3 uses seed 2
+BYTES_PER_PIXEL = 5              # algorithmic: 1 B mosaic read + 4 B RGBx written
+HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+# ----------------------------------------------------------------------------------------------
+# distributed harness (also exercised on CPU with gloo, tests/test_sharding.py)
+# ----------------------------------------------------------------------------------------------
+
+def shard_frames(total_frames, world_size, rank):
+    """Round-robin frame -> rank map of the north star: global frame g runs on rank g % N."""
+    return list(range(rank, total_frames, world_size))
+
+
+def timed_region(step_fn, steps, warmup, sync_fn, dist=None):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both
+    sides.  Returns the MAX over ranks of the elapsed seconds."""
+    for i in range(warmup):
+        step_fn(i)
+    sync_fn()
+    if dist is not None:
+        dist.barrier()
+    sync_fn()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(warmup + i)
+    sync_fn()
+    if dist is not None:
+        dist.barrier()
+    sync_fn()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def aggregate_mpix_per_s(pixels_per_step_per_rank, world_size, steps, elapsed_s):
+    return pixels_per_step_per_rank * world_size * steps / elapsed_s / 1e6
+
+
+# ----------------------------------------------------------------------------------------------
+# CPU baseline (oracle) -- reported beside the GPU number, never the thing optimised
+# ----------------------------------------------------------------------------------------------
+
+def cpu_baseline(budget_s=12.0, sample_frames=16):
+    import __graft_entry__ as entry
+    oracle = entry.load_oracle()
+    ncores = os.cpu_count() or 1
+    src = oracle.fill_synthetic(WIDTH, HEIGHT, sample_frames, SEED)
+    r, g, b = oracle.LAYOUTS[FORMAT]
+    oracle.bayer2rgb_batch(src[:1], WIDTH, "rggb", r, g, b, nthreads=1)      # warm-up / page-in
+
+    def run(nthreads, budget):
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            oracle.bayer2rgb_batch(src, WIDTH, ORDERS[reps % 4], r, g, b, nthreads=nthreads)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget:
+                return WIDTH * HEIGHT * sample_frames * reps / el / 1e6, reps, el
+
+    v1, reps1, el1 = run(1, budget_s * 0.6)
+    vn, repsn, eln = run(ncores, budget_s * 0.4)
+    return {
+        "value": round(v1, 1), "unit": "Mpix/s", "cores": 1, "kind": "port",
+        "sample": "%d of the %d 4K frames (seed %d, frames 0-%d) -> %s, all 4 orders cycled, "
+                  "%d passes in %.1f s, oracle/bayer2rgb_oracle.c gcc -O3, 1 thread (the reference "
+                  "element is single-threaded per stream)" % (
+                      sample_frames, BATCH, SEED, sample_frames - 1, FORMAT, reps1, el1),
+        "all_cores": {"value": round(vn, 1), "cores": ncores, "passes": repsn,
+                      "note": "frame-parallel pthreads"},
+    }
+
+
+# ----------------------------------------------------------------------------------------------
+# GPU benchmark
+# ----------------------------------------------------------------------------------------------
+
+def parity_spot_check(pkg, ctxs, d_src, d_dst, rank, world, stream):
+    """Frame 0 and the last frame of this rank's batch, order rggb, against the oracle."""
+    import numpy as np
+    import torch
+    import __graft_entry__ as entry
+    oracle = entry.load_oracle()
+    ctx = ctxs["rggb"]
+    ctx.process_device(d_src.data_ptr(), d_dst.data_ptr(), BATCH, stream=stream)
+    torch.cuda.synchronize()
+    r, g, b = oracle.LAYOUTS[FORMAT]
+    for local in (0, BATCH - 1):
+        gframe = rank + local * world
+        src = oracle.fill_synthetic(WIDTH, HEIGHT, 1, SEED, first_frame=gframe)[0]
+        want = oracle.bayer2rgb(src, WIDTH, "rggb", r, g, b).reshape(-1)
+        got = d_dst[local * ctx.dst_bytes:(local + 1) * ctx.dst_bytes].cpu().numpy()
+        if not np.array_equal(got, want):
+            raise AssertionError("bench parity check failed: rank %d local frame %d differs from "
+                                 "the oracle in %d bytes" % (rank, local, int((got != want).sum())))
+    return "bit-exact vs oracle on frames %d and %d of the batch (rggb->%s)" % (0, BATCH - 1, FORMAT)
+
+
+def host_path_rate(pkg, device, frames=24, inflight=3):
+    """PCIe-inclusive rate of the host path (pinned buffers, async ring).  Reported as a note only;
+    it is never `value`."""
+    import ctypes
+    import numpy as np
+    L = pkg.lib()
+    with pkg.Context(WIDTH, HEIGHT, "rggb", FORMAT, device=device, inflight=inflight) as ctx:
+        srcs, dsts = [], []
+        for _ in range(inflight):
+            ps, pd = L.mibayer_host_alloc(ctx.src_bytes), L.mibayer_host_alloc(ctx.dst_bytes)
+            s = np.ctypeslib.as_array(ctypes.cast(ps, ctypes.POINTER(ctypes.c_uint8)), (ctx.src_bytes,))
+            d = np.ctypeslib.as_array(ctypes.cast(pd, ctypes.POINTER(ctypes.c_uint8)), (ctx.dst_bytes,))
+            s[:] = 0x55
+            srcs.append((ps, s))
+            dsts.append((pd, d))
+        for phase in ("warm", "timed"):
+            n = inflight if phase == "warm" else frames
+            t0 = time.perf_counter()
+            for i in range(n):
+                if ctx.pending() == inflight:
+                    ctx.wait()
+                ctx.submit(srcs[i % inflight][1], dsts[i % inflight][1], tag=i + 1)
+            while ctx.pending():
+                ctx.wait()
+            el = time.perf_counter() - t0
+        for (ps, _), (pd, _) in zip(srcs, dsts):
+            L.mibayer_host_free(ps)
+            L.mibayer_host_free(pd)
+    return {"value": round(WIDTH * HEIGHT * frames / el / 1e6, 1), "unit": "Mpix/s",
+            "note": "host->host incl. H2D + D2H over PCIe, hipHostMalloc-pinned buffers, %d frames in "
+                    "flight, %d 4K frames; bound by PCIe (~5 B/pixel over a ~55 GB/s link), not HBM"
+                    % (inflight, frames)}
+
+
+def run(args):
+    import torch
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available() or pkg.device_count() < 1:
+        raise SystemExit("bench.py: no MI355X visible; the bayer2rgb path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    variant = args.variant
+    ctxs = {o: pkg.Context(WIDTH, HEIGHT, o, FORMAT, device=local_rank, variant=variant) for o in ORDERS}
+    ctx0 = ctxs[ORDERS[0]]
+    stream = torch.cuda.current_stream().cuda_stream
+    d_src = torch.empty(BATCH * ctx0.src_bytes, dtype=torch.uint8, device="cuda")
+    d_dst = torch.empty(BATCH * ctx0.dst_bytes, dtype=torch.uint8, device="cuda")
+    # synthetic frames generated in HBM: this rank's i-th frame is global frame rank + i*world
+    for i, gframe in enumerate(shard_frames(BATCH * world, world, rank)):
+        ctx0.fill_synthetic(d_src.data_ptr() + i * ctx0.src_bytes, 1, SEED, first_frame=gframe,
+                            stream=stream)
+    torch.cuda.synchronize()
+    parity = parity_spot_check(pkg, ctxs, d_src, d_dst, rank, world, stream)
+
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    state = {"first_timed": args.warmup}
+
+    def step(i):
+        if i == state["first_timed"]:
+            ev0.record()
+        ctxs[ORDERS[i % 4]].process_device(d_src.data_ptr(), d_dst.data_ptr(), BATCH, stream=stream)
+        if i == state["first_timed"] + args.steps - 1:
+            ev1.record()
+
+    elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, dist)
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps       # HIP events on the launch stream
+    pixels = WIDTH * HEIGHT * BATCH
+    value = aggregate_mpix_per_s(pixels, world, args.steps, elapsed)
+    achieved = BYTES_PER_PIXEL * pixels / (kernel_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "bayer2rgb Mpix/s @4K (device-resident batch)",
+        "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic (counter-based PRNG frames generated in HBM, seed %d)" % SEED,
+        "config": {"workload": "3840x2160 x 64 frames per GPU, bggr/rggb/grbg/gbrg -> BGRx cycled per step "
+                               "(BASELINE.json configs[2]), one launch per step, frames sharded round-robin "
+                               "over ranks, no collective",
+                   "kernel_variant": pkg.variant_names()[variant], "parity": parity},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * pixels},
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(traffic_file):
+        try:
+            with open(traffic_file) as f:
+                t = json.load(f)
+            result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+            result["roofline"]["traffic_source"] = t.get("source")
+        except Exception:
+            pass
+    if rank == 0 and world == 1:
+        if not args.no_host_path:
+            for c in ctxs.values():
+                c.sync()
+            result["host_path"] = host_path_rate(pkg, local_rank)
+        if not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    for c in ctxs.values():
+        c.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--variant", type=int, default=int(os.environ.get("MIBAYER_VARIANT", "0")))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # convenience: self-launch one rank per GPU the way the driver does
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    run(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,286 @@
+"""gst-plugins-bad_amd -- MI355X-native `bayer2rgb` (hot path of gst-plugins-bad's bayer plugin).
+
+The product is native code:
+
+  libmibayer.so   hand-written HIP kernels for gfx950 + the C ABI of include/mibayer.h
+                  (csrc/mibayer_kernels.hip, csrc/mibayer_abi.hip)
+  libgstbayer.so  GStreamer plugin `bayer`, element `bayer2rgb`: registration, pad templates and
+                  caps negotiation identical to reference gst/bayer/gstbayer2rgb.c, `transform`
+                  calling the C ABI (gst/gstbayer2rgb.c)
+
+This Python module is only the ctypes harness that tests/ and bench.py use to drive the C ABI
+(the directory name is not an importable identifier; load it through
+`__graft_entry__.load_package()`, which registers it as `gst_plugins_bad_amd`).  There is no Python
+or CPU compute path here: every compute call goes to libmibayer.so and raises `MibayerError` if the
+library or a GPU is missing.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libmibayer.so")
+PLUGIN_PATH = os.path.join(HERE, "libgstbayer.so")
+HEADER_PATH = os.path.join(ROOT, "include", "mibayer.h")
+
+# Bayer orders, numbering of reference gstbayer2rgb.c:95-101
+PATTERNS = {"bggr": 0, "gbrg": 1, "grbg": 2, "rggb": 3}
+# (r_off, g_off, b_off) = GST_VIDEO_INFO_COMP_OFFSET of the 8 src-template formats,
+# reference gstbayer2rgb.c:134-135, :268-271
+FORMATS = {
+    "RGBx": (0, 1, 2), "xRGB": (1, 2, 3), "BGRx": (2, 1, 0), "xBGR": (3, 2, 1),
+    "RGBA": (0, 1, 2), "ARGB": (1, 2, 3), "BGRA": (2, 1, 0), "ABGR": (3, 2, 1),
+}
+
+OK = 0
+ERR_ARG, ERR_GEOMETRY, ERR_LAYOUT, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_BUSY, ERR_EMPTY = (
+    -1, -2, -3, -4, -5, -6, -7, -8)
+
+
+class MibayerError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        msg = "mibayer status %d" % status
+        try:
+            L = lib()
+            msg = L.mibayer_strerror(status).decode()
+            hip = L.mibayer_last_hip_error().decode()
+            if status == ERR_HIP and hip:
+                msg += " [" + hip + "]"
+        except Exception:  # pragma: no cover - library itself unavailable
+            pass
+        super().__init__(("%s: " % where if where else "") + msg)
+
+
+class Cfg(ctypes.Structure):
+    """struct mibayer_cfg (include/mibayer.h)."""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("src_stride", ctypes.c_int32), ("dst_stride", ctypes.c_int32),
+        ("pattern", ctypes.c_int32),
+        ("r_off", ctypes.c_int32), ("g_off", ctypes.c_int32), ("b_off", ctypes.c_int32),
+        ("device", ctypes.c_int32), ("inflight", ctypes.c_int32), ("variant", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+    ]
+
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_vp = ctypes.c_void_p
+_lib = None
+
+# every symbol include/mibayer.h declares: name -> (restype, argtypes)
+ABI = {
+    "mibayer_abi_version": (ctypes.c_int, []),
+    "mibayer_device_count": (ctypes.c_int, []),
+    "mibayer_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "mibayer_last_hip_error": (ctypes.c_char_p, []),
+    "mibayer_create": (ctypes.c_int, [ctypes.POINTER(Cfg), ctypes.POINTER(_vp)]),
+    "mibayer_destroy": (None, [_vp]),
+    "mibayer_get_cfg": (ctypes.c_int, [_vp, ctypes.POINTER(Cfg)]),
+    "mibayer_process_host": (ctypes.c_int, [_vp, _vp, _vp]),
+    "mibayer_submit": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "mibayer_wait": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "mibayer_pending": (ctypes.c_int, [_vp]),
+    "mibayer_process_device": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
+                                              ctypes.c_int, _vp]),
+    "mibayer_sync": (ctypes.c_int, [_vp]),
+    "mibayer_time_device": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(ctypes.c_float)]),
+    "mibayer_host_alloc": (_vp, [ctypes.c_size_t]),
+    "mibayer_host_free": (None, [_vp]),
+    "mibayer_device_alloc": (_vp, [_vp, ctypes.c_size_t]),
+    "mibayer_device_free": (None, [_vp, _vp]),
+    "mibayer_copy_to_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "mibayer_copy_from_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "mibayer_fill_synthetic": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_uint32,
+                                              ctypes.c_int, ctypes.c_uint32, _vp]),
+    "mibayer_variant_count": (ctypes.c_int, []),
+    "mibayer_variant_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "mibayer_launch_geometry": (ctypes.c_int, [_vp, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 4),
+    "mibayer_block_to_tile": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64]),
+}
+
+
+def build(quiet=True):
+    """Compile libmibayer.so (hipcc, gfx950) and, when GStreamer headers exist, libgstbayer.so."""
+    subprocess.run(["make", "-C", HERE, "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def lib():
+    """The C ABI.  Fails loudly when the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MibayerErrorNoLib(
+                "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in ABI.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.mibayer_abi_version() != 1:
+            raise MibayerErrorNoLib("libmibayer.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+class MibayerErrorNoLib(RuntimeError):
+    pass
+
+
+def device_count():
+    return lib().mibayer_device_count()
+
+
+def variant_names():
+    L = lib()
+    return [L.mibayer_variant_name(i).decode() for i in range(L.mibayer_variant_count())]
+
+
+def _check(rc, where):
+    if rc != OK:
+        raise MibayerError(rc, where)
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One negotiated stream == one mibayer_ctx (what the element creates in set_caps).
+
+    `fmt` is a GStreamer video format name of the src template (RGBx, BGRx, ...) or an explicit
+    (r_off, g_off, b_off) triple.
+    """
+
+    def __init__(self, width, height, pattern="bggr", fmt="RGBx", src_stride=0, dst_stride=0,
+                 device=-1, inflight=0, variant=0):
+        r, g, b = FORMATS[fmt] if isinstance(fmt, str) else fmt
+        pat = PATTERNS[pattern] if isinstance(pattern, str) else int(pattern)
+        cfg = Cfg(ctypes.sizeof(Cfg), width, height, src_stride, dst_stride, pat, r, g, b,
+                  device, inflight, variant, 0)
+        self._h = _vp()
+        _check(lib().mibayer_create(ctypes.byref(cfg), ctypes.byref(self._h)), "mibayer_create")
+        out = Cfg()
+        _check(lib().mibayer_get_cfg(self._h, ctypes.byref(out)), "mibayer_get_cfg")
+        self.cfg = out
+        self.width, self.height = out.width, out.height
+        self.src_stride, self.dst_stride = out.src_stride, out.dst_stride
+        self.src_bytes = out.src_stride * out.height
+        self.dst_bytes = out.dst_stride * out.height
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mibayer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- host path --------------------------------------------------------------------------
+    def process_host(self, src, dst=None):
+        """src: uint8 array of src_stride*height bytes -> (height, dst_stride) uint8."""
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        assert src.size == self.src_bytes, (src.size, self.src_bytes)
+        if dst is None:
+            dst = np.full((self.height, self.dst_stride), 0xA5, np.uint8)
+        assert dst.size == self.dst_bytes and dst.flags.c_contiguous
+        _check(lib().mibayer_process_host(self._h, _ptr(src), _ptr(dst)), "mibayer_process_host")
+        return dst
+
+    def submit(self, src, dst, tag=0):
+        _check(lib().mibayer_submit(self._h, _ptr(src), _ptr(dst), _vp(tag)), "mibayer_submit")
+
+    def wait(self):
+        tag = _vp()
+        _check(lib().mibayer_wait(self._h, ctypes.byref(tag)), "mibayer_wait")
+        return tag.value or 0
+
+    def pending(self):
+        return lib().mibayer_pending(self._h)
+
+    # -- device path ------------------------------------------------------------------------
+    def device_alloc(self, nbytes):
+        p = lib().mibayer_device_alloc(self._h, nbytes)
+        if not p:
+            raise MibayerError(ERR_NOMEM, "mibayer_device_alloc(%d)" % nbytes)
+        return p
+
+    def device_free(self, p):
+        lib().mibayer_device_free(self._h, _vp(p))
+
+    def to_device(self, d_dst, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(lib().mibayer_copy_to_device(self._h, _vp(d_dst), _ptr(arr), arr.nbytes),
+               "mibayer_copy_to_device")
+
+    def from_device(self, d_src, nbytes):
+        out = np.empty(nbytes, np.uint8)
+        _check(lib().mibayer_copy_from_device(self._h, _ptr(out), _vp(d_src), nbytes),
+               "mibayer_copy_from_device")
+        return out
+
+    def process_device(self, d_src, d_dst, nframes=1, src_frame_bytes=None, dst_frame_bytes=None,
+                       stream=None):
+        _check(lib().mibayer_process_device(
+            self._h, _vp(d_src), src_frame_bytes or self.src_bytes, _vp(d_dst),
+            dst_frame_bytes or self.dst_bytes, nframes, _vp(stream or 0)), "mibayer_process_device")
+
+    def sync(self):
+        _check(lib().mibayer_sync(self._h), "mibayer_sync")
+
+    def time_device(self, d_src, d_dst, nframes, warmup=2, reps=10, src_frame_bytes=None,
+                    dst_frame_bytes=None):
+        ms = ctypes.c_float()
+        _check(lib().mibayer_time_device(
+            self._h, _vp(d_src), src_frame_bytes or self.src_bytes, _vp(d_dst),
+            dst_frame_bytes or self.dst_bytes, nframes, warmup, reps, ctypes.byref(ms)),
+            "mibayer_time_device")
+        return ms.value
+
+    def fill_synthetic(self, d_src, nframes, seed, first_frame=0, src_frame_bytes=None, stream=None):
+        _check(lib().mibayer_fill_synthetic(
+            self._h, _vp(d_src), src_frame_bytes or self.src_bytes, first_frame, nframes, seed,
+            _vp(stream or 0)), "mibayer_fill_synthetic")
+
+    def launch_geometry(self, nframes=1):
+        v = [ctypes.c_int() for _ in range(4)]
+        _check(lib().mibayer_launch_geometry(self._h, nframes, *[ctypes.byref(x) for x in v]),
+               "mibayer_launch_geometry")
+        return dict(zip(("tile_w", "tile_h", "tiles_per_frame", "grid_blocks"), [x.value for x in v]))
+
+    # -- convenience for tests ---------------------------------------------------------------
+    def process_batch_via_device(self, frames):
+        """frames: (N, height, src_stride) uint8 on the host -> (N, height, dst_stride) uint8,
+        through ONE device-resident batch launch (mibayer_process_device)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n = frames.shape[0]
+        assert frames[0].size == self.src_bytes
+        d_src = self.device_alloc(n * self.src_bytes)
+        d_dst = self.device_alloc(n * self.dst_bytes)
+        try:
+            self.to_device(d_src, frames)
+            self.process_device(d_src, d_dst, n)
+            self.sync()
+            out = self.from_device(d_dst, n * self.dst_bytes)
+        finally:
+            self.device_free(d_src)
+            self.device_free(d_dst)
+        return out.reshape(n, self.height, self.dst_stride)

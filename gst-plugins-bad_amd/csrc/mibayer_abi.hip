@@ -1,0 +1,675 @@
+/*
+ * C-ABI shim of the MI355X bayer2rgb path (include/mibayer.h).
+ *
+ * Host-side replacement for the body of gst_bayer2rgb_process
+ * (reference gst/bayer/gstbayer2rgb.c:387-451): what the reference does per
+ * frame on the streaming thread -- pick the merge pair from the byte layout and
+ * the Bayer order (:400-427), allocate scratch (:429), loop over rows (:438-448)
+ * -- becomes, here, a per-stream plan computed once in mibayer_create() (v_perm
+ * selectors, row-type swap, tile grid) and one kernel launch per frame or batch.
+ * No CPU compute path exists in this library.
+ */
+#include "../../include/mibayer.h"
+#include "mibayer_internal.h"
+
+#include <mutex>
+#include <new>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+using namespace mibayer;
+
+namespace {
+
+thread_local char t_hip_error[256] = "";
+
+bool hip_failed (hipError_t e, const char *what)
+{
+  if (e == hipSuccess)
+    return false;
+  snprintf (t_hip_error, sizeof t_hip_error, "%s: %s (%d)", what,
+      hipGetErrorString (e), (int) e);
+  return true;
+}
+
+#define HIP_TRY(expr)                                                          \
+  do {                                                                         \
+    if (hip_failed ((expr), #expr))                                            \
+      return MIBAYER_ERR_HIP;                                                  \
+  } while (0)
+
+/* hipSetDevice is per-thread state: select the context's device for the call
+ * and put the caller's device back afterwards. */
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard (int dev)
+  {
+    if (hipGetDevice (&prev) != hipSuccess)
+      prev = -1;
+    if (prev != dev)
+      ok = !hip_failed (hipSetDevice (dev), "hipSetDevice");
+    else
+      prev = -1;
+  }
+  ~DeviceGuard ()
+  {
+    if (prev >= 0)
+      (void) hipSetDevice (prev);
+  }
+};
+
+struct Slot {
+  uint8_t *d_src = nullptr;
+  uint8_t *d_dst = nullptr;
+  hipEvent_t ev_in = nullptr;     /* H2D done   */
+  hipEvent_t ev_kernel = nullptr; /* kernel done */
+  hipEvent_t ev_out = nullptr;    /* D2H done   */
+  void *tag = nullptr;
+};
+
+int device_count_cached ()
+{
+  static int n = -1;
+  static std::once_flag once;
+  std::call_once (once, [] {
+    int c = 0;
+    if (hipGetDeviceCount (&c) != hipSuccess)
+      c = 0;
+    n = c;
+  });
+  return n;
+}
+
+}  /* namespace */
+
+struct mibayer_ctx {
+  mibayer_cfg cfg;
+  int device = 0;
+  size_t src_bytes = 0;         /* one frame */
+  size_t dst_bytes = 0;
+  /* plan */
+  uint32_t sel[4];
+  int swap_rows = 0;
+  const Variant *var = nullptr;
+  /* streams: uploads, kernels and downloads each get their own queue so that
+   * frame n+1's H2D overlaps frame n's kernel and frame n-1's D2H */
+  hipStream_t s_h2d = nullptr;
+  hipStream_t s_compute = nullptr;
+  hipStream_t s_d2h = nullptr;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+  std::vector<Slot> ring;
+  int head = 0;                 /* next slot to submit into */
+  int tail = 0;                 /* oldest in-flight slot    */
+  int pending = 0;
+};
+
+/* ---- plan ----------------------------------------------------------------- */
+
+/* Byte layout check == the reference's merge-pair selection, which only knows
+ * these four (r,g,b) triples (gstbayer2rgb.c:409-421). */
+static bool layout_known (int r, int g, int b)
+{
+  return (r == 2 && g == 1 && b == 0) || (r == 3 && g == 2 && b == 1)
+      || (r == 1 && g == 2 && b == 3) || (r == 0 && g == 1 && b == 2);
+}
+
+static void make_plan (mibayer_ctx *c)
+{
+  const mibayer_cfg &f = c->cfg;
+  int rp = f.r_off, bp = f.b_off, gp = f.g_off;
+  /* "For RGGB, we swap the red offset and blue offset in the output.  For
+   * GRBG, we swap the order of the merge functions.  For GBRG, do both."
+   * (gstbayer2rgb.c:396-407, :422-427) */
+  if (f.pattern == MIBAYER_RGGB || f.pattern == MIBAYER_GBRG) {
+    int t = rp;
+    rp = bp;
+    bp = t;
+  }
+  c->swap_rows = (f.pattern == MIBAYER_GRBG || f.pattern == MIBAYER_GBRG);
+  const int ap = 6 - rp - gp - bp;
+  /* output pixel k = v_perm_b32 (M, G, sel[k]) with
+   *   M = [r' b' r' b'] of pixels (k&~1), (k|1)  -> bytes 4..7 of {M,G}
+   *   G = green of pixels 0..3                   -> bytes 0..3 of {M,G}
+   * selector 0x0d yields the constant 0xff (orc:65 `mergebw ra, r, 255`). */
+  for (int k = 0; k < 4; k++) {
+    uint32_t s = 0;
+    s |= (uint32_t) (4 + 2 * (k & 1)) << (8 * rp);
+    s |= (uint32_t) (5 + 2 * (k & 1)) << (8 * bp);
+    s |= (uint32_t) k << (8 * gp);
+    s |= (uint32_t) 0x0d << (8 * ap);
+    c->sel[k] = s;
+  }
+}
+
+static bool aligned16 (const void *p)
+{
+  return (((uintptr_t) p) & 15u) == 0;
+}
+
+static void fill_params (const mibayer_ctx *c, KParams &p, const void *d_src,
+    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes)
+{
+  const mibayer_cfg &f = c->cfg;
+  p.src = (const uint8_t *) d_src;
+  p.dst = (uint8_t *) d_dst;
+  p.src_frame_bytes = src_frame_bytes;
+  p.dst_frame_bytes = dst_frame_bytes;
+  p.width = f.width;
+  p.height = f.height;
+  p.src_stride = f.src_stride;
+  p.dst_stride = f.dst_stride;
+  p.wlimit4 = (f.width + 3) & ~3;
+  p.dn_last = f.height >= 4 ? f.height - 4 : 1;   /* ring slot reuse, :430-447 */
+  p.tiles_x = (f.width + c->var->tile_w - 1) / c->var->tile_w;
+  p.tiles_y = (f.height + c->var->tile_h - 1) / c->var->tile_h;
+  p.ntiles = (long long) nframes * p.tiles_x * p.tiles_y;
+  p.chunk = (p.ntiles + kNumXcd - 1) / kNumXcd;
+  for (int k = 0; k < 4; k++)
+    p.sel[k] = c->sel[k];
+  p.swap_rows = c->swap_rows;
+}
+
+static int launch (mibayer_ctx *c, const void *d_src, size_t src_frame_bytes,
+    void *d_dst, size_t dst_frame_bytes, int nframes, hipStream_t stream)
+{
+  if (nframes == 0)
+    return MIBAYER_OK;
+  KParams p;
+  fill_params (c, p, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes);
+  const mibayer_cfg &f = c->cfg;
+  const bool fast = (f.width % 16 == 0) && (f.src_stride % 16 == 0)
+      && (f.dst_stride % 16 == 0) && aligned16 (d_src) && aligned16 (d_dst)
+      && (nframes == 1 || (src_frame_bytes % 16 == 0
+              && dst_frame_bytes % 16 == 0));
+  void (*kern) (KParams) = fast ? c->var->fast : c->var->generic;
+  const long long grid = p.chunk * kNumXcd;
+  if (grid > 0x7fffffffLL)
+    return MIBAYER_ERR_GEOMETRY;
+  hipLaunchKernelGGL (kern, dim3 ((unsigned) grid), dim3 (c->var->threads), 0,
+      stream, p);
+  HIP_TRY (hipGetLastError ());
+  return MIBAYER_OK;
+}
+
+/* ---- global ------------------------------------------------------------------ */
+
+extern "C" int mibayer_abi_version (void)
+{
+  return MIBAYER_ABI_VERSION;
+}
+
+extern "C" int mibayer_device_count (void)
+{
+  return device_count_cached ();
+}
+
+extern "C" const char *mibayer_strerror (int status)
+{
+  switch (status) {
+    case MIBAYER_OK: return "ok";
+    case MIBAYER_ERR_ARG: return "invalid argument";
+    case MIBAYER_ERR_GEOMETRY:
+      return "unsupported geometry (need even width >= 4, height >= 3, "
+          "strides multiple of 4 and large enough)";
+    case MIBAYER_ERR_LAYOUT:
+      return "unsupported (r,g,b) byte offsets (need RGBx/BGRx/xRGB/xBGR order)";
+    case MIBAYER_ERR_NO_DEVICE: return "no usable HIP device";
+    case MIBAYER_ERR_HIP: return "HIP runtime error";
+    case MIBAYER_ERR_NOMEM: return "out of memory";
+    case MIBAYER_ERR_BUSY: return "frames in flight: ring full or busy";
+    case MIBAYER_ERR_EMPTY: return "no frame in flight";
+    default: return "unknown mibayer status";
+  }
+}
+
+extern "C" const char *mibayer_last_hip_error (void)
+{
+  return t_hip_error;
+}
+
+extern "C" int mibayer_variant_count (void)
+{
+  return variant_count ();
+}
+
+extern "C" const char *mibayer_variant_name (int v)
+{
+  if (v < 0 || v >= variant_count ())
+    return NULL;
+  return variant (v).name;
+}
+
+extern "C" int64_t mibayer_block_to_tile (int64_t block, int64_t ntiles)
+{
+  if (block < 0 || ntiles <= 0)
+    return -1;
+  return block_to_tile (block, ntiles, (ntiles + kNumXcd - 1) / kNumXcd);
+}
+
+/* ---- context -------------------------------------------------------------------- */
+
+static int validate (const mibayer_cfg *in, mibayer_cfg *out)
+{
+  if (!in || in->struct_size != sizeof (mibayer_cfg))
+    return MIBAYER_ERR_ARG;
+  mibayer_cfg f = *in;
+  if (f.pattern < MIBAYER_BGGR || f.pattern > MIBAYER_RGGB)
+    return MIBAYER_ERR_ARG;
+  if (f.flags != 0)
+    return MIBAYER_ERR_ARG;
+  if (f.variant < 0 || f.variant >= variant_count ())
+    return MIBAYER_ERR_ARG;
+  if (f.inflight < 0 || f.inflight > 64)
+    return MIBAYER_ERR_ARG;
+  if (f.width < 4 || (f.width & 1) || f.height < 3)
+    return MIBAYER_ERR_GEOMETRY;
+  if (f.width > (1 << 28) || f.height > (1 << 28))
+    return MIBAYER_ERR_GEOMETRY;
+  if (f.src_stride == 0)
+    f.src_stride = (f.width + 3) & ~3;  /* GST_ROUND_UP_4, gstbayer2rgb.c:477 */
+  if (f.dst_stride == 0)
+    f.dst_stride = 4 * f.width;         /* gstbayer2rgb.c:344 */
+  if (f.src_stride < ((f.width + 3) & ~3) || (f.src_stride & 3))
+    return MIBAYER_ERR_GEOMETRY;
+  if (f.dst_stride < 4 * f.width || (f.dst_stride & 3))
+    return MIBAYER_ERR_GEOMETRY;
+  if (!layout_known (f.r_off, f.g_off, f.b_off))
+    return MIBAYER_ERR_LAYOUT;
+  if (f.inflight == 0)
+    f.inflight = 2;
+  *out = f;
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
+{
+  if (!out)
+    return MIBAYER_ERR_ARG;
+  *out = NULL;
+  mibayer_cfg f;
+  int rc = validate (cfg, &f);
+  if (rc != MIBAYER_OK)
+    return rc;
+  const int ndev = device_count_cached ();
+  if (ndev <= 0)
+    return MIBAYER_ERR_NO_DEVICE;
+  int dev = f.device;
+  if (dev == -1) {
+    if (hip_failed (hipGetDevice (&dev), "hipGetDevice"))
+      return MIBAYER_ERR_HIP;
+  }
+  if (dev < 0 || dev >= ndev)
+    return MIBAYER_ERR_NO_DEVICE;
+  f.device = dev;
+
+  mibayer_ctx *c = new (std::nothrow) mibayer_ctx ();
+  if (!c)
+    return MIBAYER_ERR_NOMEM;
+  c->cfg = f;
+  c->device = dev;
+  c->src_bytes = (size_t) f.src_stride * f.height;
+  c->dst_bytes = (size_t) f.dst_stride * f.height;
+  c->var = &variant (f.variant);
+  make_plan (c);
+
+  DeviceGuard guard (dev);
+  if (!guard.ok) {
+    delete c;
+    return MIBAYER_ERR_HIP;
+  }
+  bool bad = false;
+  bad |= hip_failed (hipStreamCreateWithFlags (&c->s_h2d,
+          hipStreamNonBlocking), "hipStreamCreate");
+  bad |= hip_failed (hipStreamCreateWithFlags (&c->s_compute,
+          hipStreamNonBlocking), "hipStreamCreate");
+  bad |= hip_failed (hipStreamCreateWithFlags (&c->s_d2h,
+          hipStreamNonBlocking), "hipStreamCreate");
+  bad |= hip_failed (hipEventCreate (&c->ev_t0), "hipEventCreate");
+  bad |= hip_failed (hipEventCreate (&c->ev_t1), "hipEventCreate");
+  if (bad) {
+    mibayer_destroy (c);
+    return MIBAYER_ERR_HIP;
+  }
+  /* the device-side frame ring of the host path is allocated on first use, so
+   * that device-resident callers do not pay for it */
+  *out = c;
+  return MIBAYER_OK;
+}
+
+static void free_ring (mibayer_ctx *c)
+{
+  for (Slot &s : c->ring) {
+    if (s.d_src)
+      (void) hipFree (s.d_src);
+    if (s.d_dst)
+      (void) hipFree (s.d_dst);
+    if (s.ev_in)
+      (void) hipEventDestroy (s.ev_in);
+    if (s.ev_kernel)
+      (void) hipEventDestroy (s.ev_kernel);
+    if (s.ev_out)
+      (void) hipEventDestroy (s.ev_out);
+  }
+  c->ring.clear ();
+}
+
+extern "C" void mibayer_destroy (mibayer_ctx *c)
+{
+  if (!c)
+    return;
+  DeviceGuard guard (c->device);
+  if (c->s_h2d)
+    (void) hipStreamSynchronize (c->s_h2d);
+  if (c->s_compute)
+    (void) hipStreamSynchronize (c->s_compute);
+  if (c->s_d2h)
+    (void) hipStreamSynchronize (c->s_d2h);
+  free_ring (c);
+  if (c->ev_t0)
+    (void) hipEventDestroy (c->ev_t0);
+  if (c->ev_t1)
+    (void) hipEventDestroy (c->ev_t1);
+  if (c->s_h2d)
+    (void) hipStreamDestroy (c->s_h2d);
+  if (c->s_compute)
+    (void) hipStreamDestroy (c->s_compute);
+  if (c->s_d2h)
+    (void) hipStreamDestroy (c->s_d2h);
+  delete c;
+}
+
+extern "C" int mibayer_get_cfg (const mibayer_ctx *c, mibayer_cfg *out)
+{
+  if (!c || !out)
+    return MIBAYER_ERR_ARG;
+  *out = c->cfg;
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_launch_geometry (const mibayer_ctx *c, int nframes,
+    int *tile_w, int *tile_h, int *tiles_per_frame, int *grid_blocks)
+{
+  if (!c || nframes < 0)
+    return MIBAYER_ERR_ARG;
+  KParams p;
+  fill_params (c, p, NULL, 0, NULL, 0, nframes);
+  if (tile_w)
+    *tile_w = c->var->tile_w;
+  if (tile_h)
+    *tile_h = c->var->tile_h;
+  if (tiles_per_frame)
+    *tiles_per_frame = p.tiles_x * p.tiles_y;
+  if (grid_blocks)
+    *grid_blocks = (int) (p.chunk * kNumXcd);
+  return MIBAYER_OK;
+}
+
+/* ---- host-memory frame path -------------------------------------------------------- */
+
+static int ensure_ring (mibayer_ctx *c)
+{
+  if (!c->ring.empty ())
+    return MIBAYER_OK;
+  c->ring.resize ((size_t) c->cfg.inflight);
+  for (Slot &s : c->ring) {
+    bool bad = false;
+    bad |= hip_failed (hipMalloc ((void **) &s.d_src, c->src_bytes),
+        "hipMalloc");
+    bad |= hip_failed (hipMalloc ((void **) &s.d_dst, c->dst_bytes),
+        "hipMalloc");
+    bad |= hip_failed (hipEventCreateWithFlags (&s.ev_in,
+            hipEventDisableTiming), "hipEventCreate");
+    bad |= hip_failed (hipEventCreateWithFlags (&s.ev_kernel,
+            hipEventDisableTiming), "hipEventCreate");
+    bad |= hip_failed (hipEventCreateWithFlags (&s.ev_out,
+            hipEventDisableTiming), "hipEventCreate");
+    if (bad) {
+      free_ring (c);
+      return MIBAYER_ERR_HIP;
+    }
+  }
+  c->head = c->tail = c->pending = 0;
+  return MIBAYER_OK;
+}
+
+static int submit_locked (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
+    void *tag)
+{
+  int rc = ensure_ring (c);
+  if (rc != MIBAYER_OK)
+    return rc;
+  if (c->pending == (int) c->ring.size ())
+    return MIBAYER_ERR_BUSY;
+  Slot &s = c->ring[(size_t) c->head];
+  /* upload -> kernel -> download, chained by events across three queues */
+  HIP_TRY (hipMemcpyAsync (s.d_src, src, c->src_bytes, hipMemcpyHostToDevice,
+          c->s_h2d));
+  HIP_TRY (hipEventRecord (s.ev_in, c->s_h2d));
+  HIP_TRY (hipStreamWaitEvent (c->s_compute, s.ev_in, 0));
+  rc = launch (c, s.d_src, c->src_bytes, s.d_dst, c->dst_bytes, 1,
+      c->s_compute);
+  if (rc != MIBAYER_OK)
+    return rc;
+  HIP_TRY (hipEventRecord (s.ev_kernel, c->s_compute));
+  HIP_TRY (hipStreamWaitEvent (c->s_d2h, s.ev_kernel, 0));
+  if (c->cfg.dst_stride == 4 * c->cfg.width) {
+    HIP_TRY (hipMemcpyAsync (dst, s.d_dst, c->dst_bytes, hipMemcpyDeviceToHost,
+            c->s_d2h));
+  } else {
+    /* padded destination rows: only the 4*width written bytes of each row may
+     * be touched (the reference never writes the padding either) */
+    HIP_TRY (hipMemcpy2DAsync (dst, (size_t) c->cfg.dst_stride, s.d_dst,
+            (size_t) c->cfg.dst_stride, (size_t) 4 * c->cfg.width,
+            (size_t) c->cfg.height, hipMemcpyDeviceToHost, c->s_d2h));
+  }
+  HIP_TRY (hipEventRecord (s.ev_out, c->s_d2h));
+  s.tag = tag;
+  c->head = (c->head + 1) % (int) c->ring.size ();
+  c->pending++;
+  return MIBAYER_OK;
+}
+
+static int wait_locked (mibayer_ctx *c, void **tag)
+{
+  if (c->pending == 0)
+    return MIBAYER_ERR_EMPTY;
+  Slot &s = c->ring[(size_t) c->tail];
+  HIP_TRY (hipEventSynchronize (s.ev_out));
+  if (tag)
+    *tag = s.tag;
+  c->tail = (c->tail + 1) % (int) c->ring.size ();
+  c->pending--;
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_submit (mibayer_ctx *c, const uint8_t *src,
+    uint8_t *dst, void *tag)
+{
+  if (!c || !src || !dst)
+    return MIBAYER_ERR_ARG;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  return submit_locked (c, src, dst, tag);
+}
+
+extern "C" int mibayer_wait (mibayer_ctx *c, void **tag)
+{
+  if (!c)
+    return MIBAYER_ERR_ARG;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  return wait_locked (c, tag);
+}
+
+extern "C" int mibayer_pending (const mibayer_ctx *c)
+{
+  return c ? c->pending : MIBAYER_ERR_ARG;
+}
+
+extern "C" int mibayer_process_host (mibayer_ctx *c, const uint8_t *src,
+    uint8_t *dst)
+{
+  if (!c || !src || !dst)
+    return MIBAYER_ERR_ARG;
+  if (c->pending != 0)
+    return MIBAYER_ERR_BUSY;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  int rc = submit_locked (c, src, dst, NULL);
+  if (rc != MIBAYER_OK)
+    return rc;
+  return wait_locked (c, NULL);
+}
+
+/* ---- device-resident batch path ------------------------------------------------------ */
+
+extern "C" int mibayer_process_device (mibayer_ctx *c, const void *d_src,
+    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
+    void *hip_stream)
+{
+  if (!c || !d_src || !d_dst || nframes < 0)
+    return MIBAYER_ERR_ARG;
+  if (nframes > 1 && (src_frame_bytes < c->src_bytes
+          || dst_frame_bytes < c->dst_bytes || (src_frame_bytes & 3)
+          || (dst_frame_bytes & 3)))
+    return MIBAYER_ERR_GEOMETRY;
+  if ((((uintptr_t) d_src) & 3) || (((uintptr_t) d_dst) & 3))
+    return MIBAYER_ERR_ARG;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->s_compute;
+  return launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes, s);
+}
+
+extern "C" int mibayer_sync (mibayer_ctx *c)
+{
+  if (!c)
+    return MIBAYER_ERR_ARG;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  HIP_TRY (hipStreamSynchronize (c->s_h2d));
+  HIP_TRY (hipStreamSynchronize (c->s_compute));
+  HIP_TRY (hipStreamSynchronize (c->s_d2h));
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_time_device (mibayer_ctx *c, const void *d_src,
+    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
+    int warmup, int reps, float *ms_per_launch)
+{
+  if (!c || !ms_per_launch || reps < 1 || warmup < 0)
+    return MIBAYER_ERR_ARG;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  int rc;
+  for (int i = 0; i < warmup; i++) {
+    rc = mibayer_process_device (c, d_src, src_frame_bytes, d_dst,
+        dst_frame_bytes, nframes, c->s_compute);
+    if (rc != MIBAYER_OK)
+      return rc;
+  }
+  HIP_TRY (hipEventRecord (c->ev_t0, c->s_compute));
+  for (int i = 0; i < reps; i++) {
+    rc = mibayer_process_device (c, d_src, src_frame_bytes, d_dst,
+        dst_frame_bytes, nframes, c->s_compute);
+    if (rc != MIBAYER_OK)
+      return rc;
+  }
+  HIP_TRY (hipEventRecord (c->ev_t1, c->s_compute));
+  HIP_TRY (hipEventSynchronize (c->ev_t1));
+  float ms = 0.f;
+  HIP_TRY (hipEventElapsedTime (&ms, c->ev_t0, c->ev_t1));
+  *ms_per_launch = ms / (float) reps;
+  return MIBAYER_OK;
+}
+
+/* ---- memory helpers --------------------------------------------------------------------- */
+
+extern "C" void *mibayer_host_alloc (size_t bytes)
+{
+  void *p = NULL;
+  if (device_count_cached () <= 0)
+    return NULL;
+  if (hip_failed (hipHostMalloc (&p, bytes ? bytes : 1, hipHostMallocDefault),
+          "hipHostMalloc"))
+    return NULL;
+  return p;
+}
+
+extern "C" void mibayer_host_free (void *p)
+{
+  if (p)
+    (void) hipHostFree (p);
+}
+
+extern "C" void *mibayer_device_alloc (mibayer_ctx *c, size_t bytes)
+{
+  if (!c)
+    return NULL;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return NULL;
+  void *p = NULL;
+  if (hip_failed (hipMalloc (&p, bytes ? bytes : 1), "hipMalloc"))
+    return NULL;
+  return p;
+}
+
+extern "C" void mibayer_device_free (mibayer_ctx *c, void *d_ptr)
+{
+  if (!c || !d_ptr)
+    return;
+  DeviceGuard guard (c->device);
+  (void) hipFree (d_ptr);
+}
+
+extern "C" int mibayer_copy_to_device (mibayer_ctx *c, void *d_dst,
+    const void *src, size_t bytes)
+{
+  if (!c || !d_dst || !src)
+    return MIBAYER_ERR_ARG;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  HIP_TRY (hipMemcpy (d_dst, src, bytes, hipMemcpyHostToDevice));
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_copy_from_device (mibayer_ctx *c, void *dst,
+    const void *d_src, size_t bytes)
+{
+  if (!c || !dst || !d_src)
+    return MIBAYER_ERR_ARG;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  HIP_TRY (hipMemcpy (dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_fill_synthetic (mibayer_ctx *c, void *d_src,
+    size_t src_frame_bytes, uint32_t first_frame, int nframes, uint32_t seed,
+    void *hip_stream)
+{
+  if (!c || !d_src || nframes < 0)
+    return MIBAYER_ERR_ARG;
+  if (nframes > 1 && src_frame_bytes < c->src_bytes)
+    return MIBAYER_ERR_GEOMETRY;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->s_compute;
+  HIP_TRY (launch_fill_synthetic ((uint8_t *) d_src, c->cfg.width,
+          c->cfg.height, c->cfg.src_stride, src_frame_bytes, first_frame,
+          nframes, seed, s));
+  return MIBAYER_OK;
+}

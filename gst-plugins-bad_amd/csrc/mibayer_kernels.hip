@@ -1,0 +1,555 @@
+/*
+ * bayer2rgb demosaic for MI355X (gfx950, CDNA4) -- device code.
+ *
+ * Replaces, in ONE fused kernel, the reference's per-row CPU loops
+ *   gst_bayer2rgb_split_and_upsample_horiz   gst/bayer/gstbayer2rgb.c:354-381
+ *   bayer_orc_horiz_upsample_unaligned        gst/bayer/gstbayerorc.orc:3-19
+ *   bayer_orc_merge_{bg,gr}_{bgra,abgr,rgba,argb}   gstbayerorc.orc:43-248
+ * and the frame loop around them, gst_bayer2rgb_process (gstbayer2rgb.c:387-451).
+ *
+ * Algorithm (all uint8, avg(a,b) = (a+b+1)>>1, the ORC `avgub`):
+ *   for every source row y two lines are defined (reference :354-381)
+ *     E_y[x] = S(y,x)                 x even      O_y[x] = S(y,x)                 x odd
+ *            = avg(S(y,x-1),S(y,x+1)) x odd              = avg(S(y,x-1),S(y,x+1)) x even
+ *     with the edge columns  O_y[0]=S(y,1), E_y[W-1]=S(y,W-2), O_y[W-2]=S(y,W-3)
+ *   output row j uses rows u=up(j), j, d=dn(j) where up(0)=1 and dn(H-1)=H-4
+ *   (the reference's 4-slot ring, :430-447), and with T = (j&1)^swap_rows
+ *     T=0 (merge_bg): B'=E_j  R'=avg(O_u,O_d)  G = x even ? avg(avg(E_u,E_d),O_j) : O_j
+ *     T=1 (merge_gr): B'=avg(E_u,E_d)  R'=O_j  G = x even ? E_j : avg(avg(O_u,O_d),E_j)
+ *   R'/B' land on the r/b byte offsets (swapped for rggb/gbrg, :403-407), the
+ *   remaining byte is 255.
+ *
+ * Mapping to the machine:
+ *   - a lane owns 4 horizontally adjacent pixels = one source dword, so a wave64
+ *     reads 256 contiguous bytes and writes 1 KiB contiguous bytes per row
+ *     (global_store_dwordx4, every 128-byte line fully written by one instruction);
+ *   - all arithmetic is 4-pixels-per-instruction packed bytes: v_lerp_u8 is
+ *     exactly avgub on four bytes, v_alignbit_b32 builds the x-1 / x+1 neighbour
+ *     dwords, v_bfi_b32 does the even/odd column select, v_perm_b32 interleaves
+ *     R',G,B',255 into the output pixels (selectors are kernel arguments, so one
+ *     kernel serves all 4 byte layouts and all 4 Bayer orders);
+ *   - a workgroup stages its tile plus one halo row above and below (and one halo
+ *     dword left and right) in LDS with 16-byte coalesced loads; each wave then
+ *     marches down its rows with a 3-row sliding window of (E,O) in registers;
+ *   - the x-1 / x+4 neighbour bytes come from the adjacent lanes through DPP
+ *     wave shifts (no memory traffic); only lanes 0 and 63 take theirs from LDS;
+ *   - blockIdx -> tile is XCD-aware (mibayer_internal.h: block_to_tile).
+ * The op is a pure HBM stream (1 B read + 4 B written per pixel, ~25 integer
+ * ops per 4 pixels): no MFMA.
+ */
+#include "mibayer_internal.h"
+
+namespace mibayer {
+
+typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
+typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
+
+/* ------------------------------------------------------------------------- */
+/* packed-byte primitives                                                     */
+/* ------------------------------------------------------------------------- */
+
+/* four avgub at once */
+template <bool INTRIN>
+__device__ __forceinline__ uint32_t avg4 (uint32_t a, uint32_t b)
+{
+  if constexpr (INTRIN) {
+    /* v_lerp_u8: per byte (a + b + (c & 1)) >> 1 */
+    return __builtin_amdgcn_lerp (a, b, 0x01010101u);
+  } else {
+    return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu);
+  }
+}
+
+/* ({hi,lo} >> (8*nbytes)) & 0xffffffff */
+template <bool INTRIN>
+__device__ __forceinline__ uint32_t funnel_bytes (uint32_t hi, uint32_t lo,
+    int nbytes)
+{
+  if constexpr (INTRIN) {
+    return __builtin_amdgcn_alignbit (hi, lo, 8 * nbytes);
+  } else {
+    return (uint32_t) ((((unsigned long long) hi << 32) | lo) >> (8 * nbytes));
+  }
+}
+
+/* v_perm_b32: byte i of the result is byte sel[i] of {s0,s1} (0-3 = s1, 4-7 = s0),
+ * 12 = 0x00, >= 13 = 0xff */
+template <bool INTRIN>
+__device__ __forceinline__ uint32_t perm4 (uint32_t s0, uint32_t s1,
+    uint32_t sel)
+{
+  if constexpr (INTRIN) {
+    return __builtin_amdgcn_perm (s0, s1, sel);
+  } else {
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint32_t idx = (sel >> (8 * i)) & 0xffu, b;
+      if (idx < 4)
+        b = (s1 >> (8 * idx)) & 0xffu;
+      else if (idx < 8)
+        b = (s0 >> (8 * (idx - 4))) & 0xffu;
+      else if (idx == 12)
+        b = 0;
+      else
+        b = 0xffu;
+      r |= b << (8 * i);
+    }
+    return r;
+  }
+}
+
+/* (m & a) | (~m & b)  ->  v_bfi_b32 */
+__device__ __forceinline__ uint32_t bsel (uint32_t m, uint32_t a, uint32_t b)
+{
+  return (m & a) | (~m & b);
+}
+
+constexpr uint32_t kEvenBytes = 0x00ff00ffu;
+
+/* DPP wave shifts (gfx9 encodings).  Lanes whose source lane does not exist
+ * keep `edge`. */
+__device__ __forceinline__ uint32_t from_lane_below (uint32_t edge, uint32_t v)
+{
+  /* wave_shr:1 -- lane i receives lane i-1 */
+  return (uint32_t) __builtin_amdgcn_update_dpp ((int) edge, (int) v, 0x138,
+      0xf, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t from_lane_above (uint32_t edge, uint32_t v)
+{
+  /* wave_shl:1 -- lane i receives lane i+1 */
+  return (uint32_t) __builtin_amdgcn_update_dpp ((int) edge, (int) v, 0x130,
+      0xf, 0xf, false);
+}
+
+/* ------------------------------------------------------------------------- */
+/* per-row horizontal lines, reference gstbayer2rgb.c:354-381                  */
+/* ------------------------------------------------------------------------- */
+
+struct Lines { uint32_t e, o; };
+
+/* c  = S[x0..x0+3], cl = dword left of it, cr = dword right of it.
+ * first: x0 == 0.   lastmode: 1 = this lane holds columns W-4..W-1,
+ *                             2 = this lane holds columns W-2..W-1 only. */
+template <bool INTRIN, bool GENERIC>
+__device__ __forceinline__ Lines row_lines (uint32_t c, uint32_t cl,
+    uint32_t cr, bool first, int lastmode)
+{
+  /* x-1 neighbours: [cl.3, c0, c1, c2];  x+1 neighbours: [c1, c2, c3, cr.0] */
+  uint32_t lsh = funnel_bytes<INTRIN> (c, cl, 3);
+  uint32_t rsh = funnel_bytes<INTRIN> (cr, c, 1);
+  /* O[0] = S[1] (:361): make the left neighbour of column 0 equal S[1] */
+  uint32_t lsh_first = (lsh & 0xffffff00u) | ((c >> 8) & 0xffu);
+  lsh = first ? lsh_first : lsh;
+  /* E[W-1] = S[W-2], O[W-2] = S[W-3] (:372-380): right neighbours of the last
+   * two columns are replaced by their left neighbours */
+  uint32_t t = lsh >> 16;                    /* [c1, c2, 0, 0] */
+  uint32_t rsh_last = t | (t << 16);          /* [c1, c2, c1, c2] */
+  rsh = (lastmode == 1) ? rsh_last : rsh;
+  if constexpr (GENERIC)
+    rsh = (lastmode == 2) ? lsh : rsh;        /* [L, c0, -, -] */
+  uint32_t a = avg4<INTRIN> (lsh, rsh);
+  Lines r;
+  r.e = bsel (kEvenBytes, c, a);
+  r.o = bsel (kEvenBytes, a, c);
+  return r;
+}
+
+/* ------------------------------------------------------------------------- */
+/* vertical merge + interleave, reference gstbayerorc.orc:43-92                */
+/* ------------------------------------------------------------------------- */
+
+template <bool INTRIN>
+__device__ __forceinline__ u32x4 merge_rows (const Lines &u, const Lines &c,
+    const Lines &d, int type, const uint32_t (&sel)[4])
+{
+  uint32_t ve = avg4<INTRIN> (u.e, d.e);
+  uint32_t vo = avg4<INTRIN> (u.o, d.o);
+  uint32_t rq, bq, g;
+  if (type == 0) {              /* merge_bg, orc:57-66 */
+    bq = c.e;
+    rq = vo;
+    g = bsel (kEvenBytes, avg4<INTRIN> (ve, c.o), c.o);
+  } else {                      /* merge_gr, orc:83-92 */
+    bq = ve;
+    rq = c.o;
+    g = bsel (kEvenBytes, c.e, avg4<INTRIN> (vo, c.e));
+  }
+  /* [r0 b0 r1 b1], [r2 b2 r3 b3] */
+  uint32_t m_lo = perm4<INTRIN> (rq, bq, 0x01050004u);
+  uint32_t m_hi = perm4<INTRIN> (rq, bq, 0x03070206u);
+  u32x4 px;
+  px.x = perm4<INTRIN> (m_lo, g, sel[0]);
+  px.y = perm4<INTRIN> (m_lo, g, sel[1]);
+  px.z = perm4<INTRIN> (m_hi, g, sel[2]);
+  px.w = perm4<INTRIN> (m_hi, g, sel[3]);
+  return px;
+}
+
+template <bool NT, bool GENERIC>
+__device__ __forceinline__ void store_pixels (uint8_t *p, u32x4 px,
+    int lastmode)
+{
+  if constexpr (!GENERIC) {
+    if constexpr (NT)
+      __builtin_nontemporal_store (px, (u32x4 *) p);
+    else
+      *(u32x4 *) p = px;
+  } else {
+    uint32_t *q = (uint32_t *) p;
+    q[0] = px.x;
+    q[1] = px.y;
+    if (lastmode != 2) {
+      q[2] = px.z;
+      q[3] = px.w;
+    }
+  }
+}
+
+/* source row standing in for row y of the (virtually extended) frame:
+ * up(0) = 1, dn(H-1) = dn_last (H-4, or 1 when H == 3) -- gstbayer2rgb.c:430-447 */
+__device__ __forceinline__ int map_row (int y, int height, int dn_last)
+{
+  return y < 0 ? 1 : (y < height ? y : dn_last);
+}
+
+/* ------------------------------------------------------------------------- */
+/* LDS-staged tile kernel                                                      */
+/* ------------------------------------------------------------------------- */
+/* WX x WY waves per workgroup; a wave covers 256 px (64 lanes x 4 px) and marches
+ * RPW rows.  Tile = (256*WX) x (WY*RPW) px.
+ * NEIGH: 0 = DPP wave shift, 1 = __shfl_up/down (ds_bpermute), 2 = LDS reads.   */
+template <int WX, int WY, int RPW, int NEIGH, bool NT, bool INTRIN,
+    bool GENERIC>
+__global__ void __launch_bounds__ (64 * WX * WY)
+bayer2rgb_lds_kernel (KParams p)
+{
+  constexpr int NTHREADS = 64 * WX * WY;
+  constexpr int TW = 256 * WX;
+  constexpr int TR = WY * RPW;
+  constexpr int NROWS = TR + 2;
+  /* LDS row: 12 B pad | left halo dword | TW bytes | right halo dword | 12 B pad */
+  constexpr int PITCH = TW + 32;
+  constexpr int MAIN = 16;
+  static_assert (RPW % 2 == 0, "row parity is derived from the in-tile row");
+
+  __shared__ __attribute__ ((aligned (16))) uint8_t lds[NROWS * PITCH];
+
+  const long long tile = block_to_tile (blockIdx.x, p.ntiles, p.chunk);
+  if (tile < 0)
+    return;
+  const int tx = (int) (tile % p.tiles_x);
+  const long long trest = tile / p.tiles_x;
+  const int ty = (int) (trest % p.tiles_y);
+  const long long frame = trest / p.tiles_y;
+  const uint8_t *src = p.src + frame * p.src_frame_bytes;
+  uint8_t *dst = p.dst + frame * p.dst_frame_bytes;
+  const int tile_x = tx * TW;
+  const int tile_y = ty * TR;
+  const int tid = threadIdx.x;
+
+  /* ---- stage rows tile_y-1 .. tile_y+TR (through map_row) into LDS ---------- */
+  if constexpr (!GENERIC) {
+    constexpr int TPR = TW / 16;          /* threads per row, 16 B each */
+    constexpr int RPP = NTHREADS / TPR;   /* rows per pass */
+    constexpr int NPASS = (NROWS + RPP - 1) / RPP;
+    const int c = (tid % TPR) * 16;
+    const int rr = tid / TPR;
+    u32x4 v[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int r = i * RPP + rr;
+      const int y = tile_y - 1 + r;
+      v[i] = (u32x4) (0u);
+      if (r < NROWS && y <= p.height && tile_x + c < p.width) {
+        const uint8_t *g = src
+            + (size_t) map_row (y, p.height, p.dn_last) * p.src_stride
+            + tile_x + c;
+        v[i] = *(const u32x4 *) g;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int r = i * RPP + rr;
+      if (r < NROWS)
+        *(u32x4 *) &lds[r * PITCH + MAIN + c] = v[i];
+    }
+  } else {
+    constexpr int TPR = TW / 4;           /* 4 B each */
+    constexpr int RPP = NTHREADS / TPR;
+    constexpr int NPASS = (NROWS + RPP - 1) / RPP;
+    const int c = (tid % TPR) * 4;
+    const int rr = tid / TPR;
+    uint32_t v[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int r = i * RPP + rr;
+      const int y = tile_y - 1 + r;
+      v[i] = 0u;
+      if (r < NROWS && y <= p.height && tile_x + c < p.wlimit4) {
+        const uint8_t *g = src
+            + (size_t) map_row (y, p.height, p.dn_last) * p.src_stride
+            + tile_x + c;
+        v[i] = *(const uint32_t *) g;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int r = i * RPP + rr;
+      if (r < NROWS)
+        *(uint32_t *) &lds[r * PITCH + MAIN + c] = v[i];
+    }
+  }
+  /* halo dwords: column tile_x-4 and tile_x+TW of every staged row */
+  for (int h = tid; h < 2 * NROWS; h += NTHREADS) {
+    const int r = h >> 1;
+    const int side = h & 1;
+    const int y = tile_y - 1 + r;
+    const int col = side ? tile_x + TW : tile_x - 4;
+    uint32_t v = 0u;
+    if (y <= p.height && col >= 0 && col < p.wlimit4)
+      v = *(const uint32_t *) (src
+          + (size_t) map_row (y, p.height, p.dn_last) * p.src_stride + col);
+    *(uint32_t *) &lds[r * PITCH + (side ? MAIN + TW : MAIN - 4)] = v;
+  }
+  __syncthreads ();
+
+  /* ---- per-wave march -------------------------------------------------------- */
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wx = wave % WX;
+  const int wy = wave / WX;
+  const int xl = 256 * wx + 4 * lane;
+  const int x0 = tile_x + xl;
+  const bool first = (x0 == 0);
+  const int lastmode = (x0 + 4 == p.width) ? 1
+      : ((GENERIC && x0 + 2 == p.width) ? 2 : 0);
+  const bool active = x0 < p.width;
+  const uint8_t *lrow = &lds[MAIN + xl];
+  /* lanes 0 / 63 take the neighbour that lives in another wave (or the halo) */
+  const int edge_off = (lane == 0) ? -4 : 4;
+
+  auto lines_of = [&](int r) -> Lines {
+    const uint8_t *q = lrow + r * PITCH;
+    const uint32_t c = *(const uint32_t *) q;
+    uint32_t cl, cr;
+    if constexpr (NEIGH == 2) {
+      cl = *(const uint32_t *) (q - 4);
+      cr = *(const uint32_t *) (q + 4);
+    } else {
+      const uint32_t edge = *(const uint32_t *) (q + edge_off);
+      if constexpr (NEIGH == 0) {
+        cl = from_lane_below (edge, c);
+        cr = from_lane_above (edge, c);
+      } else {
+        cl = __shfl_up (c, 1);
+        cr = __shfl_down (c, 1);
+        cl = (lane == 0) ? edge : cl;
+        cr = (lane == 63) ? edge : cr;
+      }
+    }
+    return row_lines<INTRIN, GENERIC> (c, cl, cr, first, lastmode);
+  };
+
+  const int r0 = wy * RPW;      /* LDS row of up(first output row of this wave) */
+  Lines up = lines_of (r0);
+  Lines cur = lines_of (r0 + 1);
+  uint8_t *out = dst + (size_t) (tile_y + r0) * p.dst_stride + (size_t) x0 * 4;
+  const int nrows = p.height - (tile_y + r0);   /* rows of this wave inside the frame */
+#pragma unroll
+  for (int k = 0; k < RPW; k++) {
+    const Lines dn = lines_of (r0 + k + 2);
+    const int type = (k & 1) ^ p.swap_rows;
+    const u32x4 px = merge_rows<INTRIN> (up, cur, dn, type, p.sel);
+    if (active && k < nrows)
+      store_pixels<NT, GENERIC> (out, px, lastmode);
+    out += p.dst_stride;
+    up = cur;
+    cur = dn;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* direct kernel: no LDS, every wave streams its own strip                     */
+/* ------------------------------------------------------------------------- */
+/* Experiment arm (same arithmetic): rows come straight from global memory, the
+ * wave-edge lanes fetch their neighbour dword with a second, 2-lane load.      */
+template <int WX, int WY, int RPW, bool NT, bool INTRIN, bool GENERIC>
+__global__ void __launch_bounds__ (64 * WX * WY)
+bayer2rgb_direct_kernel (KParams p)
+{
+  constexpr int TW = 256 * WX;
+  constexpr int TR = WY * RPW;
+  static_assert (RPW % 2 == 0, "row parity is derived from the in-tile row");
+
+  const long long tile = block_to_tile (blockIdx.x, p.ntiles, p.chunk);
+  if (tile < 0)
+    return;
+  const int tx = (int) (tile % p.tiles_x);
+  const long long trest = tile / p.tiles_x;
+  const int ty = (int) (trest % p.tiles_y);
+  const long long frame = trest / p.tiles_y;
+  const uint8_t *src = p.src + frame * p.src_frame_bytes;
+  uint8_t *dst = p.dst + frame * p.dst_frame_bytes;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wx = wave % WX;
+  const int wy = wave / WX;
+  const int x0 = tx * TW + 256 * wx + 4 * lane;
+  const int yb = ty * TR + wy * RPW;
+  const bool first = (x0 == 0);
+  const int lastmode = (x0 + 4 == p.width) ? 1
+      : ((GENERIC && x0 + 2 == p.width) ? 2 : 0);
+  const bool active = x0 < p.width;
+  const bool readable = x0 < p.wlimit4;
+  const int xe = (lane == 0) ? x0 - 4 : x0 + 4;
+  const bool edge_lane = (lane == 0 || lane == 63) && xe >= 0
+      && xe < p.wlimit4;
+
+  uint32_t c[RPW + 2], e[RPW + 2];
+#pragma unroll
+  for (int r = 0; r < RPW + 2; r++) {
+    const int y = yb - 1 + r;
+    c[r] = 0u;
+    e[r] = 0u;
+    if (y <= p.height) {
+      const uint8_t *row = src
+          + (size_t) map_row (y, p.height, p.dn_last) * p.src_stride;
+      if (readable)
+        c[r] = *(const uint32_t *) (row + x0);
+      if (edge_lane)
+        e[r] = *(const uint32_t *) (row + xe);
+    }
+  }
+
+  auto lines_of = [&](int r) -> Lines {
+    const uint32_t cl = from_lane_below (e[r], c[r]);
+    const uint32_t cr = from_lane_above (e[r], c[r]);
+    return row_lines<INTRIN, GENERIC> (c[r], cl, cr, first, lastmode);
+  };
+
+  Lines up = lines_of (0);
+  Lines cur = lines_of (1);
+  uint8_t *out = dst + (size_t) yb * p.dst_stride + (size_t) x0 * 4;
+  const int nrows = p.height - yb;              /* rows of this wave inside the frame */
+#pragma unroll
+  for (int k = 0; k < RPW; k++) {
+    const Lines dn = lines_of (k + 2);
+    const int type = (k & 1) ^ p.swap_rows;
+    const u32x4 px = merge_rows<INTRIN> (up, cur, dn, type, p.sel);
+    if (active && k < nrows)
+      store_pixels<NT, GENERIC> (out, px, lastmode);
+    out += p.dst_stride;
+    up = cur;
+    cur = dn;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* variant table                                                               */
+/* ------------------------------------------------------------------------- */
+
+#define LDS_VARIANT(name, WX, WY, RPW, NEIGH, NT, INTRIN)                      \
+  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY),                          \
+    bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, NT, INTRIN, false>,               \
+    bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, NT, INTRIN, true> }
+#define DIRECT_VARIANT(name, WX, WY, RPW, NT, INTRIN)                          \
+  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY),                          \
+    bayer2rgb_direct_kernel<WX, WY, RPW, NT, INTRIN, false>,                   \
+    bayer2rgb_direct_kernel<WX, WY, RPW, NT, INTRIN, true> }
+
+static const Variant kVariants[] = {
+  /* 0: default (kept equal to the best measured arm) */
+  LDS_VARIANT ("lds_1x4_r8_dpp", 1, 4, 8, 0, false, true),
+  /* 1.. : tuning / verification arms */
+  LDS_VARIANT ("lds_1x4_r8_dpp_nt", 1, 4, 8, 0, true, true),
+  LDS_VARIANT ("lds_1x4_r16_dpp", 1, 4, 16, 0, false, true),
+  LDS_VARIANT ("lds_4x1_r16_dpp", 4, 1, 16, 0, false, true),
+  LDS_VARIANT ("lds_4x1_r32_dpp", 4, 1, 32, 0, false, true),
+  LDS_VARIANT ("lds_2x2_r16_dpp", 2, 2, 16, 0, false, true),
+  LDS_VARIANT ("lds_1x4_r8_shfl", 1, 4, 8, 1, false, true),
+  LDS_VARIANT ("lds_1x4_r8_ldsnb", 1, 4, 8, 2, false, true),
+  LDS_VARIANT ("lds_1x4_r8_ldsnb_swar", 1, 4, 8, 2, false, false),
+  DIRECT_VARIANT ("direct_1x4_r8", 1, 4, 8, false, true),
+  DIRECT_VARIANT ("direct_1x4_r16", 1, 4, 16, false, true),
+  DIRECT_VARIANT ("direct_1x4_r16_nt", 1, 4, 16, true, true),
+  DIRECT_VARIANT ("direct_1x1_r16", 1, 1, 16, false, true),
+  LDS_VARIANT ("lds_1x8_r8_dpp", 1, 8, 8, 0, false, true),
+  LDS_VARIANT ("lds_4x1_r16_dpp_nt", 4, 1, 16, 0, true, true),
+};
+
+int variant_count ()
+{
+  return (int) (sizeof (kVariants) / sizeof (kVariants[0]));
+}
+
+const Variant &variant (int id)
+{
+  return kVariants[id];
+}
+
+/* ------------------------------------------------------------------------- */
+/* synthetic mosaic (counter-based, stateless per byte)                        */
+/* ------------------------------------------------------------------------- */
+
+__device__ __forceinline__ uint32_t fmix32 (uint32_t z)
+{
+  z ^= z >> 16;
+  z *= 0x85EBCA6Bu;
+  z ^= z >> 13;
+  z *= 0xC2B2AE35u;
+  z ^= z >> 16;
+  return z;
+}
+
+/* byte(f,y,x) = fmix32((f*H*W + y*W + x) * 2654435761 + seed*0x9E3779B9) & 0xff;
+ * one thread writes one dword (4 columns); padding columns are 0. */
+__global__ void __launch_bounds__ (256)
+fill_synthetic_kernel (uint8_t *buf, int width, int height, int stride,
+    unsigned long long frame_bytes, uint32_t first_frame, int nframes,
+    uint32_t seed)
+{
+  const int dwords_per_row = stride >> 2;
+  const unsigned long long per_frame = (unsigned long long) dwords_per_row
+      * height;
+  const unsigned long long total = per_frame * nframes;
+  for (unsigned long long i = blockIdx.x * (unsigned long long) blockDim.x
+      + threadIdx.x; i < total;
+      i += (unsigned long long) gridDim.x * blockDim.x) {
+    const unsigned long long f = i / per_frame;
+    const unsigned long long rem = i - f * per_frame;
+    const int y = (int) (rem / dwords_per_row);
+    const int x = (int) (rem - (unsigned long long) y * dwords_per_row) * 4;
+    const uint32_t base = (first_frame + (uint32_t) f) * (uint32_t) height
+        * (uint32_t) width + (uint32_t) y * (uint32_t) width + (uint32_t) x;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (x + k < width)
+        v |= (fmix32 ((base + k) * 2654435761u + seed * 0x9E3779B9u) & 0xffu)
+            << (8 * k);
+    }
+    *(uint32_t *) (buf + f * frame_bytes + (size_t) y * stride + x) = v;
+  }
+}
+
+hipError_t launch_fill_synthetic (uint8_t *d_buf, int width, int height,
+    int stride, unsigned long long frame_bytes, uint32_t first_frame,
+    int nframes, uint32_t seed, hipStream_t stream)
+{
+  const unsigned long long total = (unsigned long long) (stride >> 2) * height
+      * nframes;
+  unsigned long long blocks = (total + 255) / 256;
+  if (blocks > 256ull * 32)
+    blocks = 256ull * 32;
+  if (blocks == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL (fill_synthetic_kernel, dim3 ((unsigned) blocks),
+      dim3 (256), 0, stream, d_buf, width, height, stride, frame_bytes,
+      first_frame, nframes, seed);
+  return hipGetLastError ();
+}
+
+}  /* namespace mibayer */

@@ -1,0 +1,185 @@
+/*
+ * mibayer.h -- C ABI of the MI355X-native bayer2rgb hot path.
+ *
+ * This is the drop-in boundary for gst-plugins-bad's `bayer2rgb` element
+ * (reference v1.19.2, paths relative to the gst-plugins-bad tree):
+ *
+ *   the element's per-frame call
+ *       gst_bayer2rgb_process (filter, output, frame.info.stride[0],
+ *                              map.data, GST_ROUND_UP_4 (filter->width));
+ *       gst/bayer/gstbayer2rgb.c:475-477  (body :387-451, row helper :354-381,
+ *       ORC inner loops gst/bayer/gstbayerorc.orc:3-248)
+ *   is replaced by  mibayer_process_host()  /  mibayer_submit()+mibayer_wait(),
+ *   and the per-stream state the reference keeps in struct _GstBayer2RGB
+ *   (gstbayer2rgb.c:115-127: width, height, r_off, g_off, b_off, format) is
+ *   what mibayer_cfg carries into mibayer_create() from the element's
+ *   set_caps vfunc (gstbayer2rgb.c:237-276).
+ *
+ * Plain C, no GLib / GStreamer / torch types.  All entry points return
+ * MIBAYER_OK (0) or a negative mibayer_status; nothing throws across the ABI.
+ * There is NO CPU fallback behind this ABI: without a HIP device every
+ * compute entry point fails with MIBAYER_ERR_NO_DEVICE.
+ *
+ * Output is bit-exact (uint8) with the reference CPU/ORC path for every
+ * geometry in which the reference is well defined: even width >= 4 and
+ * height >= 3 (odd widths leave the last column unwritten and read
+ * uninitialised scratch in the reference; height < 3 reads uninitialised or
+ * out-of-bounds rows -- gstbayer2rgb.c:365-380, :430-447).  Anything else is
+ * rejected with MIBAYER_ERR_GEOMETRY at mibayer_create() time.
+ */
+#ifndef MIBAYER_H
+#define MIBAYER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIBAYER_ABI_VERSION 1
+
+/* Bayer order; numbering identical to the reference's anonymous enum
+ * GST_BAYER_2_RGB_FORMAT_*, gstbayer2rgb.c:95-101. */
+typedef enum mibayer_pattern {
+  MIBAYER_BGGR = 0,
+  MIBAYER_GBRG = 1,
+  MIBAYER_GRBG = 2,
+  MIBAYER_RGGB = 3
+} mibayer_pattern;
+
+typedef enum mibayer_status {
+  MIBAYER_OK = 0,
+  MIBAYER_ERR_ARG = -1,         /* NULL pointer, bad struct_size, bad enum   */
+  MIBAYER_ERR_GEOMETRY = -2,    /* width/height/stride outside the domain    */
+  MIBAYER_ERR_LAYOUT = -3,      /* (r,g,b)_off is none of the 4 byte layouts
+                                   the reference has merge functions for
+                                   (gstbayer2rgb.c:409-421)                  */
+  MIBAYER_ERR_NO_DEVICE = -4,   /* no HIP device / ordinal out of range      */
+  MIBAYER_ERR_HIP = -5,         /* a HIP runtime call failed                 */
+  MIBAYER_ERR_NOMEM = -6,
+  MIBAYER_ERR_BUSY = -7,        /* async ring full: call mibayer_wait()      */
+  MIBAYER_ERR_EMPTY = -8        /* mibayer_wait() with nothing in flight     */
+} mibayer_status;
+
+/* Per-stream configuration == the fields of struct _GstBayer2RGB
+ * (gstbayer2rgb.c:115-127) plus the strides gst_bayer2rgb_transform passes
+ * (:475-477) and where to run. */
+typedef struct mibayer_cfg {
+  uint32_t struct_size;   /* = sizeof (mibayer_cfg)                          */
+  int32_t width;          /* pixels; even, >= 4                              */
+  int32_t height;         /* rows; >= 3                                      */
+  int32_t src_stride;     /* bytes per mosaic row; 0 = GST_ROUND_UP_4(width),
+                             the value the reference always passes (:477);
+                             must be a multiple of 4 and >= ROUND_UP_4(width) */
+  int32_t dst_stride;     /* bytes per output row; 0 = 4*width; multiple of 4,
+                             >= 4*width (GstVideoMeta may pad, :476)         */
+  int32_t pattern;        /* mibayer_pattern                                 */
+  int32_t r_off;          /* byte index of R, G, B inside the 4-byte output  */
+  int32_t g_off;          /* pixel == GST_VIDEO_INFO_COMP_OFFSET (info, 0..2) */
+  int32_t b_off;          /* (:268-271).  The 4th byte is written as 255.    */
+  int32_t device;         /* HIP device ordinal; -1 = the current device     */
+  int32_t inflight;       /* host path: frames in flight (ring depth) for
+                             mibayer_submit(); 0 = default (2)               */
+  int32_t variant;        /* kernel variant; 0 = default.  Tuning knob, every
+                             variant is bit-exact            */
+  uint32_t flags;         /* reserved, 0                                     */
+} mibayer_cfg;
+
+typedef struct mibayer_ctx mibayer_ctx;
+
+/* ---- global ------------------------------------------------------------- */
+
+int mibayer_abi_version (void);
+/* number of HIP devices, 0 if none (never negative) */
+int mibayer_device_count (void);
+const char *mibayer_strerror (int status);
+/* text of the last HIP error seen by the calling thread ("" if none) */
+const char *mibayer_last_hip_error (void);
+
+/* ---- per-stream context (created in set_caps, destroyed in stop/finalize) -- */
+
+/* Validates cfg, selects the device, creates the compute and copy streams and
+ * the device-side frame ring.  Replaces the per-frame g_malloc'ed scratch of
+ * the reference (:429) with state that lives as long as the caps do. */
+int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out);
+void mibayer_destroy (mibayer_ctx *ctx);
+/* the configuration with every default resolved */
+int mibayer_get_cfg (const mibayer_ctx *ctx, mibayer_cfg *out);
+
+/* ---- host-memory frame path (what the GStreamer element calls) ------------ */
+
+/* Synchronous drop-in for gst_bayer2rgb_process (:475-477): `src` holds
+ * src_stride*height bytes, `dst` receives dst_stride*height bytes (only the
+ * first 4*width bytes of each row are written); returns when dst is complete.
+ * H2D, kernel and D2H run on the context's streams.  src/dst may be pageable
+ * or pinned (mibayer_host_alloc) memory. */
+int mibayer_process_host (mibayer_ctx *ctx, const uint8_t *src, uint8_t *dst);
+
+/* Asynchronous form: up to cfg.inflight frames between submit and wait.
+ * Frames complete in submission order; `tag` is handed back by wait.
+ * src/dst must stay valid until the matching wait returns. */
+int mibayer_submit (mibayer_ctx *ctx, const uint8_t *src, uint8_t *dst,
+    void *tag);
+int mibayer_wait (mibayer_ctx *ctx, void **tag);
+int mibayer_pending (const mibayer_ctx *ctx);
+
+/* ---- device-resident batch path (roofline runs, GPU-side consumers) -------- */
+
+/* Enqueues ONE kernel launch converting `nframes` frames that already live in
+ * device memory: frame f is read at d_src + f*src_frame_bytes and written at
+ * d_dst + f*dst_frame_bytes.  `hip_stream` is a hipStream_t (NULL = the
+ * context's compute stream).  Returns after the launch is enqueued. */
+int mibayer_process_device (mibayer_ctx *ctx, const void *d_src,
+    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
+    void *hip_stream);
+/* waits for the context's own streams */
+int mibayer_sync (mibayer_ctx *ctx);
+
+/* Times `reps` back-to-back launches of mibayer_process_device with HIP events
+ * recorded on the launch stream (after `warmup` untimed launches); writes the
+ * mean milliseconds per launch. */
+int mibayer_time_device (mibayer_ctx *ctx, const void *d_src,
+    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
+    int warmup, int reps, float *ms_per_launch);
+
+/* ---- memory helpers --------------------------------------------------------- */
+
+/* Pinned (hipHostMalloc) memory for buffer pools feeding the host path. */
+void *mibayer_host_alloc (size_t bytes);
+void mibayer_host_free (void *p);
+
+/* Device memory on the context's device, for C callers without another
+ * allocator. */
+void *mibayer_device_alloc (mibayer_ctx *ctx, size_t bytes);
+void mibayer_device_free (mibayer_ctx *ctx, void *d_ptr);
+int mibayer_copy_to_device (mibayer_ctx *ctx, void *d_dst, const void *src,
+    size_t bytes);
+int mibayer_copy_from_device (mibayer_ctx *ctx, void *dst, const void *d_src,
+    size_t bytes);
+
+/* Counter-based synthetic mosaic generated on the device (stateless per byte;
+ * definition in DESIGN.md "Synthetic input"): frames first_frame ..
+ * first_frame+nframes-1 with the context's width/height/src_stride. */
+int mibayer_fill_synthetic (mibayer_ctx *ctx, void *d_src,
+    size_t src_frame_bytes, uint32_t first_frame, int nframes, uint32_t seed,
+    void *hip_stream);
+
+/* ---- introspection (tests) --------------------------------------------------- */
+
+/* Number of kernel variants; variant ids are 0 .. n-1 (0 = default). */
+int mibayer_variant_count (void);
+const char *mibayer_variant_name (int variant);
+/* Launch geometry the context would use for nframes frames: tile width/height
+ * in pixels, tiles per frame, grid size.  Any pointer may be NULL. */
+int mibayer_launch_geometry (const mibayer_ctx *ctx, int nframes, int *tile_w,
+    int *tile_h, int *tiles_per_frame, int *grid_blocks);
+/* The XCD-aware block -> tile permutation used by the kernel, evaluated on the
+ * host: returns the linear tile id block `block` of a `grid_blocks` launch
+ * over `ntiles` tiles processes, or -1 if that block idles. */
+int64_t mibayer_block_to_tile (int64_t block, int64_t ntiles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIBAYER_H */

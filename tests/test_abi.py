@@ -1,0 +1,116 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol of
+include/mibayer.h, validates configurations like the reference's set_caps/process would, and has no
+CPU compute path behind it (no GPU here => every compute entry point must fail loudly)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mibayer.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mibayer_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(pkg):
+    syms = declared_symbols()
+    assert len(syms) >= 24
+    raw = ctypes.CDLL(pkg.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), "libmibayer.so does not export %s" % s
+    assert sorted(pkg.ABI) == syms, "python harness and header disagree"
+
+
+def test_version_strerror_variants(pkg):
+    L = pkg.lib()
+    assert L.mibayer_abi_version() == 1
+    for code in range(-8, 1):
+        assert L.mibayer_strerror(code)
+    names = pkg.variant_names()
+    assert len(names) == len(set(names)) >= 1
+    assert L.mibayer_variant_name(len(names)) is None
+
+
+def make_cfg(pkg, **kw):
+    d = dict(width=64, height=48, src_stride=0, dst_stride=0, pattern=0, r_off=0, g_off=1, b_off=2,
+             device=-1, inflight=0, variant=0, flags=0)
+    d.update(kw)
+    return pkg.Cfg(ctypes.sizeof(pkg.Cfg), d["width"], d["height"], d["src_stride"], d["dst_stride"],
+                   d["pattern"], d["r_off"], d["g_off"], d["b_off"], d["device"], d["inflight"],
+                   d["variant"], d["flags"])
+
+
+def create(pkg, cfg):
+    h = ctypes.c_void_p()
+    rc = pkg.lib().mibayer_create(ctypes.byref(cfg), ctypes.byref(h))
+    if rc == 0:
+        pkg.lib().mibayer_destroy(h)
+    return rc
+
+
+def test_cfg_validation_matches_reference_domain(pkg):
+    ok_or_nodev = (pkg.OK, pkg.ERR_NO_DEVICE)
+    assert create(pkg, make_cfg(pkg)) in ok_or_nodev
+    # geometry: odd / tiny widths and heights < 3 are where the reference reads uninitialised memory
+    for kw in (dict(width=5), dict(width=2), dict(width=0), dict(height=2), dict(height=0),
+               dict(src_stride=62), dict(src_stride=66), dict(dst_stride=252), dict(dst_stride=258)):
+        assert create(pkg, make_cfg(pkg, **kw)) == pkg.ERR_GEOMETRY, kw
+    # the 4 byte layouts of gstbayer2rgb.c:409-421 and nothing else
+    for (r, g, b) in [(0, 1, 2), (2, 1, 0), (1, 2, 3), (3, 2, 1)]:
+        assert create(pkg, make_cfg(pkg, r_off=r, g_off=g, b_off=b)) in ok_or_nodev
+    for (r, g, b) in [(0, 2, 1), (1, 1, 1), (0, 1, 3), (4, 1, 0)]:
+        assert create(pkg, make_cfg(pkg, r_off=r, g_off=g, b_off=b)) == pkg.ERR_LAYOUT
+    for kw in (dict(pattern=4), dict(pattern=-1), dict(flags=1), dict(variant=10 ** 6), dict(inflight=-1)):
+        assert create(pkg, make_cfg(pkg, **kw)) == pkg.ERR_ARG, kw
+    bad = make_cfg(pkg)
+    bad.struct_size = 8
+    assert create(pkg, bad) == pkg.ERR_ARG
+    assert pkg.lib().mibayer_create(None, None) == pkg.ERR_ARG
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a device the product must refuse, not compute on the host."""
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is visible; the no-device behaviour is checked on CPU boxes")
+    with pytest.raises(pkg.MibayerError) as e:
+        pkg.Context(64, 48)
+    assert e.value.status == pkg.ERR_NO_DEVICE
+    assert pkg.lib().mibayer_host_alloc(64) is None
+
+
+def test_product_does_not_link_or_mention_the_oracle(pkg):
+    out = subprocess.run(["ldd", pkg.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    pdir = os.path.join(ROOT, "gst-plugins-bad_amd")
+    for dirpath, _, files in os.walk(pdir):
+        for f in files:
+            if f.endswith((".hip", ".h", ".c", ".cpp", ".py")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in text and "import oracle" not in text, f
+                assert "bayer2rgb_oracle" not in text, f
+
+
+def test_xcd_block_to_tile_is_a_bijection(pkg):
+    f = pkg.lib().mibayer_block_to_tile
+    for ntiles in (1, 7, 8, 9, 63, 64, 65, 1000, 4321):
+        chunk = (ntiles + 7) // 8
+        grid = chunk * 8
+        tiles = [f(b, ntiles) for b in range(grid)]
+        live = [t for t in tiles if t >= 0]
+        assert sorted(live) == list(range(ntiles)), ntiles
+        # XCD k (blocks k, k+8, ...) walks one contiguous tile range in order
+        for k in range(8):
+            mine = [t for t in tiles[k::8] if t >= 0]
+            assert mine == list(range(k * chunk, k * chunk + len(mine)))
+    assert f(-1, 10) == -1 and f(0, 0) == -1
+
+
+def test_launch_geometry_needs_no_device_math(pkg):
+    # pure host arithmetic check of the tile grid through the variant table
+    names = pkg.variant_names()
+    assert names[0].startswith("lds_")

@@ -1,0 +1,226 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
+include/mibayer.h, must be bit-exact (uint8) with the CPU oracle -- and through it with the
+reference -- for every Bayer order x byte layout, on edge geometries, on the committed golden
+fixtures, on the survey's whole-element md5 known answers at 1080p/4K/8K, and for every kernel
+variant."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATTERNS = ("bggr", "gbrg", "grbg", "rggb")
+LAYOUTS = ("RGBx", "BGRx", "xRGB", "xBGR")
+ALL_FORMATS = ("RGBx", "xRGB", "BGRx", "xBGR", "RGBA", "ARGB", "BGRA", "ABGR")
+
+
+def md5(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def check(pkg, oracle, src, w, pat, fmt, variant=0, dst_stride=0, via="device"):
+    h, stride = src.shape
+    r, g, b = pkg.FORMATS[fmt]
+    want = oracle.bayer2rgb(src, w, pat, r, g, b, dst_stride=dst_stride or None)
+    with pkg.Context(w, h, pat, fmt, src_stride=stride, dst_stride=dst_stride, variant=variant) as ctx:
+        if via == "host":
+            got = ctx.process_host(src)
+        else:
+            got = ctx.process_batch_via_device(src[None])[0]
+    if via == "host" and dst_stride:
+        # padding bytes of the destination rows keep their guard fill, as with the reference
+        assert (got[:, 4 * w:] == 0xA5).all()
+    else:
+        want = want.copy()
+    n_bad = int((got[:, :4 * w] != want[:, :4 * w]).sum())
+    assert n_bad == 0, "%dx%d %s->%s variant %d via %s: %d differing bytes, first at %s" % (
+        w, h, pat, fmt, variant, via, n_bad, np.argwhere(got[:, :4 * w] != want[:, :4 * w])[:4].tolist())
+
+
+def test_golden_fixtures(gpu_pkg, golden):
+    for name in [k for k in golden.files if k.startswith("in_")]:
+        dims = name[3:]
+        w, h = (int(v) for v in dims.split("x"))
+        src = golden[name]
+        for pat in PATTERNS:
+            for lay in LAYOUTS:
+                want = golden["out_%s_%s_%s" % (dims, pat, lay)]
+                with gpu_pkg.Context(w, h, pat, lay, src_stride=src.shape[1]) as ctx:
+                    got = ctx.process_batch_via_device(src[None])[0]
+                assert np.array_equal(got, want), (dims, pat, lay)
+
+
+def test_all_orders_all_formats_fast_and_generic_paths(gpu_pkg, oracle):
+    rng = np.random.default_rng(3)
+    # 512x70: W%16==0 -> 16-byte fast path, two tile rows; 258x37 / 1030x9: generic path,
+    # W%4==2 tail lane, tiles crossing the 256/1024-pixel strip boundaries
+    for (w, h) in [(512, 70), (258, 37), (1030, 9), (2048, 33)]:
+        stride = (w + 3) & ~3
+        src = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+        for pat in PATTERNS:
+            for fmt in ALL_FORMATS:
+                check(gpu_pkg, oracle, src, w, pat, fmt)
+
+
+def test_edge_geometries(gpu_pkg, oracle):
+    rng = np.random.default_rng(4)
+    sizes = [(4, 3), (4, 4), (6, 4), (8, 5), (16, 3), (16, 4), (254, 4), (256, 5), (258, 6), (260, 7),
+             (1024, 8), (1026, 31), (1028, 32), (1280, 33), (66, 34), (4, 65), (3840, 3)]
+    for (w, h) in sizes:
+        stride = (w + 3) & ~3
+        src = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+        for pat in ("bggr", "gbrg"):
+            check(gpu_pkg, oracle, src, w, pat, "BGRx")
+            check(gpu_pkg, oracle, src, w, pat, "xRGB", via="host")
+
+
+def test_every_variant_is_bit_exact(gpu_pkg, oracle):
+    rng = np.random.default_rng(5)
+    names = gpu_pkg.variant_names()
+    for (w, h) in [(1296, 75), (262, 19), (3840, 40)]:
+        stride = (w + 3) & ~3
+        src = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+        for v in range(len(names)):
+            for pat, fmt in (("rggb", "BGRx"), ("grbg", "xBGR")):
+                check(gpu_pkg, oracle, src, w, pat, fmt, variant=v)
+
+
+def test_rounding_stress_inputs(gpu_pkg, oracle):
+    w, h = 528, 20
+    yy, xx = np.mgrid[0:h, 0:w]
+    cases = [np.zeros((h, w)), np.full((h, w), 255), ((yy + xx) & 1) * 255, (xx & 1) * 255,
+             (yy & 1) * 255, (xx * 7 + yy * 13) & 255, 255 - ((xx + yy) & 1), (xx & 3) * 85]
+    for S in cases:
+        S = np.ascontiguousarray(S.astype(np.uint8))
+        for pat in PATTERNS:
+            check(gpu_pkg, oracle, S, w, pat, "RGBx")
+
+
+def test_strides_and_padding(gpu_pkg, oracle):
+    rng = np.random.default_rng(6)
+    w, h = 130, 21
+    src = rng.integers(0, 256, (h, 144), dtype=np.uint8)      # padded source rows
+    check(gpu_pkg, oracle, src, w, "grbg", "BGRx")
+    check(gpu_pkg, oracle, src, w, "grbg", "BGRx", dst_stride=4 * w + 40)
+    check(gpu_pkg, oracle, src, w, "grbg", "BGRx", dst_stride=4 * w + 40, via="host")
+    src2 = src.copy()
+    src2[:, w:] ^= 0xFF          # padding bytes never influence the result
+    r, g, b = gpu_pkg.FORMATS["BGRx"]
+    with gpu_pkg.Context(w, h, "grbg", "BGRx", src_stride=144) as ctx:
+        assert np.array_equal(ctx.process_host(src), ctx.process_host(src2))
+
+
+def test_known_md5_answers_full_size(gpu_pkg):
+    """BASELINE.json configs 2-4 geometries: md5 of the HIP output equals the md5 the compiled
+    reference element produced.  Input is generated ON the device."""
+    with open(os.path.join(ROOT, "tests", "golden", "known_md5.json")) as f:
+        entries = json.load(f)["entries"]
+    for e in entries:
+        w, h = e["width"], e["height"]
+        with gpu_pkg.Context(w, h, e["pattern"], e["format"]) as ctx:
+            d_src = ctx.device_alloc(ctx.src_bytes)
+            d_dst = ctx.device_alloc(ctx.dst_bytes)
+            ctx.fill_synthetic(d_src, 1, e["seed"])
+            ctx.process_device(d_src, d_dst, 1)
+            ctx.sync()
+            assert md5(ctx.from_device(d_src, ctx.src_bytes)) == e["md5_input"], e
+            assert md5(ctx.from_device(d_dst, ctx.dst_bytes)) == e["md5_output"], e
+            ctx.device_free(d_src)
+            ctx.device_free(d_dst)
+
+
+def test_batch_launch_equals_per_frame(gpu_pkg, oracle):
+    """One launch over N frames (blockIdx decodes frame, tile) == N oracle frames; also with a
+    frame pitch larger than the frame (gaps must stay untouched)."""
+    w, h, n = 640, 50, 9
+    src = oracle.fill_synthetic(w, h, n, seed=21)
+    want = oracle.bayer2rgb_batch(src, w, "gbrg", 2, 1, 0, nthreads=2)
+    with gpu_pkg.Context(w, h, "gbrg", "BGRx") as ctx:
+        got = ctx.process_batch_via_device(src)
+        assert np.array_equal(got, want)
+        gap_s, gap_d = ctx.src_bytes + 256, ctx.dst_bytes + 512
+        d_src = ctx.device_alloc(n * gap_s)
+        d_dst = ctx.device_alloc(n * gap_d)
+        host = np.full((n, gap_s), 0x11, np.uint8)
+        host[:, :ctx.src_bytes] = src.reshape(n, -1)
+        ctx.to_device(d_src, host)
+        ctx.to_device(d_dst, np.full(n * gap_d, 0xEE, np.uint8))
+        ctx.process_device(d_src, d_dst, n, src_frame_bytes=gap_s, dst_frame_bytes=gap_d)
+        ctx.sync()
+        out = ctx.from_device(d_dst, n * gap_d).reshape(n, gap_d)
+        assert np.array_equal(out[:, :ctx.dst_bytes].reshape(want.shape), want)
+        assert (out[:, ctx.dst_bytes:] == 0xEE).all()
+        ctx.device_free(d_src)
+        ctx.device_free(d_dst)
+
+
+def test_linearity_free_property_4k_batch(gpu_pkg, oracle):
+    """Full-size property check (config 3 geometry): frames of a 4K batch are independent and the
+    kernel is deterministic -- frame f of a batch launch equals the single-frame launch of the same
+    input, and frame 0 equals the oracle."""
+    w, h, n = 3840, 2160, 6
+    with gpu_pkg.Context(w, h, "rggb", "BGRx") as ctx:
+        d_src = ctx.device_alloc(n * ctx.src_bytes)
+        d_dst = ctx.device_alloc(n * ctx.dst_bytes)
+        d_one = ctx.device_alloc(ctx.dst_bytes)
+        ctx.fill_synthetic(d_src, n, seed=2)
+        ctx.process_device(d_src, d_dst, n)
+        ctx.sync()
+        batch = ctx.from_device(d_dst, n * ctx.dst_bytes).reshape(n, -1)
+        for f in (0, 3, 5):
+            ctx.process_device(d_src + f * ctx.src_bytes, d_one, 1)
+            ctx.sync()
+            assert np.array_equal(ctx.from_device(d_one, ctx.dst_bytes), batch[f])
+        src0 = oracle.fill_synthetic(w, h, 1, seed=2)[0]
+        assert np.array_equal(oracle.bayer2rgb(src0, w, "rggb", 2, 1, 0).reshape(-1), batch[0])
+        # frame 5 against the oracle too (frame index enters the generator)
+        src5 = oracle.fill_synthetic(w, h, 1, seed=2, first_frame=5)[0]
+        assert np.array_equal(oracle.bayer2rgb(src5, w, "rggb", 2, 1, 0).reshape(-1), batch[5])
+        for p in (d_src, d_dst, d_one):
+            ctx.device_free(p)
+
+
+def test_async_ring_order_and_tags(gpu_pkg, oracle):
+    w, h, n = 320, 64, 7
+    src = oracle.fill_synthetic(w, h, n, seed=31)
+    want = oracle.bayer2rgb_batch(src, w, "bggr", 0, 1, 2)
+    with gpu_pkg.Context(w, h, "bggr", "RGBx", inflight=3) as ctx:
+        outs = [np.zeros((h, 4 * w), np.uint8) for _ in range(n)]
+        done = []
+        for i in range(n):
+            if ctx.pending() == 3:
+                done.append(ctx.wait())
+            ctx.submit(src[i], outs[i], tag=1000 + i)
+        with pytest.raises(gpu_pkg.MibayerError):
+            while True:                     # ring never holds more than `inflight`
+                ctx.submit(src[0], np.zeros((h, 4 * w), np.uint8), tag=1)
+        # drain the extra submissions too
+        while ctx.pending():
+            done.append(ctx.wait())
+        assert done[:n] == [1000 + i for i in range(n)]
+        with pytest.raises(gpu_pkg.MibayerError) as e:
+            ctx.wait()
+        assert e.value.status == gpu_pkg.ERR_EMPTY
+        for i in range(n):
+            assert np.array_equal(outs[i], want[i])
+
+
+def test_pinned_host_memory_path(gpu_pkg, oracle):
+    import ctypes
+    w, h = 1920, 1080            # BASELINE.json configs[1]
+    L = gpu_pkg.lib()
+    with gpu_pkg.Context(w, h, "rggb", "BGRx") as ctx:
+        p_src = L.mibayer_host_alloc(ctx.src_bytes)
+        p_dst = L.mibayer_host_alloc(ctx.dst_bytes)
+        assert p_src and p_dst
+        src = np.ctypeslib.as_array(ctypes.cast(p_src, ctypes.POINTER(ctypes.c_uint8)), (h, w))
+        dst = np.ctypeslib.as_array(ctypes.cast(p_dst, ctypes.POINTER(ctypes.c_uint8)), (h, 4 * w))
+        src[:] = oracle.fill_synthetic(w, h, 1, seed=1)[0]
+        ctx.process_host(src, dst)
+        assert md5(dst) == "f14f6ad248ef0bac0f28546db6d14813"     # SURVEY.md B.3, 1080p rggb->BGRx
+        L.mibayer_host_free(p_src)
+        L.mibayer_host_free(p_dst)

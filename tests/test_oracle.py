@@ -1,0 +1,152 @@
+"""CPU tests of the oracle itself: it must reproduce the reference before it may judge the HIP path.
+
+Pins (see oracle/README.md): reference row kernels (oracle/_ref, when present), the survey's
+whole-element md5 known answers, the hand-checkable 4x4 frame, committed golden fixtures."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATTERNS = ("bggr", "gbrg", "grbg", "rggb")
+LAYOUTS = ("RGBx", "BGRx", "xRGB", "xBGR")
+
+
+def md5(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_prng_check_value(oracle):
+    # SURVEY.md Appendix C check value
+    row = oracle.fill_synthetic(7680, 1, 1, seed=3)[0, 0]
+    assert row[:8].tolist() == [204, 225, 36, 209, 124, 122, 38, 104]
+    assert np.array_equal(row, oracle.synthetic_frames(7680, 1, 1, 3)[0, 0])
+    a = oracle.fill_synthetic(34, 5, 3, seed=9, first_frame=2, stride=36)
+    b = oracle.synthetic_frames(34, 5, 3, 9, first_frame=2, stride=36)
+    assert np.array_equal(a, b)
+
+
+def test_hand_checkable_4x4(oracle):
+    # SURVEY.md Appendix B.4 (oracle = compiled reference element)
+    S = np.array([[10, 200, 30, 180], [90, 250, 70, 5], [50, 120, 255, 0], [33, 77, 141, 222]], np.uint8)
+    bggr = [[(250, 145, 10), (250, 200, 20), (250, 135, 30), (5, 180, 30)],
+            [(250, 90, 30), (250, 120, 87), (250, 70, 143), (5, 80, 143)],
+            [(164, 91, 50), (164, 120, 153), (164, 113, 255), (114, 0, 255)],
+            [(77, 33, 30), (77, 124, 87), (77, 141, 143), (222, 116, 143)]]
+    gbrg = [[(90, 10, 200), (80, 135, 200), (70, 30, 200), (70, 18, 180)],
+            [(90, 140, 160), (80, 250, 160), (70, 197, 160), (70, 5, 90)],
+            [(62, 50, 120), (84, 159, 120), (106, 255, 120), (106, 185, 0)],
+            [(33, 54, 160), (87, 77, 160), (141, 110, 160), (141, 222, 90)]]
+    for pat, want in (("bggr", bggr), ("gbrg", gbrg)):
+        for impl in ("c", "np"):
+            if impl == "c":
+                out = oracle.bayer2rgb(S, 4, pat, 0, 1, 2).reshape(4, 4, 4)
+            else:
+                out = oracle.np_oracle.bayer2rgb(S, pat, 0, 1, 2)
+            assert out[..., :3].tolist() == [[list(p) for p in row] for row in want], (pat, impl)
+            assert (out[..., 3] == 255).all()
+
+
+def test_known_md5_answers(oracle):
+    with open(os.path.join(ROOT, "tests", "golden", "known_md5.json")) as f:
+        entries = json.load(f)["entries"]
+    assert len(entries) >= 7
+    for e in entries:
+        src = oracle.fill_synthetic(e["width"], e["height"], 1, e["seed"])[0]
+        assert md5(src) == e["md5_input"]
+        r, g, b = oracle.LAYOUTS[e["format"]]
+        out = oracle.bayer2rgb(src, e["width"], e["pattern"], r, g, b)
+        assert md5(out) == e["md5_output"], e
+
+
+def test_golden_fixtures_all_implementations(oracle, golden):
+    names = [k for k in golden.files if k.startswith("in_")]
+    assert len(names) >= 17
+    for name in names:
+        dims = name[3:]
+        w, h = (int(v) for v in dims.split("x"))
+        src = golden[name]
+        for pat in PATTERNS:
+            for lay in LAYOUTS:
+                want = golden["out_%s_%s_%s" % (dims, pat, lay)]
+                r, g, b = oracle.LAYOUTS[lay]
+                got_c = oracle.bayer2rgb(src, w, pat, r, g, b)
+                got_np = oracle.np_oracle.bayer2rgb(src[:, :w], pat, r, g, b).reshape(h, 4 * w)
+                assert np.array_equal(got_c, want), (dims, pat, lay)
+                assert np.array_equal(got_np, want), (dims, pat, lay)
+
+
+def test_own_rows_equal_reference_rows(oracle):
+    if not oracle.have_ref_rows():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    rng = np.random.default_rng(5)
+    for (w, h) in [(4, 3), (6, 4), (66, 50), (64, 48), (130, 33), (1920, 8)]:
+        stride = (w + 3) & ~3
+        src = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+        for pat in PATTERNS:
+            for lay in LAYOUTS:
+                r, g, b = oracle.LAYOUTS[lay]
+                a = oracle.bayer2rgb(src, w, pat, r, g, b)
+                b_ = oracle.bayer2rgb(src, w, pat, r, g, b, ref_rows=True)
+                assert np.array_equal(a, b_), (w, h, pat, lay)
+
+
+def test_extreme_inputs_closed_form_vs_ring(oracle):
+    # rounding stress: all-0, all-255, 0/255 checkerboards, gradients
+    w, h = 34, 12
+    yy, xx = np.mgrid[0:h, 0:w]
+    cases = [np.zeros((h, w)), np.full((h, w), 255), ((yy + xx) & 1) * 255, (xx & 1) * 255,
+             (yy & 1) * 255, (xx * 7 + yy * 13) & 255, 255 - ((xx + yy) & 1)]
+    for S in cases:
+        S = S.astype(np.uint8)
+        src = np.zeros((h, 36), np.uint8)
+        src[:, :w] = S
+        for pat in PATTERNS:
+            a = oracle.bayer2rgb(src, w, pat, 2, 1, 0).reshape(h, w, 4)
+            b = oracle.np_oracle.bayer2rgb(S, pat, 2, 1, 0)
+            assert np.array_equal(a, b)
+
+
+def test_bottom_row_pairs_with_row_h_minus_4(oracle):
+    # the parity trap of SURVEY.md A.4(3): changing row H-4 changes the last output row,
+    # changing row H-2 changes it too (via the row above), but a "mirror" implementation
+    # would not depend on row H-4 at all
+    rng = np.random.default_rng(1)
+    S = rng.integers(0, 256, (12, 16), dtype=np.uint8)
+    base = oracle.bayer2rgb(S, 16, "bggr", 0, 1, 2)
+    S2 = S.copy()
+    S2[12 - 4] ^= 0xFF
+    mod = oracle.bayer2rgb(S2, 16, "bggr", 0, 1, 2)
+    assert not np.array_equal(base[11], mod[11])
+
+
+def test_padding_and_dst_stride(oracle):
+    rng = np.random.default_rng(2)
+    w, h = 10, 6
+    src = rng.integers(0, 256, (h, 12), dtype=np.uint8)
+    a = oracle.bayer2rgb(src, w, "grbg", 1, 2, 3)
+    src2 = src.copy()
+    src2[:, w:] ^= 0x5A          # padding bytes must not matter
+    assert np.array_equal(a, oracle.bayer2rgb(src2, w, "grbg", 1, 2, 3))
+    wide = oracle.bayer2rgb(src, w, "grbg", 1, 2, 3, dst_stride=4 * w + 24)
+    assert np.array_equal(wide[:, :4 * w], a)
+    assert (wide[:, 4 * w:] == 0xA5).all()      # row padding untouched
+
+
+def test_batch_threads_match_single(oracle):
+    src = oracle.fill_synthetic(64, 48, 5, seed=11)
+    one = np.stack([oracle.bayer2rgb(f, 64, "rggb", 2, 1, 0) for f in src])
+    for nt in (1, 2, 4):
+        assert np.array_equal(oracle.bayer2rgb_batch(src, 64, "rggb", 2, 1, 0, nthreads=nt), one)
+
+
+def test_domain_is_rejected(oracle):
+    ok = np.zeros((4, 4), np.uint8)
+    for (w, h) in [(2, 4), (5, 4), (4, 2), (4, 1)]:
+        src = np.zeros((h, 8), np.uint8)
+        with pytest.raises(ValueError):
+            oracle.bayer2rgb(src, w, "bggr", 0, 1, 2)
+    with pytest.raises(ValueError):
+        oracle.bayer2rgb(ok, 4, "bggr", 0, 2, 1)    # not one of the reference's 4 layouts
