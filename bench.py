@@ -82,7 +82,7 @@ def aggregate_mpix_per_s(pixels_per_step_per_rank, world_size, steps, elapsed_s)
 # CPU baseline (oracle) -- reported beside the GPU number, never the thing optimised
 # ----------------------------------------------------------------------------------------------
 
-def cpu_baseline(budget_s=12.0, sample_frames=16):
+def cpu_baseline(budget_s=12.0, sample_frames=32):
     import __graft_entry__ as entry
     oracle = entry.load_oracle()
     ncores = os.cpu_count() or 1
@@ -100,15 +100,16 @@ def cpu_baseline(budget_s=12.0, sample_frames=16):
                 return WIDTH * HEIGHT * sample_frames * reps / el / 1e6, reps, el
 
     v1, reps1, el1 = run(1, budget_s * 0.6)
-    vn, repsn, eln = run(ncores, budget_s * 0.4)
+    nthreads = min(ncores, sample_frames)
+    vn, repsn, eln = run(nthreads, budget_s * 0.4)
     return {
         "value": round(v1, 1), "unit": "Mpix/s", "cores": 1, "kind": "port",
         "sample": "%d of the %d 4K frames (seed %d, frames 0-%d) -> %s, all 4 orders cycled, "
                   "%d passes in %.1f s, oracle/bayer2rgb_oracle.c gcc -O3, 1 thread (the reference "
                   "element is single-threaded per stream)" % (
                       sample_frames, BATCH, SEED, sample_frames - 1, FORMAT, reps1, el1),
-        "all_cores": {"value": round(vn, 1), "cores": ncores, "passes": repsn,
-                      "note": "frame-parallel pthreads"},
+        "all_cores": {"value": round(vn, 1), "cores": nthreads, "host_cores": ncores, "passes": repsn,
+                      "note": "frame-parallel pthreads, one frame per thread"},
     }
 
 
@@ -194,7 +195,10 @@ def run(args):
     variant = args.variant
     ctxs = {o: pkg.Context(WIDTH, HEIGHT, o, FORMAT, device=local_rank, variant=variant) for o in ORDERS}
     ctx0 = ctxs[ORDERS[0]]
-    stream = torch.cuda.current_stream().cuda_stream
+    # one side stream for every launch of the run; the HIP events below are recorded on it
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
     d_src = torch.empty(BATCH * ctx0.src_bytes, dtype=torch.uint8, device="cuda")
     d_dst = torch.empty(BATCH * ctx0.dst_bytes, dtype=torch.uint8, device="cuda")
     # synthetic frames generated in HBM: this rank's i-th frame is global frame rank + i*world

@@ -87,6 +87,7 @@ ABI = {
     "mibayer_pending": (ctypes.c_int, [_vp]),
     "mibayer_process_device": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
                                               ctypes.c_int, _vp]),
+    "mibayer_ctx_stream": (_vp, [_vp]),
     "mibayer_sync": (ctypes.c_int, [_vp]),
     "mibayer_time_device": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -237,11 +238,18 @@ class Context:
                "mibayer_copy_from_device")
         return out
 
+    @property
+    def stream(self):
+        """The context's own compute stream (hipStream_t as an int)."""
+        return lib().mibayer_ctx_stream(self._h)
+
     def process_device(self, d_src, d_dst, nframes=1, src_frame_bytes=None, dst_frame_bytes=None,
-                       stream=None):
+                       stream="ctx"):
+        """stream: "ctx" = the context's compute stream, else a hipStream_t value (0/None = null stream)."""
+        s = self.stream if stream == "ctx" else (stream or 0)
         _check(lib().mibayer_process_device(
             self._h, _vp(d_src), src_frame_bytes or self.src_bytes, _vp(d_dst),
-            dst_frame_bytes or self.dst_bytes, nframes, _vp(stream or 0)), "mibayer_process_device")
+            dst_frame_bytes or self.dst_bytes, nframes, _vp(s)), "mibayer_process_device")
 
     def sync(self):
         _check(lib().mibayer_sync(self._h), "mibayer_sync")
@@ -255,10 +263,11 @@ class Context:
             "mibayer_time_device")
         return ms.value
 
-    def fill_synthetic(self, d_src, nframes, seed, first_frame=0, src_frame_bytes=None, stream=None):
+    def fill_synthetic(self, d_src, nframes, seed, first_frame=0, src_frame_bytes=None, stream="ctx"):
+        s = self.stream if stream == "ctx" else (stream or 0)
         _check(lib().mibayer_fill_synthetic(
             self._h, _vp(d_src), src_frame_bytes or self.src_bytes, first_frame, nframes, seed,
-            _vp(stream or 0)), "mibayer_fill_synthetic")
+            _vp(s)), "mibayer_fill_synthetic")
 
     def launch_geometry(self, nframes=1):
         v = [ctypes.c_int() for _ in range(4)]

@@ -166,7 +166,7 @@ static void fill_params (const mibayer_ctx *c, KParams &p, const void *d_src,
   p.tiles_x = (f.width + c->var->tile_w - 1) / c->var->tile_w;
   p.tiles_y = (f.height + c->var->tile_h - 1) / c->var->tile_h;
   p.ntiles = (long long) nframes * p.tiles_x * p.tiles_y;
-  p.chunk = (p.ntiles + kNumXcd - 1) / kNumXcd;
+  p.chunk = c->var->xcd_remap ? (p.ntiles + kNumXcd - 1) / kNumXcd : 0;
   for (int k = 0; k < 4; k++)
     p.sel[k] = c->sel[k];
   p.swap_rows = c->swap_rows;
@@ -185,7 +185,7 @@ static int launch (mibayer_ctx *c, const void *d_src, size_t src_frame_bytes,
       && (nframes == 1 || (src_frame_bytes % 16 == 0
               && dst_frame_bytes % 16 == 0));
   void (*kern) (KParams) = fast ? c->var->fast : c->var->generic;
-  const long long grid = p.chunk * kNumXcd;
+  const long long grid = p.chunk ? p.chunk * kNumXcd : p.ntiles;
   if (grid > 0x7fffffffLL)
     return MIBAYER_ERR_GEOMETRY;
   hipLaunchKernelGGL (kern, dim3 ((unsigned) grid), dim3 (c->var->threads), 0,
@@ -403,7 +403,7 @@ extern "C" int mibayer_launch_geometry (const mibayer_ctx *c, int nframes,
   if (tiles_per_frame)
     *tiles_per_frame = p.tiles_x * p.tiles_y;
   if (grid_blocks)
-    *grid_blocks = (int) (p.chunk * kNumXcd);
+    *grid_blocks = (int) (p.chunk ? p.chunk * kNumXcd : p.ntiles);
   return MIBAYER_OK;
 }
 
@@ -544,8 +544,13 @@ extern "C" int mibayer_process_device (mibayer_ctx *c, const void *d_src,
   DeviceGuard guard (c->device);
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
-  hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->s_compute;
-  return launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes, s);
+  return launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes,
+      (hipStream_t) hip_stream);
+}
+
+extern "C" void *mibayer_ctx_stream (mibayer_ctx *c)
+{
+  return c ? (void *) c->s_compute : NULL;
 }
 
 extern "C" int mibayer_sync (mibayer_ctx *c)
@@ -667,7 +672,7 @@ extern "C" int mibayer_fill_synthetic (mibayer_ctx *c, void *d_src,
   DeviceGuard guard (c->device);
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
-  hipStream_t s = hip_stream ? (hipStream_t) hip_stream : c->s_compute;
+  hipStream_t s = (hipStream_t) hip_stream;
   HIP_TRY (launch_fill_synthetic ((uint8_t *) d_src, c->cfg.width,
           c->cfg.height, c->cfg.src_stride, src_frame_bytes, first_frame,
           nframes, seed, s));

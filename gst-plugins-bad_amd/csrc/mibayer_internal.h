@@ -25,7 +25,7 @@ struct KParams {
   int tiles_x;
   int tiles_y;
   long long ntiles;             /* nframes * tiles_y * tiles_x                 */
-  long long chunk;              /* tiles per XCD = ceil(ntiles / 8)            */
+  long long chunk;              /* tiles per XCD = ceil(ntiles / 8); 0 = identity */
   uint32_t sel[4];              /* v_perm_b32 selectors of output pixel 0..3   */
   int swap_rows;                /* 1 for grbg / gbrg                           */
 };
@@ -38,6 +38,8 @@ struct KParams {
 __host__ __device__ inline long long
 block_to_tile (long long block, long long ntiles, long long chunk)
 {
+  if (chunk == 0)               /* identity map (A/B arm) */
+    return block < ntiles ? block : -1;
   long long xcd = block % kNumXcd;
   long long i = block / kNumXcd;
   long long id = xcd * chunk + i;
@@ -49,6 +51,7 @@ struct Variant {
   int tile_w;                   /* pixels */
   int tile_h;                   /* rows   */
   int threads;
+  int xcd_remap;                /* 1: XCD-chunked block->tile map, 0: identity (A/B arm) */
   void (*fast) (KParams);       /* W%16==0, 16-byte aligned rows both sides */
   void (*generic) (KParams);    /* any even W >= 4, 4-byte aligned rows     */
 };

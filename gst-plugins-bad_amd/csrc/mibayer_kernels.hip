@@ -187,13 +187,22 @@ __device__ __forceinline__ u32x4 merge_rows (const Lines &u, const Lines &c,
   return px;
 }
 
-template <bool NT, bool GENERIC>
+/* ST = cache policy of the 16-byte output stores (the output is never re-read):
+ * 0 plain, 1 nt (streaming hint), 2 sc1, 3 sc0 sc1 (write-through, line dropped
+ * from the XCD L2), 4 nt sc1 */
+template <int ST, bool GENERIC>
 __device__ __forceinline__ void store_pixels (uint8_t *p, u32x4 px,
     int lastmode)
 {
   if constexpr (!GENERIC) {
-    if constexpr (NT)
+    if constexpr (ST == 1)
       __builtin_nontemporal_store (px, (u32x4 *) p);
+    else if constexpr (ST == 2)
+      asm volatile ("global_store_dwordx4 %0, %1, off sc1" :: "v" (p), "v" (px) : "memory");
+    else if constexpr (ST == 3)
+      asm volatile ("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v" (p), "v" (px) : "memory");
+    else if constexpr (ST == 4)
+      asm volatile ("global_store_dwordx4 %0, %1, off sc1 nt" :: "v" (p), "v" (px) : "memory");
     else
       *(u32x4 *) p = px;
   } else {
@@ -220,7 +229,7 @@ __device__ __forceinline__ int map_row (int y, int height, int dn_last)
 /* WX x WY waves per workgroup; a wave covers 256 px (64 lanes x 4 px) and marches
  * RPW rows.  Tile = (256*WX) x (WY*RPW) px.
  * NEIGH: 0 = DPP wave shift, 1 = __shfl_up/down (ds_bpermute), 2 = LDS reads.   */
-template <int WX, int WY, int RPW, int NEIGH, bool NT, bool INTRIN,
+template <int WX, int WY, int RPW, int NEIGH, int ST, bool INTRIN,
     bool GENERIC>
 __global__ void __launch_bounds__ (64 * WX * WY)
 bayer2rgb_lds_kernel (KParams p)
@@ -363,7 +372,7 @@ bayer2rgb_lds_kernel (KParams p)
     const int type = (k & 1) ^ p.swap_rows;
     const u32x4 px = merge_rows<INTRIN> (up, cur, dn, type, p.sel);
     if (active && k < nrows)
-      store_pixels<NT, GENERIC> (out, px, lastmode);
+      store_pixels<ST, GENERIC> (out, px, lastmode);
     out += p.dst_stride;
     up = cur;
     cur = dn;
@@ -375,7 +384,7 @@ bayer2rgb_lds_kernel (KParams p)
 /* ------------------------------------------------------------------------- */
 /* Experiment arm (same arithmetic): rows come straight from global memory, the
  * wave-edge lanes fetch their neighbour dword with a second, 2-lane load.      */
-template <int WX, int WY, int RPW, bool NT, bool INTRIN, bool GENERIC>
+template <int WX, int WY, int RPW, int ST, bool INTRIN, bool GENERIC>
 __global__ void __launch_bounds__ (64 * WX * WY)
 bayer2rgb_direct_kernel (KParams p)
 {
@@ -440,7 +449,7 @@ bayer2rgb_direct_kernel (KParams p)
     const int type = (k & 1) ^ p.swap_rows;
     const u32x4 px = merge_rows<INTRIN> (up, cur, dn, type, p.sel);
     if (active && k < nrows)
-      store_pixels<NT, GENERIC> (out, px, lastmode);
+      store_pixels<ST, GENERIC> (out, px, lastmode);
     out += p.dst_stride;
     up = cur;
     cur = dn;
@@ -451,33 +460,40 @@ bayer2rgb_direct_kernel (KParams p)
 /* variant table                                                               */
 /* ------------------------------------------------------------------------- */
 
-#define LDS_VARIANT(name, WX, WY, RPW, NEIGH, NT, INTRIN)                      \
-  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY),                          \
-    bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, NT, INTRIN, false>,               \
-    bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, NT, INTRIN, true> }
-#define DIRECT_VARIANT(name, WX, WY, RPW, NT, INTRIN)                          \
-  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY),                          \
-    bayer2rgb_direct_kernel<WX, WY, RPW, NT, INTRIN, false>,                   \
-    bayer2rgb_direct_kernel<WX, WY, RPW, NT, INTRIN, true> }
+#define LDS_VARIANT(name, WX, WY, RPW, NEIGH, ST, INTRIN, REMAP)               \
+  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), REMAP,                   \
+    bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, false>,               \
+    bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, true> }
+#define DIRECT_VARIANT(name, WX, WY, RPW, ST, INTRIN, REMAP)                   \
+  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), REMAP,                   \
+    bayer2rgb_direct_kernel<WX, WY, RPW, ST, INTRIN, false>,                   \
+    bayer2rgb_direct_kernel<WX, WY, RPW, ST, INTRIN, true> }
 
 static const Variant kVariants[] = {
   /* 0: default (kept equal to the best measured arm) */
-  LDS_VARIANT ("lds_1x4_r8_dpp", 1, 4, 8, 0, false, true),
+  LDS_VARIANT ("lds_1x4_r8_dpp_nt", 1, 4, 8, 0, 1, true, 1),
   /* 1.. : tuning / verification arms */
-  LDS_VARIANT ("lds_1x4_r8_dpp_nt", 1, 4, 8, 0, true, true),
-  LDS_VARIANT ("lds_1x4_r16_dpp", 1, 4, 16, 0, false, true),
-  LDS_VARIANT ("lds_4x1_r16_dpp", 4, 1, 16, 0, false, true),
-  LDS_VARIANT ("lds_4x1_r32_dpp", 4, 1, 32, 0, false, true),
-  LDS_VARIANT ("lds_2x2_r16_dpp", 2, 2, 16, 0, false, true),
-  LDS_VARIANT ("lds_1x4_r8_shfl", 1, 4, 8, 1, false, true),
-  LDS_VARIANT ("lds_1x4_r8_ldsnb", 1, 4, 8, 2, false, true),
-  LDS_VARIANT ("lds_1x4_r8_ldsnb_swar", 1, 4, 8, 2, false, false),
-  DIRECT_VARIANT ("direct_1x4_r8", 1, 4, 8, false, true),
-  DIRECT_VARIANT ("direct_1x4_r16", 1, 4, 16, false, true),
-  DIRECT_VARIANT ("direct_1x4_r16_nt", 1, 4, 16, true, true),
-  DIRECT_VARIANT ("direct_1x1_r16", 1, 1, 16, false, true),
-  LDS_VARIANT ("lds_1x8_r8_dpp", 1, 8, 8, 0, false, true),
-  LDS_VARIANT ("lds_4x1_r16_dpp_nt", 4, 1, 16, 0, true, true),
+  LDS_VARIANT ("lds_1x4_r8_dpp", 1, 4, 8, 0, 0, true, 1),
+  LDS_VARIANT ("lds_1x4_r8_dpp_nt_noxcd", 1, 4, 8, 0, 1, true, 0),
+  LDS_VARIANT ("lds_1x4_r8_dpp_sc1", 1, 4, 8, 0, 2, true, 1),
+  LDS_VARIANT ("lds_1x4_r8_dpp_sc0sc1", 1, 4, 8, 0, 3, true, 1),
+  LDS_VARIANT ("lds_1x4_r8_dpp_ntsc1", 1, 4, 8, 0, 4, true, 1),
+  LDS_VARIANT ("lds_1x4_r16_dpp_nt", 1, 4, 16, 0, 1, true, 1),
+  LDS_VARIANT ("lds_1x4_r4_dpp_nt", 1, 4, 4, 0, 1, true, 1),
+  LDS_VARIANT ("lds_1x8_r8_dpp_nt", 1, 8, 8, 0, 1, true, 1),
+  LDS_VARIANT ("lds_1x8_r4_dpp_nt", 1, 8, 4, 0, 1, true, 1),
+  LDS_VARIANT ("lds_1x2_r16_dpp_nt", 1, 2, 16, 0, 1, true, 1),
+  LDS_VARIANT ("lds_1x1_r32_dpp_nt", 1, 1, 32, 0, 1, true, 1),
+  LDS_VARIANT ("lds_4x1_r16_dpp_nt", 4, 1, 16, 0, 1, true, 1),
+  LDS_VARIANT ("lds_4x1_r32_dpp_nt", 4, 1, 32, 0, 1, true, 1),
+  LDS_VARIANT ("lds_4x2_r16_dpp_nt", 4, 2, 16, 0, 1, true, 1),
+  LDS_VARIANT ("lds_2x2_r16_dpp_nt", 2, 2, 16, 0, 1, true, 1),
+  LDS_VARIANT ("lds_1x4_r8_shfl_nt", 1, 4, 8, 1, 1, true, 1),
+  LDS_VARIANT ("lds_1x4_r8_ldsnb_nt", 1, 4, 8, 2, 1, true, 1),
+  LDS_VARIANT ("lds_1x4_r8_ldsnb_swar", 1, 4, 8, 2, 0, false, 1),
+  DIRECT_VARIANT ("direct_1x4_r16_nt", 1, 4, 16, 1, true, 1),
+  DIRECT_VARIANT ("direct_1x1_r16_nt", 1, 1, 16, 1, true, 1),
+  DIRECT_VARIANT ("direct_1x4_r8", 1, 4, 8, 0, true, 1),
 };
 
 int variant_count ()

@@ -128,17 +128,20 @@ int mibayer_pending (const mibayer_ctx *ctx);
 
 /* Enqueues ONE kernel launch converting `nframes` frames that already live in
  * device memory: frame f is read at d_src + f*src_frame_bytes and written at
- * d_dst + f*dst_frame_bytes.  `hip_stream` is a hipStream_t (NULL = the
- * context's compute stream).  Returns after the launch is enqueued. */
+ * d_dst + f*dst_frame_bytes.  `hip_stream` is the hipStream_t to launch on,
+ * used as given (NULL is HIP's null stream); pass mibayer_ctx_stream() for the
+ * context's own compute stream.  Returns after the launch is enqueued. */
 int mibayer_process_device (mibayer_ctx *ctx, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     void *hip_stream);
+/* the context's compute stream (a hipStream_t), created non-blocking */
+void *mibayer_ctx_stream (mibayer_ctx *ctx);
 /* waits for the context's own streams */
 int mibayer_sync (mibayer_ctx *ctx);
 
-/* Times `reps` back-to-back launches of mibayer_process_device with HIP events
- * recorded on the launch stream (after `warmup` untimed launches); writes the
- * mean milliseconds per launch. */
+/* Times `reps` back-to-back launches of mibayer_process_device on the context's
+ * compute stream with HIP events recorded on that stream (after `warmup` untimed
+ * launches); writes the mean milliseconds per launch. */
 int mibayer_time_device (mibayer_ctx *ctx, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     int warmup, int reps, float *ms_per_launch);
@@ -163,7 +166,7 @@ int mibayer_copy_from_device (mibayer_ctx *ctx, void *dst, const void *d_src,
  * first_frame+nframes-1 with the context's width/height/src_stride. */
 int mibayer_fill_synthetic (mibayer_ctx *ctx, void *d_src,
     size_t src_frame_bytes, uint32_t first_frame, int nframes, uint32_t seed,
-    void *hip_stream);
+    void *hip_stream /* used as given, like mibayer_process_device */);
 
 /* ---- introspection (tests) --------------------------------------------------- */
 

@@ -1,0 +1,172 @@
+"""The GStreamer boundary: plugin `bayer`, element `bayer2rgb` (gst-plugins-bad_amd/gst/).
+
+CPU tests pin what a neighbouring element can observe -- factory/klass/metadata strings, pad
+templates, rank -- to the reference's values (gst/bayer/gstbayer2rgb.c:134-138, :180-190,
+gst/bayer/gstbayer.c:28-43) and check that without a GPU the element refuses loudly.
+GPU tests run real pipelines (BASELINE.json configs[0]: videotestsrc 640x480 bggr -> RGBx) and compare
+the bytes written by the element with the oracle applied to the bytes that entered it.
+Pattern follows the reference's pipeline tests (tests/check/elements/autovideoconvert.c:56-96)."""
+import hashlib
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_DIR = os.path.join(ROOT, "gst-plugins-bad_amd")
+GST_PREFIX = os.environ.get("GST_PREFIX", "/opt/conda")
+GST_LAUNCH = os.path.join(GST_PREFIX, "bin", "gst-launch-1.0")
+GST_INSPECT = os.path.join(GST_PREFIX, "bin", "gst-inspect-1.0")
+PLUGIN = os.path.join(PKG_DIR, "libgstbayer.so")
+
+needs_gst = pytest.mark.skipif(
+    not (os.path.exists(GST_LAUNCH) and os.path.exists(GST_INSPECT)),
+    reason="no GStreamer installation under %s" % GST_PREFIX)
+
+
+def gst_env(tmp):
+    env = dict(os.environ)
+    env.update({
+        "GST_PLUGIN_SYSTEM_PATH_1_0": os.path.join(GST_PREFIX, "lib", "gstreamer-1.0"),
+        "GST_PLUGIN_PATH_1_0": PKG_DIR,
+        "GST_PLUGIN_SCANNER": os.path.join(GST_PREFIX, "libexec", "gstreamer-1.0", "gst-plugin-scanner"),
+        "GST_REGISTRY": os.path.join(str(tmp), "registry.bin"),
+    })
+    return env
+
+
+@pytest.fixture(scope="module")
+def plugin(pkg):
+    if not (os.path.exists(GST_LAUNCH) and os.path.exists(GST_INSPECT)):
+        pytest.skip("no GStreamer installation")
+    if not os.path.exists(PLUGIN):
+        pkg.build()
+    assert os.path.exists(PLUGIN), "libgstbayer.so was not built although GStreamer is installed"
+    return PLUGIN
+
+
+def launch(tmp, pipeline, timeout=300):
+    return subprocess.run([GST_LAUNCH, "-q"] + pipeline.split(), capture_output=True, text=True,
+                          env=gst_env(tmp), timeout=timeout)
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+# ------------------------------------------------------------------------------------------- CPU
+
+@needs_gst
+def test_factory_details_match_reference(plugin, tmp_path):
+    out = subprocess.run([GST_INSPECT, "bayer2rgb"], capture_output=True, text=True,
+                         env=gst_env(tmp_path), timeout=120).stdout
+    want = {
+        "Rank": "none (0)",                                   # GST_RANK_NONE, gstbayer2rgb.c:149
+        "Long-name": "Bayer to RGB decoder for cameras",       # :181
+        "Klass": "Filter/Converter/Video",                     # :181 (autovideoconvert matches on it)
+        "Description": "Converts video/x-bayer to video/x-raw",  # :182
+        "Author": "William Brack <wbrack@mmm.com.hk>",         # :183
+        "Name": "bayer",                                       # gstbayer.c:40
+    }
+    fields = {}
+    for line in out.splitlines():
+        parts = line.strip().split(None, 1)
+        if len(parts) == 2 and parts[0] not in fields:
+            fields[parts[0]] = parts[1].strip()
+    for k, v in want.items():
+        assert fields.get(k) == v, (k, fields.get(k))
+    assert "Elements to convert Bayer images" in out        # gstbayer.c:41
+    assert "GstBayer2RGB" in out and "GstBaseTransform" in out
+    # pad templates, gstbayer2rgb.c:134-138: order of the src formats matters (first = default)
+    assert "format: { (string)bggr, (string)grbg, (string)gbrg, (string)rggb }" in out
+    assert ("format: { (string)RGBx, (string)xRGB, (string)BGRx, (string)xBGR, (string)RGBA, "
+            "(string)ARGB, (string)BGRA, (string)ABGR }") in out
+    assert out.count("Availability: Always") == 2
+
+
+@needs_gst
+def test_without_gpu_the_element_errors_instead_of_falling_back(plugin, pkg, tmp_path):
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    res = launch(tmp_path, "videotestsrc num-buffers=1 ! video/x-bayer,format=bggr,width=64,height=48 "
+                           "! bayer2rgb ! fakesink")
+    assert res.returncode != 0
+    assert "no usable MI355X" in res.stderr + res.stdout
+
+
+@needs_gst
+def test_unknown_downstream_format_fails_negotiation(plugin, tmp_path):
+    res = launch(tmp_path, "videotestsrc num-buffers=1 ! video/x-bayer,format=bggr,width=64,height=48 "
+                           "! bayer2rgb ! video/x-raw,format=I420 ! fakesink")
+    assert res.returncode != 0            # caps logic only; never reaches the GPU
+
+
+# ------------------------------------------------------------------------------------------- GPU
+
+def run_file_pipeline(tmp, src_bytes, w, h, order, fmt, nframes=1):
+    inp = os.path.join(str(tmp), "in.raw")
+    outp = os.path.join(str(tmp), "out_%s_%s.raw" % (order, fmt or "default"))
+    with open(inp, "wb") as f:
+        f.write(src_bytes)
+    stride = (w + 3) & ~3
+    caps = " ! video/x-raw,format=%s" % fmt if fmt else ""
+    res = launch(tmp, "filesrc location=%s blocksize=%d ! video/x-bayer,format=%s,width=%d,height=%d,"
+                      "framerate=1/1 ! bayer2rgb%s ! filesink location=%s"
+                 % (inp, stride * h, order, w, h, caps, outp))
+    assert res.returncode == 0, res.stderr[-1500:]
+    assert "WARNING" not in res.stderr and "ERROR" not in res.stderr, res.stderr[-1500:]
+    data = open(outp, "rb").read()
+    assert len(data) == nframes * w * h * 4
+    return np.frombuffer(data, np.uint8).reshape(nframes, h, 4 * w)
+
+
+@pytest.mark.gpu
+@needs_gst
+def test_config1_videotestsrc_640x480_bggr_rgbx(plugin, gpu_pkg, oracle, tmp_path):
+    """BASELINE.json configs[0] through the drop-in element."""
+    inp, outp = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
+    res = launch(tmp_path,
+                 "videotestsrc num-buffers=1 ! video/x-bayer,format=bggr,width=640,height=480,framerate=30/1 "
+                 "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! bayer2rgb "
+                 "! video/x-raw,format=RGBx ! filesink location=%s" % (inp, outp))
+    assert res.returncode == 0, res.stderr[-1500:]
+    assert "WARNING" not in res.stderr and "ERROR" not in res.stderr
+    src = np.fromfile(inp, np.uint8).reshape(480, 640)
+    got = np.fromfile(outp, np.uint8).reshape(480, 2560)
+    assert np.array_equal(got, oracle.bayer2rgb(src, 640, "bggr", 0, 1, 2))
+    if md5(src.tobytes()) == "1e5c707ce781f5ebe87429f1e15e8c77":       # videotestsrc 1.14.0 smpte frame
+        # output of the compiled reference element for exactly this input
+        assert md5(got.tobytes()) == "7585ebf1d99b583a3e30b81f45ceb89c"
+
+
+@pytest.mark.gpu
+@needs_gst
+def test_default_negotiation_picks_rgbx(plugin, gpu_pkg, oracle, tmp_path):
+    src = oracle.fill_synthetic(64, 48, 1, seed=7)[0]
+    got = run_file_pipeline(tmp_path, src.tobytes(), 64, 48, "bggr", None)[0]
+    assert md5(got.tobytes()) == "5e213c796b18997f2a81d54aee9afcd8"    # SURVEY.md B.3, 64x48 seed 7 RGBx
+
+
+@pytest.mark.gpu
+@needs_gst
+def test_all_orders_and_formats_through_pipeline(plugin, gpu_pkg, oracle, tmp_path):
+    w, h = 322, 50                      # W%4 == 2: padded source rows (stride 324), generic kernel
+    src = oracle.fill_synthetic(w, h, 1, seed=13, stride=324)[0]
+    for order in ("bggr", "gbrg", "grbg", "rggb"):
+        for fmt in ("RGBx", "xRGB", "BGRx", "xBGR", "RGBA", "ARGB", "BGRA", "ABGR"):
+            got = run_file_pipeline(tmp_path, src.tobytes(), w, h, order, fmt)[0]
+            r, g, b = gpu_pkg.FORMATS[fmt]
+            assert np.array_equal(got, oracle.bayer2rgb(src, w, order, r, g, b)), (order, fmt)
+
+
+@pytest.mark.gpu
+@needs_gst
+def test_multi_frame_stream_1080p(plugin, gpu_pkg, oracle, tmp_path):
+    w, h, n = 1920, 1080, 4             # BASELINE.json configs[1] geometry, rggb -> BGRx
+    src = oracle.fill_synthetic(w, h, n, seed=1)
+    got = run_file_pipeline(tmp_path, src.tobytes(), w, h, "rggb", "BGRx", nframes=n)
+    want = oracle.bayer2rgb_batch(src, w, "rggb", 2, 1, 0, nthreads=2)
+    assert np.array_equal(got, want)
+    assert md5(got[0].tobytes()) == "f14f6ad248ef0bac0f28546db6d14813"

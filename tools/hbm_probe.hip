@@ -68,12 +68,15 @@ int main (int argc, char **argv)
 {
   const size_t out_bytes = (size_t) 3840 * 2160 * 4 * 64;     /* the 4K x 64 batch output: 2.12 GB */
   const size_t in_bytes = out_bytes / 4;
-  const int reps = 20;
+  const int reps = argc > 1 ? atoi (argv[1]) : 20;
+  const int only_grid = argc > 2 ? atoi (argv[2]) : 0;
   uint8_t *a, *b; uint32_t *sink;
   CK (hipMalloc (&a, out_bytes)); CK (hipMalloc (&b, out_bytes)); CK (hipMalloc (&sink, 4));
   CK (hipMemset (a, 1, out_bytes)); CK (hipMemset (b, 2, out_bytes));
   const int grids[] = { 2048, 8192, 32768 };
   for (int g : grids) {
+    if (only_grid && g != only_grid)
+      continue;
     dim3 grid (g), blk (256);
     double t;
     t = time_ms ([&] { hipLaunchKernelGGL (k_read, grid, blk, 0, 0, (const u32x4 *) a, out_bytes / 16, sink); }, reps);
