@@ -234,7 +234,7 @@ def run(args):
         "config": {"workload": "3840x2160 x 64 frames per GPU, bggr/rggb/grbg/gbrg -> BGRx cycled per step "
                                "(BASELINE.json configs[2]), one launch per step, frames sharded round-robin "
                                "over ranks, no collective",
-                   "kernel_variant": pkg.variant_names()[variant], "parity": parity},
+                   "kernel_variant": ctx0.variant_name, "parity": parity},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel_ms": round(kernel_ms, 4),

@@ -102,8 +102,12 @@ ABI = {
                                               ctypes.c_int, ctypes.c_uint32, _vp]),
     "mibayer_variant_count": (ctypes.c_int, []),
     "mibayer_variant_name": (ctypes.c_char_p, [ctypes.c_int]),
-    "mibayer_launch_geometry": (ctypes.c_int, [_vp, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 4),
-    "mibayer_block_to_tile": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64]),
+    "mibayer_ctx_variant_name": (ctypes.c_char_p, [_vp]),
+    "mibayer_launch_geometry": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                               ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                               ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int),
+                                               ctypes.POINTER(ctypes.c_int64)]),
+    "mibayer_block_to_tile": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
 }
 
 
@@ -176,6 +180,7 @@ class Context:
         self.src_stride, self.dst_stride = out.src_stride, out.dst_stride
         self.src_bytes = out.src_stride * out.height
         self.dst_bytes = out.dst_stride * out.height
+        self.variant_name = lib().mibayer_ctx_variant_name(self._h).decode()
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -270,10 +275,13 @@ class Context:
             _vp(s)), "mibayer_fill_synthetic")
 
     def launch_geometry(self, nframes=1):
-        v = [ctypes.c_int() for _ in range(4)]
-        _check(lib().mibayer_launch_geometry(self._h, nframes, *[ctypes.byref(x) for x in v]),
-               "mibayer_launch_geometry")
-        return dict(zip(("tile_w", "tile_h", "tiles_per_frame", "grid_blocks"), [x.value for x in v]))
+        tw, th, tx, band = (ctypes.c_int() for _ in range(4))
+        rows, grid = ctypes.c_int64(), ctypes.c_int64()
+        _check(lib().mibayer_launch_geometry(self._h, nframes, ctypes.byref(tw), ctypes.byref(th),
+                                             ctypes.byref(tx), ctypes.byref(rows), ctypes.byref(band),
+                                             ctypes.byref(grid)), "mibayer_launch_geometry")
+        return {"tile_w": tw.value, "tile_h": th.value, "tiles_x": tx.value, "tile_rows": rows.value,
+                "band": band.value, "grid_blocks": grid.value}
 
     # -- convenience for tests ---------------------------------------------------------------
     def process_batch_via_device(self, frames):

@@ -12,6 +12,7 @@
 #include "../../include/mibayer.h"
 #include "mibayer_internal.h"
 
+#include <limits.h>
 #include <mutex>
 #include <new>
 #include <stdio.h>
@@ -94,6 +95,7 @@ struct mibayer_ctx {
   uint32_t sel[4];
   int swap_rows = 0;
   const Variant *var = nullptr;
+  int band_override = INT32_MIN;        /* MIBAYER_XCD_BAND (tuning), else the variant's */
   /* streams: uploads, kernels and downloads each get their own queue so that
    * frame n+1's H2D overlaps frame n's kernel and frame n-1's D2H */
   hipStream_t s_h2d = nullptr;
@@ -165,8 +167,11 @@ static void fill_params (const mibayer_ctx *c, KParams &p, const void *d_src,
   p.dn_last = f.height >= 4 ? f.height - 4 : 1;   /* ring slot reuse, :430-447 */
   p.tiles_x = (f.width + c->var->tile_w - 1) / c->var->tile_w;
   p.tiles_y = (f.height + c->var->tile_h - 1) / c->var->tile_h;
-  p.ntiles = (long long) nframes * p.tiles_x * p.tiles_y;
-  p.chunk = c->var->xcd_remap ? (p.ntiles + kNumXcd - 1) / kNumXcd : 0;
+  p.tile_rows = (long long) nframes * p.tiles_y;
+  int band = c->band_override != INT32_MIN ? c->band_override : c->var->band;
+  if (band < 0)                 /* one contiguous chunk of tile rows per XCD */
+    band = (int) ((p.tile_rows + kNumXcd - 1) / kNumXcd);
+  p.band = band;
   for (int k = 0; k < 4; k++)
     p.sel[k] = c->sel[k];
   p.swap_rows = c->swap_rows;
@@ -185,7 +190,7 @@ static int launch (mibayer_ctx *c, const void *d_src, size_t src_frame_bytes,
       && (nframes == 1 || (src_frame_bytes % 16 == 0
               && dst_frame_bytes % 16 == 0));
   void (*kern) (KParams) = fast ? c->var->fast : c->var->generic;
-  const long long grid = p.chunk ? p.chunk * kNumXcd : p.ntiles;
+  const long long grid = grid_blocks_for (p.tiles_x, p.tile_rows, p.band);
   if (grid > 0x7fffffffLL)
     return MIBAYER_ERR_GEOMETRY;
   hipLaunchKernelGGL (kern, dim3 ((unsigned) grid), dim3 (c->var->threads), 0,
@@ -242,11 +247,12 @@ extern "C" const char *mibayer_variant_name (int v)
   return variant (v).name;
 }
 
-extern "C" int64_t mibayer_block_to_tile (int64_t block, int64_t ntiles)
+extern "C" int64_t mibayer_block_to_tile (int64_t block, int tiles_x,
+    int64_t tile_rows, int band)
 {
-  if (block < 0 || ntiles <= 0)
+  if (block < 0 || tiles_x <= 0 || tile_rows <= 0)
     return -1;
-  return block_to_tile (block, ntiles, (ntiles + kNumXcd - 1) / kNumXcd);
+  return block_to_tile (block, tiles_x, tile_rows, band);
 }
 
 /* ---- context -------------------------------------------------------------------- */
@@ -312,7 +318,9 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   c->device = dev;
   c->src_bytes = (size_t) f.src_stride * f.height;
   c->dst_bytes = (size_t) f.dst_stride * f.height;
-  c->var = &variant (f.variant);
+  c->var = &variant (resolve_variant (f.variant, f.width));
+  if (const char *e = getenv ("MIBAYER_XCD_BAND"))
+    c->band_override = atoi (e);
   make_plan (c);
 
   DeviceGuard guard (dev);
@@ -381,6 +389,11 @@ extern "C" void mibayer_destroy (mibayer_ctx *c)
   delete c;
 }
 
+extern "C" const char *mibayer_ctx_variant_name (const mibayer_ctx *c)
+{
+  return c ? c->var->name : NULL;
+}
+
 extern "C" int mibayer_get_cfg (const mibayer_ctx *c, mibayer_cfg *out)
 {
   if (!c || !out)
@@ -390,7 +403,8 @@ extern "C" int mibayer_get_cfg (const mibayer_ctx *c, mibayer_cfg *out)
 }
 
 extern "C" int mibayer_launch_geometry (const mibayer_ctx *c, int nframes,
-    int *tile_w, int *tile_h, int *tiles_per_frame, int *grid_blocks)
+    int *tile_w, int *tile_h, int *tiles_x, int64_t *tile_rows, int *band,
+    int64_t *grid_blocks)
 {
   if (!c || nframes < 0)
     return MIBAYER_ERR_ARG;
@@ -400,10 +414,14 @@ extern "C" int mibayer_launch_geometry (const mibayer_ctx *c, int nframes,
     *tile_w = c->var->tile_w;
   if (tile_h)
     *tile_h = c->var->tile_h;
-  if (tiles_per_frame)
-    *tiles_per_frame = p.tiles_x * p.tiles_y;
+  if (tiles_x)
+    *tiles_x = p.tiles_x;
+  if (tile_rows)
+    *tile_rows = p.tile_rows;
+  if (band)
+    *band = p.band;
   if (grid_blocks)
-    *grid_blocks = (int) (p.chunk ? p.chunk * kNumXcd : p.ntiles);
+    *grid_blocks = grid_blocks_for (p.tiles_x, p.tile_rows, p.band);
   return MIBAYER_OK;
 }
 

@@ -24,26 +24,51 @@ struct KParams {
   int dn_last;                  /* source row standing in for row `height`     */
   int tiles_x;
   int tiles_y;
-  long long ntiles;             /* nframes * tiles_y * tiles_x                 */
-  long long chunk;              /* tiles per XCD = ceil(ntiles / 8); 0 = identity */
+  long long tile_rows;          /* nframes * tiles_y                            */
+  int band;                     /* tile rows per XCD band; 0 = identity map     */
   uint32_t sel[4];              /* v_perm_b32 selectors of output pixel 0..3   */
   int swap_rows;                /* 1 for grbg / gbrg                           */
 };
 
 /* XCD-aware block -> tile map, identical on host and device.
- * Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each
- * XCD has a private 4 MiB L2.  Giving XCD k the contiguous tile range
- * [k*chunk, (k+1)*chunk) makes tiles that share halo rows / columns run on the
- * same XCD at about the same time, so halo re-reads hit that XCD's L2. */
+ *
+ * Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8) and
+ * each XCD has a private 4 MiB L2.  With the identity map horizontally adjacent
+ * tiles land on different XCDs, so every tile's left/right halo dword drags a
+ * full 128-byte line of its neighbour through the fabric a second time
+ * (measured: L2->fabric reads = 2.0x the algorithmic bytes for 256-px tiles).
+ *
+ * The band map hands XCD k whole tile rows: tile row R (counted through the
+ * batch, R = frame * tiles_y + ty) belongs to XCD (R / band) % 8, and an XCD
+ * walks its rows left to right.  Horizontal neighbours (and, inside a band,
+ * vertical neighbours) then share an L2, while all 8 XCDs still work within
+ * 8*band consecutive tile rows of the same frame, which keeps the DRAM write
+ * stream compact.  band = 0 selects the identity map. */
 __host__ __device__ inline long long
-block_to_tile (long long block, long long ntiles, long long chunk)
+block_to_tile (long long block, int tiles_x, long long tile_rows, int band)
 {
-  if (chunk == 0)               /* identity map (A/B arm) */
-    return block < ntiles ? block : -1;
-  long long xcd = block % kNumXcd;
-  long long i = block / kNumXcd;
-  long long id = xcd * chunk + i;
-  return (i < chunk && id < ntiles) ? id : -1;
+  if (band <= 0) {
+    return block < tile_rows * tiles_x ? block : -1;
+  }
+  const long long xcd = block % kNumXcd;
+  const long long i = block / kNumXcd;          /* i-th block of this XCD */
+  const long long per_group = (long long) band * tiles_x;
+  const long long group = i / per_group;
+  const long long in_group = i - group * per_group;
+  const long long r_local = in_group / tiles_x;
+  const long long tx = in_group - r_local * tiles_x;
+  const long long row = (group * kNumXcd + xcd) * band + r_local;
+  return row < tile_rows ? row * tiles_x + tx : -1;
+}
+
+__host__ __device__ inline long long
+grid_blocks_for (int tiles_x, long long tile_rows, int band)
+{
+  if (band <= 0)
+    return tile_rows * tiles_x;
+  const long long group_rows = (long long) kNumXcd * band;
+  const long long groups = (tile_rows + group_rows - 1) / group_rows;
+  return groups * group_rows * tiles_x;
 }
 
 struct Variant {
@@ -51,13 +76,15 @@ struct Variant {
   int tile_w;                   /* pixels */
   int tile_h;                   /* rows   */
   int threads;
-  int xcd_remap;                /* 1: XCD-chunked block->tile map, 0: identity (A/B arm) */
+  int band;                     /* XCD band map: tile rows per band; 0 = identity, -1 = one
+                                   contiguous chunk per XCD */
   void (*fast) (KParams);       /* W%16==0, 16-byte aligned rows both sides */
   void (*generic) (KParams);    /* any even W >= 4, 4-byte aligned rows     */
 };
 
 int variant_count ();
 const Variant &variant (int id);
+int resolve_variant (int id, int width);        /* 0 ("auto") -> a concrete id */
 
 /* synthetic mosaic generator kernel launcher */
 hipError_t launch_fill_synthetic (uint8_t *d_buf, int width, int height,

@@ -245,7 +245,8 @@ bayer2rgb_lds_kernel (KParams p)
 
   __shared__ __attribute__ ((aligned (16))) uint8_t lds[NROWS * PITCH];
 
-  const long long tile = block_to_tile (blockIdx.x, p.ntiles, p.chunk);
+  const long long tile = block_to_tile (blockIdx.x, p.tiles_x, p.tile_rows,
+      p.band);
   if (tile < 0)
     return;
   const int tx = (int) (tile % p.tiles_x);
@@ -392,7 +393,8 @@ bayer2rgb_direct_kernel (KParams p)
   constexpr int TR = WY * RPW;
   static_assert (RPW % 2 == 0, "row parity is derived from the in-tile row");
 
-  const long long tile = block_to_tile (blockIdx.x, p.ntiles, p.chunk);
+  const long long tile = block_to_tile (blockIdx.x, p.tiles_x, p.tile_rows,
+      p.band);
   if (tile < 0)
     return;
   const int tx = (int) (tile % p.tiles_x);
@@ -460,40 +462,38 @@ bayer2rgb_direct_kernel (KParams p)
 /* variant table                                                               */
 /* ------------------------------------------------------------------------- */
 
-#define LDS_VARIANT(name, WX, WY, RPW, NEIGH, ST, INTRIN, REMAP)               \
-  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), REMAP,                   \
+#define LDS_VARIANT(name, WX, WY, RPW, NEIGH, ST, INTRIN)                      \
+  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1,                      \
     bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, false>,               \
     bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, true> }
-#define DIRECT_VARIANT(name, WX, WY, RPW, ST, INTRIN, REMAP)                   \
-  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), REMAP,                   \
+#define DIRECT_VARIANT(name, WX, WY, RPW, ST, INTRIN)                          \
+  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1,                      \
     bayer2rgb_direct_kernel<WX, WY, RPW, ST, INTRIN, false>,                   \
     bayer2rgb_direct_kernel<WX, WY, RPW, ST, INTRIN, true> }
 
+/* Measured on MI355X (profiles/sweep_r01_*.log, interleaved A/B, 4K x 64 frames):
+ * 4 rows per wave and 8 waves per workgroup is the sweet spot (83-84 % of the
+ * 8 TB/s HBM peak); 8 rows per wave costs 3 points, 2 rows per wave 15; nt
+ * stores gain 1.3 points over plain stores, sc1 / sc0 sc1 stores lose 2; DPP,
+ * ds_bpermute and LDS neighbour reads tie; the no-LDS arm loses 15 points. */
 static const Variant kVariants[] = {
-  /* 0: default (kept equal to the best measured arm) */
-  LDS_VARIANT ("lds_1x4_r8_dpp_nt", 1, 4, 8, 0, 1, true, 1),
-  /* 1.. : tuning / verification arms */
-  LDS_VARIANT ("lds_1x4_r8_dpp", 1, 4, 8, 0, 0, true, 1),
-  LDS_VARIANT ("lds_1x4_r8_dpp_nt_noxcd", 1, 4, 8, 0, 1, true, 0),
-  LDS_VARIANT ("lds_1x4_r8_dpp_sc1", 1, 4, 8, 0, 2, true, 1),
-  LDS_VARIANT ("lds_1x4_r8_dpp_sc0sc1", 1, 4, 8, 0, 3, true, 1),
-  LDS_VARIANT ("lds_1x4_r8_dpp_ntsc1", 1, 4, 8, 0, 4, true, 1),
-  LDS_VARIANT ("lds_1x4_r16_dpp_nt", 1, 4, 16, 0, 1, true, 1),
-  LDS_VARIANT ("lds_1x4_r4_dpp_nt", 1, 4, 4, 0, 1, true, 1),
-  LDS_VARIANT ("lds_1x8_r8_dpp_nt", 1, 8, 8, 0, 1, true, 1),
-  LDS_VARIANT ("lds_1x8_r4_dpp_nt", 1, 8, 4, 0, 1, true, 1),
-  LDS_VARIANT ("lds_1x2_r16_dpp_nt", 1, 2, 16, 0, 1, true, 1),
-  LDS_VARIANT ("lds_1x1_r32_dpp_nt", 1, 1, 32, 0, 1, true, 1),
-  LDS_VARIANT ("lds_4x1_r16_dpp_nt", 4, 1, 16, 0, 1, true, 1),
-  LDS_VARIANT ("lds_4x1_r32_dpp_nt", 4, 1, 32, 0, 1, true, 1),
-  LDS_VARIANT ("lds_4x2_r16_dpp_nt", 4, 2, 16, 0, 1, true, 1),
-  LDS_VARIANT ("lds_2x2_r16_dpp_nt", 2, 2, 16, 0, 1, true, 1),
-  LDS_VARIANT ("lds_1x4_r8_shfl_nt", 1, 4, 8, 1, 1, true, 1),
-  LDS_VARIANT ("lds_1x4_r8_ldsnb_nt", 1, 4, 8, 2, 1, true, 1),
-  LDS_VARIANT ("lds_1x4_r8_ldsnb_swar", 1, 4, 8, 2, 0, false, 1),
-  DIRECT_VARIANT ("direct_1x4_r16_nt", 1, 4, 16, 1, true, 1),
-  DIRECT_VARIANT ("direct_1x1_r16_nt", 1, 1, 16, 1, true, 1),
-  DIRECT_VARIANT ("direct_1x4_r8", 1, 4, 8, 0, true, 1),
+  /* 0: "auto" -- resolved per stream width by resolve_variant() below */
+  { "auto", 0, 0, 0, -1, nullptr, nullptr },
+  /* 1-3: the production shapes (tile 1024x8, 512x16, 256x32; 512 threads) */
+  LDS_VARIANT ("lds_4x2_r4_dpp_nt", 4, 2, 4, 0, 1, true),
+  LDS_VARIANT ("lds_2x4_r4_dpp_nt", 2, 4, 4, 0, 1, true),
+  LDS_VARIANT ("lds_1x8_r4_dpp_nt", 1, 8, 4, 0, 1, true),
+  /* 4.. : tuning / verification arms, all bit-exact (tests/test_gpu_parity.py) */
+  LDS_VARIANT ("lds_1x8_r4_dpp", 1, 8, 4, 0, 0, true),
+  LDS_VARIANT ("lds_1x8_r4_dpp_sc1", 1, 8, 4, 0, 2, true),
+  LDS_VARIANT ("lds_1x8_r4_shfl_nt", 1, 8, 4, 1, 1, true),
+  LDS_VARIANT ("lds_1x8_r4_ldsnb_nt", 1, 8, 4, 2, 1, true),
+  LDS_VARIANT ("lds_1x8_r4_ldsnb_swar", 1, 8, 4, 2, 0, false),
+  LDS_VARIANT ("lds_1x4_r8_dpp_nt", 1, 4, 8, 0, 1, true),
+  LDS_VARIANT ("lds_1x16_r4_dpp_nt", 1, 16, 4, 0, 1, true),
+  LDS_VARIANT ("lds_1x8_r2_dpp_nt", 1, 8, 2, 0, 1, true),
+  LDS_VARIANT ("lds_4x1_r16_dpp_nt", 4, 1, 16, 0, 1, true),
+  DIRECT_VARIANT ("direct_1x4_r8_nt", 1, 4, 8, 1, true),
 };
 
 int variant_count ()
@@ -504,6 +504,20 @@ int variant_count ()
 const Variant &variant (int id)
 {
   return kVariants[id];
+}
+
+/* variant 0: the widest tile that the frame width still fills.  All three
+ * shapes run within 1 % of each other on 4K / 8K; on widths that are not a
+ * multiple of the tile the wider tile wastes fewer partial waves per row. */
+int resolve_variant (int id, int width)
+{
+  if (id != 0)
+    return id;
+  if (width > 512)
+    return 1;                   /* 1024 x 8  */
+  if (width > 256)
+    return 2;                   /* 512 x 16  */
+  return 3;                     /* 256 x 32  */
 }
 
 /* ------------------------------------------------------------------------- */

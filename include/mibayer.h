@@ -170,17 +170,24 @@ int mibayer_fill_synthetic (mibayer_ctx *ctx, void *d_src,
 
 /* ---- introspection (tests) --------------------------------------------------- */
 
-/* Number of kernel variants; variant ids are 0 .. n-1 (0 = default). */
+/* Number of kernel variants; variant ids are 0 .. n-1.  0 = "auto": the
+ * production tile shape chosen from the stream width at mibayer_create(). */
 int mibayer_variant_count (void);
 const char *mibayer_variant_name (int variant);
-/* Launch geometry the context would use for nframes frames: tile width/height
- * in pixels, tiles per frame, grid size.  Any pointer may be NULL. */
+/* name of the concrete variant the context resolved to */
+const char *mibayer_ctx_variant_name (const mibayer_ctx *ctx);
+/* Launch geometry the context would use for nframes frames: tile size in
+ * pixels, tiles per tile row, tile rows in the batch (nframes * tiles_y), the
+ * XCD band (tile rows per XCD band, 0 = identity map) and the grid size.  Any
+ * pointer may be NULL. */
 int mibayer_launch_geometry (const mibayer_ctx *ctx, int nframes, int *tile_w,
-    int *tile_h, int *tiles_per_frame, int *grid_blocks);
+    int *tile_h, int *tiles_x, int64_t *tile_rows, int *band,
+    int64_t *grid_blocks);
 /* The XCD-aware block -> tile permutation used by the kernel, evaluated on the
- * host: returns the linear tile id block `block` of a `grid_blocks` launch
- * over `ntiles` tiles processes, or -1 if that block idles. */
-int64_t mibayer_block_to_tile (int64_t block, int64_t ntiles);
+ * host: linear tile id (tile_row * tiles_x + tx) that block `block` processes,
+ * or -1 if that block idles. */
+int64_t mibayer_block_to_tile (int64_t block, int tiles_x, int64_t tile_rows,
+    int band);
 
 #ifdef __cplusplus
 }

@@ -96,21 +96,37 @@ def test_product_does_not_link_or_mention_the_oracle(pkg):
 
 
 def test_xcd_block_to_tile_is_a_bijection(pkg):
+    """Every tile is processed by exactly one block, for the identity map and for every band width;
+    with a band map, XCD k (blocks k, k+8, ...) owns whole tile rows, walks each left to right and
+    keeps vertically adjacent rows of a band on the same XCD."""
     f = pkg.lib().mibayer_block_to_tile
-    for ntiles in (1, 7, 8, 9, 63, 64, 65, 1000, 4321):
-        chunk = (ntiles + 7) // 8
-        grid = chunk * 8
-        tiles = [f(b, ntiles) for b in range(grid)]
-        live = [t for t in tiles if t >= 0]
-        assert sorted(live) == list(range(ntiles)), ntiles
-        # XCD k (blocks k, k+8, ...) walks one contiguous tile range in order
-        for k in range(8):
-            mine = [t for t in tiles[k::8] if t >= 0]
-            assert mine == list(range(k * chunk, k * chunk + len(mine)))
-    assert f(-1, 10) == -1 and f(0, 0) == -1
+    for tiles_x, tile_rows in [(1, 1), (15, 68), (4, 270), (3, 7), (8, 8), (2, 65), (30, 4320 // 32)]:
+        ntiles = tiles_x * tile_rows
+        for band in (0, 1, 2, 3, 8, (tile_rows + 7) // 8):
+            if band == 0:
+                grid = ntiles
+            else:
+                groups = -(-tile_rows // (8 * band))
+                grid = groups * 8 * band * tiles_x
+            tiles = [f(b, tiles_x, tile_rows, band) for b in range(grid)]
+            live = [t for t in tiles if t >= 0]
+            assert sorted(live) == list(range(ntiles)), (tiles_x, tile_rows, band)
+            assert f(grid + 8 * band * tiles_x, tiles_x, tile_rows, band) == -1 or band == 0
+            if band == 0:
+                assert tiles == list(range(ntiles))
+                continue
+            for k in range(8):
+                mine = [t for t in tiles[k::8] if t >= 0]
+                rows = [t // tiles_x for t in mine]
+                assert all((r // band) % 8 == k for r in rows)          # whole rows per XCD
+                for r in set(rows):                                       # each row left to right
+                    xs = [t % tiles_x for t in mine if t // tiles_x == r]
+                    assert xs == list(range(tiles_x))
+                assert rows == sorted(rows)
+    assert f(-1, 4, 10, 1) == -1 and f(0, 0, 10, 1) == -1 and f(0, 4, 0, 1) == -1
 
 
 def test_launch_geometry_needs_no_device_math(pkg):
     # pure host arithmetic check of the tile grid through the variant table
     names = pkg.variant_names()
-    assert names[0].startswith("lds_")
+    assert names[0] == "auto" and all(n.startswith(("lds_", "direct_")) for n in names[1:])

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-end evidence pass: parity suite, bench line, rocprofv3 kernel stats of the same bench command, and
+# HBM traffic counters (separate --pmc passes) for the bench kernel plus the calibration probe.
+# Usage (on the GPU box, via gpurun): bash tools/gpu_profile.sh rNN
+set +e
+TAG=${1:-r01}
+mkdir -p gpurun_out/$TAG
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/smoke.log
+echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $O/pytest_gpu.log
+echo "== bench"; timeout 600 python bench.py 2>&1 | tail -1 | tee $O/bench.json
+cd /tmp
+echo "== rocprof stats (same command as the bench line, fewer steps)"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --steps 100 --warmup 10 --no-cpu --no-host-path 2>&1 | grep -v "^W20" | tail -1 | cut -c1-300
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_bench_$c -o $TAG -- python $R/bench.py --steps 8 --warmup 2 --no-cpu --no-host-path 2>&1 | grep -v "^W20" | tail -1 | cut -c1-120
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_probe_$c -o $TAG -- $R/tools/hbm_probe 2 32768 2>&1 | grep -v "^W20" | tail -1
+done
+cd $R; find gpurun_out/$TAG -name "*.csv" | wc -l

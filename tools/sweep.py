@@ -22,8 +22,8 @@ with pkg.Context(W, H, "rggb", "BGRx") as c0:
             best = min(c.time_device(d_src, d_dst, N, warmup=3, reps=20) for _ in range(3))
             gbs = 5.0 * W * H * N / (best * 1e-3) / 1e9
             g = c.launch_geometry(N)
-            print("variant %2d %-24s %8.4f ms  %8.1f GB/s  %5.1f%% of 8 TB/s  %9.0f Mpix/s  tile %dx%d grid %d"
+            print("variant %2d %-24s %8.4f ms  %8.1f GB/s  %5.1f%% of 8 TB/s  %9.0f Mpix/s  tile %dx%d band %d grid %d"
                   % (v, names[v], best, gbs, gbs / 80.0, W * H * N / best / 1e3, g["tile_w"], g["tile_h"],
-                     g["grid_blocks"]), flush=True)
+                     g["band"], g["grid_blocks"]), flush=True)
     c0.device_free(d_src)
     c0.device_free(d_dst)

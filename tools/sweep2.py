@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Development tool: interleaved A/B timing of (kernel variant, XCD band) arms.
+
+All arms are created up front and timed round-robin for several rounds in ONE process, so slow drifts
+of the box (clock / thermal state) hit every arm alike; reports min and median per arm.
+Usage: python tools/sweep2.py W H N rounds arm [arm ...]   with arm = variant_name[:band]"""
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+pkg = entry.load_package()
+W, H, N, ROUNDS = (int(v) for v in sys.argv[1:5])
+names = pkg.variant_names()
+arms = []
+for spec in sys.argv[5:]:
+    name, _, band = spec.partition(":")
+    if band:
+        os.environ["MIBAYER_XCD_BAND"] = band
+    else:
+        os.environ.pop("MIBAYER_XCD_BAND", None)
+    ctx = pkg.Context(W, H, "rggb", "BGRx", variant=names.index(name))
+    arms.append((spec, ctx, []))
+os.environ.pop("MIBAYER_XCD_BAND", None)
+c0 = arms[0][1]
+d_src = c0.device_alloc(N * c0.src_bytes)
+d_dst = c0.device_alloc(N * c0.dst_bytes)
+c0.fill_synthetic(d_src, N, 2)
+c0.sync()
+for r in range(ROUNDS + 1):
+    for spec, ctx, ts in arms:
+        t = ctx.time_device(d_src, d_dst, N, warmup=2, reps=10)
+        if r > 0:
+            ts.append(t)
+print("%dx%d x %d frames, %d interleaved rounds x 10 launches" % (W, H, N, ROUNDS))
+for spec, ctx, ts in sorted(arms, key=lambda a: statistics.median(a[2])):
+    g = ctx.launch_geometry(N)
+    med, best = statistics.median(ts), min(ts)
+    print("%-34s band %4d  median %.4f ms %7.1f GB/s %5.1f%%   best %.4f ms %7.1f GB/s %5.1f%%"
+          % (spec, g["band"], med, 5.0 * W * H * N / med / 1e6, 5.0 * W * H * N / med / 1e6 / 80,
+             best, 5.0 * W * H * N / best / 1e6, 5.0 * W * H * N / best / 1e6 / 80), flush=True)
