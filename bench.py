@@ -199,13 +199,30 @@ def run(args):
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
-    d_src = torch.empty(BATCH * ctx0.src_bytes, dtype=torch.uint8, device="cuda")
-    d_dst = torch.empty(BATCH * ctx0.dst_bytes, dtype=torch.uint8, device="cuda")
+    if args.alloc == "hip":     # A/B arm: raw hipMalloc instead of torch's caching allocator
+        class _Raw:
+            def __init__(self, n):
+                self.p, self.n = ctx0.device_alloc(n), n
+            def data_ptr(self):
+                return self.p
+            def __getitem__(self, sl):
+                import numpy as np
+                return torch.from_numpy(np.array(ctx0.from_device(self.p + sl.start, sl.stop - sl.start)))
+        d_src, d_dst = _Raw(BATCH * ctx0.src_bytes), _Raw(BATCH * ctx0.dst_bytes)
+    else:
+        d_src = torch.empty(BATCH * ctx0.src_bytes, dtype=torch.uint8, device="cuda")
+        d_dst = torch.empty(BATCH * ctx0.dst_bytes, dtype=torch.uint8, device="cuda")
     # synthetic frames generated in HBM: this rank's i-th frame is global frame rank + i*world
     for i, gframe in enumerate(shard_frames(BATCH * world, world, rank)):
         ctx0.fill_synthetic(d_src.data_ptr() + i * ctx0.src_bytes, 1, SEED, first_frame=gframe,
                             stream=stream)
     torch.cuda.synchronize()
+    # measured launch-plan selection (product API mibayer_autotune), once per stream context, outside
+    # the timed region: MI355X boxes differ in which block->tile order streams best
+    tune = {}
+    if not args.no_autotune:
+        for o in ORDERS:
+            tune[o] = ctxs[o].autotune(d_src.data_ptr(), d_dst.data_ptr(), BATCH)
     parity = parity_spot_check(pkg, ctxs, d_src, d_dst, rank, world, stream)
 
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -234,7 +251,8 @@ def run(args):
         "config": {"workload": "3840x2160 x 64 frames per GPU, bggr/rggb/grbg/gbrg -> BGRx cycled per step "
                                "(BASELINE.json configs[2]), one launch per step, frames sharded round-robin "
                                "over ranks, no collective",
-                   "kernel_variant": ctx0.variant_name, "parity": parity},
+                   "kernel_variant": ctx0.variant_name, "launch_plan": ctx0.launch_geometry(BATCH),
+                   "autotune": tune.get(ORDERS[0], "off"), "parity": parity},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel_ms": round(kernel_ms, 4),
@@ -274,6 +292,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--alloc", choices=("torch", "hip"), default="torch")
+    ap.add_argument("--no-autotune", action="store_true")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # convenience: self-launch one rank per GPU the way the driver does

@@ -92,6 +92,8 @@ ABI = {
     "mibayer_time_device": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.POINTER(ctypes.c_float)]),
+    "mibayer_autotune": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int,
+                                        ctypes.c_char_p, ctypes.c_size_t]),
     "mibayer_host_alloc": (_vp, [ctypes.c_size_t]),
     "mibayer_host_free": (None, [_vp]),
     "mibayer_device_alloc": (_vp, [_vp, ctypes.c_size_t]),
@@ -267,6 +269,15 @@ class Context:
             dst_frame_bytes or self.dst_bytes, nframes, warmup, reps, ctypes.byref(ms)),
             "mibayer_time_device")
         return ms.value
+
+    def autotune(self, d_src, d_dst, nframes, src_frame_bytes=None, dst_frame_bytes=None):
+        """Measured plan selection (mibayer_autotune); returns the one-line report."""
+        buf = ctypes.create_string_buffer(512)
+        _check(lib().mibayer_autotune(
+            self._h, _vp(d_src), src_frame_bytes or self.src_bytes, _vp(d_dst),
+            dst_frame_bytes or self.dst_bytes, nframes, buf, len(buf)), "mibayer_autotune")
+        self.variant_name = lib().mibayer_ctx_variant_name(self._h).decode()
+        return buf.value.decode()
 
     def fill_synthetic(self, d_src, nframes, seed, first_frame=0, src_frame_bytes=None, stream="ctx"):
         s = self.stream if stream == "ctx" else (stream or 0)

@@ -94,8 +94,10 @@ struct mibayer_ctx {
   /* plan */
   uint32_t sel[4];
   int swap_rows = 0;
-  const Variant *var = nullptr;
-  int band_override = INT32_MIN;        /* MIBAYER_XCD_BAND (tuning), else the variant's */
+  const Variant *var = nullptr;         /* launch plan: tile shape ...                */
+  int band_override = INT32_MIN;        /* ... and XCD band (INT32_MIN = the variant's);
+                                           set by MIBAYER_XCD_BAND or mibayer_autotune() */
+  int xcd_rot = 0;                      /* MIBAYER_XCD_ROT (tuning) */
   /* streams: uploads, kernels and downloads each get their own queue so that
    * frame n+1's H2D overlaps frame n's kernel and frame n-1's D2H */
   hipStream_t s_h2d = nullptr;
@@ -172,13 +174,15 @@ static void fill_params (const mibayer_ctx *c, KParams &p, const void *d_src,
   if (band < 0)                 /* one contiguous chunk of tile rows per XCD */
     band = (int) ((p.tile_rows + kNumXcd - 1) / kNumXcd);
   p.band = band;
+  p.xcd_rot = c->xcd_rot;
   for (int k = 0; k < 4; k++)
     p.sel[k] = c->sel[k];
   p.swap_rows = c->swap_rows;
 }
 
-static int launch (mibayer_ctx *c, const void *d_src, size_t src_frame_bytes,
-    void *d_dst, size_t dst_frame_bytes, int nframes, hipStream_t stream)
+static int launch (const mibayer_ctx *c, const void *d_src,
+    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
+    hipStream_t stream)
 {
   if (nframes == 0)
     return MIBAYER_OK;
@@ -321,6 +325,8 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   c->var = &variant (resolve_variant (f.variant, f.width));
   if (const char *e = getenv ("MIBAYER_XCD_BAND"))
     c->band_override = atoi (e);
+  if (const char *e = getenv ("MIBAYER_XCD_ROT"))
+    c->xcd_rot = atoi (e) & 7;
   make_plan (c);
 
   DeviceGuard guard (dev);
@@ -612,6 +618,69 @@ extern "C" int mibayer_time_device (mibayer_ctx *c, const void *d_src,
   float ms = 0.f;
   HIP_TRY (hipEventElapsedTime (&ms, c->ev_t0, c->ev_t1));
   *ms_per_launch = ms / (float) reps;
+  return MIBAYER_OK;
+}
+
+/* Measured plan selection.  The kernel is idempotent and deterministic, so the
+ * candidates are simply run on the caller's real buffers: d_dst ends up holding
+ * the correct output whichever plan wins. */
+extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
+    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
+    char *report, size_t report_len)
+{
+  if (!c || !d_src || !d_dst || nframes < 1)
+    return MIBAYER_ERR_ARG;
+  if (report && report_len)
+    report[0] = 0;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+
+  /* candidate tile shapes: the configured one, plus the 256-wide production
+   * shape when "auto" picked a wider one */
+  const Variant *shapes[2] = { c->var, nullptr };
+  int nshapes = 1;
+  if (c->cfg.variant == 0 && c->var != &variant (3))
+    shapes[nshapes++] = &variant (3);
+  const bool band_forced = getenv ("MIBAYER_XCD_BAND") != NULL;
+  const int bands[2] = { -1, 0 };       /* one chunk per XCD | identity map */
+  const int nbands = band_forced ? 1 : 2;
+
+  const Variant *keep_var = c->var, *best_var = c->var;
+  const int keep_band = c->band_override;
+  int best_band = keep_band;
+  float best_ms = 0.f;
+  size_t used = 0;
+  const int reps = 4;
+  for (int si = 0; si < nshapes; si++) {
+    for (int bi = 0; bi < nbands; bi++) {
+      c->var = shapes[si];
+      if (!band_forced)
+        c->band_override = bands[bi];
+      float ms = 0.f;
+      int rc = mibayer_time_device (c, d_src, src_frame_bytes, d_dst,
+          dst_frame_bytes, nframes, 1, reps, &ms);
+      if (rc != MIBAYER_OK) {
+        c->var = keep_var;
+        c->band_override = keep_band;
+        return rc;
+      }
+      if (report && used < report_len) {
+        int n = snprintf (report + used, report_len - used, "%s%s/band%d=%.4fms",
+            used ? " " : "", c->var->name, band_forced ? keep_band : bands[bi],
+            ms);
+        if (n > 0)
+          used += (size_t) n;
+      }
+      if (best_ms == 0.f || ms < best_ms) {
+        best_ms = ms;
+        best_var = c->var;
+        best_band = c->band_override;
+      }
+    }
+  }
+  c->var = best_var;
+  c->band_override = best_band;
   return MIBAYER_OK;
 }
 

@@ -26,6 +26,7 @@ struct KParams {
   int tiles_y;
   long long tile_rows;          /* nframes * tiles_y                            */
   int band;                     /* tile rows per XCD band; 0 = identity map     */
+  int xcd_rot;                  /* tuning: XCD k takes the bands of XCD (k+rot)%8 */
   uint32_t sel[4];              /* v_perm_b32 selectors of output pixel 0..3   */
   int swap_rows;                /* 1 for grbg / gbrg                           */
 };
@@ -45,12 +46,13 @@ struct KParams {
  * 8*band consecutive tile rows of the same frame, which keeps the DRAM write
  * stream compact.  band = 0 selects the identity map. */
 __host__ __device__ inline long long
-block_to_tile (long long block, int tiles_x, long long tile_rows, int band)
+block_to_tile (long long block, int tiles_x, long long tile_rows, int band,
+    int rot = 0)
 {
   if (band <= 0) {
     return block < tile_rows * tiles_x ? block : -1;
   }
-  const long long xcd = block % kNumXcd;
+  const long long xcd = (block + rot) % kNumXcd;
   const long long i = block / kNumXcd;          /* i-th block of this XCD */
   const long long per_group = (long long) band * tiles_x;
   const long long group = i / per_group;

@@ -246,7 +246,7 @@ bayer2rgb_lds_kernel (KParams p)
   __shared__ __attribute__ ((aligned (16))) uint8_t lds[NROWS * PITCH];
 
   const long long tile = block_to_tile (blockIdx.x, p.tiles_x, p.tile_rows,
-      p.band);
+      p.band, p.xcd_rot);
   if (tile < 0)
     return;
   const int tx = (int) (tile % p.tiles_x);
@@ -394,7 +394,7 @@ bayer2rgb_direct_kernel (KParams p)
   static_assert (RPW % 2 == 0, "row parity is derived from the in-tile row");
 
   const long long tile = block_to_tile (blockIdx.x, p.tiles_x, p.tile_rows,
-      p.band);
+      p.band, p.xcd_rot);
   if (tile < 0)
     return;
   const int tx = (int) (tile % p.tiles_x);

@@ -146,6 +146,17 @@ int mibayer_time_device (mibayer_ctx *ctx, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     int warmup, int reps, float *ms_per_launch);
 
+/* Measured launch-plan selection for the device-resident path.  MI355X boxes
+ * differ in which block->tile order streams best (DESIGN.md "XCD map"): this
+ * call times the candidate plans (tile shape x XCD band map) on the caller's
+ * own buffers with HIP events on the context's compute stream, a few launches
+ * each, and keeps the fastest for every later launch of this context.  The
+ * kernel is idempotent, so d_dst holds the correct output afterwards.
+ * Synchronous.  `report` (may be NULL) receives a one-line summary. */
+int mibayer_autotune (mibayer_ctx *ctx, const void *d_src,
+    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
+    char *report, size_t report_len);
+
 /* ---- memory helpers --------------------------------------------------------- */
 
 /* Pinned (hipHostMalloc) memory for buffer pools feeding the host path. */

@@ -224,3 +224,25 @@ def test_pinned_host_memory_path(gpu_pkg, oracle):
         assert md5(dst) == "f14f6ad248ef0bac0f28546db6d14813"     # SURVEY.md B.3, 1080p rggb->BGRx
         L.mibayer_host_free(p_src)
         L.mibayer_host_free(p_dst)
+
+
+def test_autotune_keeps_results_bit_exact(gpu_pkg, oracle):
+    """mibayer_autotune() runs every candidate plan on the caller's buffers: whichever wins, d_dst
+    holds the oracle's bytes afterwards and so does every later launch."""
+    w, h, n = 1280, 96, 12
+    src = oracle.fill_synthetic(w, h, n, seed=41)
+    want = oracle.bayer2rgb_batch(src, w, "grbg", 1, 2, 3, nthreads=2)
+    with gpu_pkg.Context(w, h, "grbg", "xRGB") as ctx:
+        d_src = ctx.device_alloc(n * ctx.src_bytes)
+        d_dst = ctx.device_alloc(n * ctx.dst_bytes)
+        ctx.to_device(d_src, src)
+        report = ctx.autotune(d_src, d_dst, n)
+        assert "band" in report and "ms" in report
+        assert np.array_equal(ctx.from_device(d_dst, n * ctx.dst_bytes).reshape(want.shape), want)
+        ctx.to_device(d_dst, np.zeros(n * ctx.dst_bytes, np.uint8))
+        ctx.process_device(d_src, d_dst, n)
+        ctx.sync()
+        assert np.array_equal(ctx.from_device(d_dst, n * ctx.dst_bytes).reshape(want.shape), want)
+        assert ctx.launch_geometry(n)["band"] in (0, -(-ctx.launch_geometry(n)["tile_rows"] // 8))
+        ctx.device_free(d_src)
+        ctx.device_free(d_dst)

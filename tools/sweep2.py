@@ -17,17 +17,21 @@ W, H, N, ROUNDS = (int(v) for v in sys.argv[1:5])
 names = pkg.variant_names()
 arms = []
 for spec in sys.argv[5:]:
-    name, _, band = spec.partition(":")
-    if band:
-        os.environ["MIBAYER_XCD_BAND"] = band
-    else:
-        os.environ.pop("MIBAYER_XCD_BAND", None)
+    name, _, rest = spec.partition(":")
+    band, _, rot = rest.partition(":")
+    for key, val in (("MIBAYER_XCD_BAND", band), ("MIBAYER_XCD_ROT", rot)):
+        if val:
+            os.environ[key] = val
+        else:
+            os.environ.pop(key, None)
     ctx = pkg.Context(W, H, "rggb", "BGRx", variant=names.index(name))
     arms.append((spec, ctx, []))
 os.environ.pop("MIBAYER_XCD_BAND", None)
+os.environ.pop("MIBAYER_XCD_ROT", None)
 c0 = arms[0][1]
 d_src = c0.device_alloc(N * c0.src_bytes)
 d_dst = c0.device_alloc(N * c0.dst_bytes)
+print("d_src %#x d_dst %#x" % (d_src, d_dst))
 c0.fill_synthetic(d_src, N, 2)
 c0.sync()
 for r in range(ROUNDS + 1):
