@@ -94,6 +94,7 @@ ABI = {
                                            ctypes.POINTER(ctypes.c_float)]),
     "mibayer_autotune": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int,
                                         ctypes.c_char_p, ctypes.c_size_t]),
+    "mibayer_copy_plan": (ctypes.c_int, [_vp, _vp]),
     "mibayer_host_alloc": (_vp, [ctypes.c_size_t]),
     "mibayer_host_free": (None, [_vp]),
     "mibayer_device_alloc": (_vp, [_vp, ctypes.c_size_t]),
@@ -278,6 +279,10 @@ class Context:
             dst_frame_bytes or self.dst_bytes, nframes, buf, len(buf)), "mibayer_autotune")
         self.variant_name = lib().mibayer_ctx_variant_name(self._h).decode()
         return buf.value.decode()
+
+    def copy_plan_from(self, other):
+        _check(lib().mibayer_copy_plan(self._h, other._h), "mibayer_copy_plan")
+        self.variant_name = lib().mibayer_ctx_variant_name(self._h).decode()
 
     def fill_synthetic(self, d_src, nframes, seed, first_frame=0, src_frame_bytes=None, stream="ctx"):
         s = self.stream if stream == "ctx" else (stream or 0)

@@ -684,6 +684,17 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
   return MIBAYER_OK;
 }
 
+extern "C" int mibayer_copy_plan (mibayer_ctx *dst, const mibayer_ctx *src)
+{
+  if (!dst || !src)
+    return MIBAYER_ERR_ARG;
+  if (dst->cfg.width != src->cfg.width || dst->cfg.height != src->cfg.height)
+    return MIBAYER_ERR_GEOMETRY;
+  dst->var = src->var;
+  dst->band_override = src->band_override;
+  return MIBAYER_OK;
+}
+
 /* ---- memory helpers --------------------------------------------------------------------- */
 
 extern "C" void *mibayer_host_alloc (size_t bytes)

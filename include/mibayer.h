@@ -157,6 +157,10 @@ int mibayer_autotune (mibayer_ctx *ctx, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     char *report, size_t report_len);
 
+/* Copies the launch plan chosen by mibayer_autotune() to another context of the
+ * same width/height (e.g. the same camera geometry in another Bayer order). */
+int mibayer_copy_plan (mibayer_ctx *dst, const mibayer_ctx *src);
+
 /* ---- memory helpers --------------------------------------------------------- */
 
 /* Pinned (hipHostMalloc) memory for buffer pools feeding the host path. */
