@@ -138,13 +138,13 @@ def parity_spot_check(pkg, ctxs, d_src, d_dst, rank, world, stream):
     return "bit-exact vs oracle on frames %d and %d of the batch (rggb->%s)" % (0, BATCH - 1, FORMAT)
 
 
-def host_path_rate(pkg, device, frames=24, inflight=3):
-    """PCIe-inclusive rate of the host path (pinned buffers, async ring).  Reported as a note only;
-    it is never `value`."""
+def host_path_rate(pkg, device, frames=24, inflight=3, flags=0):
+    """PCIe-inclusive rate of the host path (hipHostMalloc-pinned buffers, async ring; flags=FLAG_HIPGRAPH runs each
+    frame's H2D -> kernel -> D2H chain as one instantiated graph).  Returns (Mpix/s, seconds)."""
     import ctypes
     import numpy as np
     L = pkg.lib()
-    with pkg.Context(WIDTH, HEIGHT, "rggb", FORMAT, device=device, inflight=inflight) as ctx:
+    with pkg.Context(WIDTH, HEIGHT, "rggb", FORMAT, device=device, inflight=inflight, flags=flags) as ctx:
         srcs, dsts = [], []
         for _ in range(inflight):
             ps, pd = L.mibayer_host_alloc(ctx.src_bytes), L.mibayer_host_alloc(ctx.dst_bytes)
@@ -154,7 +154,7 @@ def host_path_rate(pkg, device, frames=24, inflight=3):
             srcs.append((ps, s))
             dsts.append((pd, d))
         for phase in ("warm", "timed"):
-            n = inflight if phase == "warm" else frames
+            n = 2 * inflight if phase == "warm" else frames
             t0 = time.perf_counter()
             for i in range(n):
                 if ctx.pending() == inflight:
@@ -166,10 +166,69 @@ def host_path_rate(pkg, device, frames=24, inflight=3):
         for (ps, _), (pd, _) in zip(srcs, dsts):
             L.mibayer_host_free(ps)
             L.mibayer_host_free(pd)
-    return {"value": round(WIDTH * HEIGHT * frames / el / 1e6, 1), "unit": "Mpix/s",
-            "note": "host->host incl. H2D + D2H over PCIe, hipHostMalloc-pinned buffers, %d frames in "
-                    "flight, %d 4K frames; bound by PCIe (~5 B/pixel over a ~55 GB/s link), not HBM"
-                    % (inflight, frames)}
+    return WIDTH * HEIGHT * frames / el / 1e6, el
+
+
+def host_path_note(pkg, device):
+    plain, _ = host_path_rate(pkg, device, 24, 3, 0)
+    graph, _ = host_path_rate(pkg, device, 24, 3, pkg.FLAG_HIPGRAPH)
+    return {"value": round(max(plain, graph), 1), "unit": "Mpix/s", "streams_and_events": round(plain, 1),
+            "hipgraph_per_frame": round(graph, 1),
+            "note": "host->host incl. H2D + D2H over PCIe, hipHostMalloc-pinned buffers, 3 frames in flight, 24 4K "
+                    "frames; bound by PCIe (5 B/pixel over a Gen5 x16 link), not HBM; never `value`"}
+
+
+def run_stream(args):
+    """BASELINE.json configs[4]: 3840x2160 steady-state stream, pinned double-buffered H2D/D2H + hipGraph launch,
+    1000 frames sharded round-robin over the ranks.  PCIe/host-DRAM-bound by construction."""
+    import torch
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    total = 1000
+    mine = len(shard_frames(total, world, rank))
+    def timed(flags):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        _, e = host_path_rate(pkg, local_rank, mine, 2, flags)
+        if dist is not None:
+            t = torch.tensor([e], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        return e
+
+    el_alt = timed(pkg.FLAG_HIPGRAPH if args.no_graph else 0)
+    el = timed(0 if args.no_graph else pkg.FLAG_HIPGRAPH)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        px = WIDTH * HEIGHT * total
+        print(json.dumps({
+            "metric": "bayer2rgb Mpix/s @4K (host-fed stream incl. PCIe)", "value": round(px / el / 1e6, 1),
+            "unit": "Mpix/s", "n_gpus": world, "steps": total, "warmup": 4, "ms_per_step": round(el / total * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic constant frames in pinned host memory",
+            "config": {"workload": "3840x2160 stream, 1000 frames round-robin over ranks, pinned double-buffered "
+                                   "H2D/D2H, %s (BASELINE.json configs[4])"
+                                   % ("streams+events" if args.no_graph else "one hipGraph launch per frame")},
+            "other_mechanism": {"name": "hipGraph per frame" if args.no_graph else "streams+events (3 queues)",
+                                "value": round(px / el_alt / 1e6, 1)},
+            "roofline": {"bound": "pcie", "achieved": round(4 * px / el / 1e9, 2), "peak": 63.0 * world,
+                         "unit": "GB/s", "frac": round(4 * px / el / 1e9 / (63.0 * world), 4), "traffic": None,
+                         "note": "binding direction = D2H, 4 B/pixel, against PCIe Gen5 x16 63 GB/s per GPU (spec); the "
+                                 "1 B/pixel H2D runs concurrently on the other direction"}}),
+              flush=True)
 
 
 def run(args):
@@ -272,7 +331,7 @@ def run(args):
         if not args.no_host_path:
             for c in ctxs.values():
                 c.sync()
-            result["host_path"] = host_path_rate(pkg, local_rank)
+            result["host_path"] = host_path_note(pkg, local_rank)
         if not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     for c in ctxs.values():
@@ -295,6 +354,9 @@ def main():
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--alloc", choices=("torch", "hip"), default="torch")
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--mode", choices=("batch", "stream"), default="batch",
+                    help="batch = the headline device-resident metric (default); stream = configs[4] host-fed stream")
+    ap.add_argument("--no-graph", action="store_true", help="stream mode: streams+events instead of hipGraph")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # convenience: self-launch one rank per GPU the way the driver does
@@ -302,7 +364,10 @@ def main():
                "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
                "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
-    run(args)
+    if args.mode == "stream":
+        run_stream(args)
+    else:
+        run(args)
 
 
 if __name__ == "__main__":

@@ -68,6 +68,16 @@ class Cfg(ctypes.Structure):
     ]
 
 
+MAX_SHARDS = 16
+FLAG_HIPGRAPH = 1
+
+
+class PoolCfg(ctypes.Structure):
+    """struct mibayer_pool_cfg (include/mibayer.h)."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("stream", Cfg), ("ndevices", ctypes.c_int32),
+                ("devices", ctypes.c_int32 * MAX_SHARDS)]
+
+
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _vp = ctypes.c_void_p
 _lib = None
@@ -85,6 +95,12 @@ ABI = {
     "mibayer_submit": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "mibayer_wait": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "mibayer_pending": (ctypes.c_int, [_vp]),
+    "mibayer_pool_create": (ctypes.c_int, [ctypes.POINTER(PoolCfg), ctypes.POINTER(_vp)]),
+    "mibayer_pool_destroy": (None, [_vp]),
+    "mibayer_pool_capacity": (ctypes.c_int, [_vp]),
+    "mibayer_pool_pending": (ctypes.c_int, [_vp]),
+    "mibayer_pool_submit": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "mibayer_pool_wait": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "mibayer_process_device": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
                                               ctypes.c_int, _vp]),
     "mibayer_ctx_stream": (_vp, [_vp]),
@@ -161,6 +177,57 @@ def _ptr(a):
     return ctypes.c_void_p(a.ctypes.data)
 
 
+def make_cfg(width, height, pattern="bggr", fmt="RGBx", src_stride=0, dst_stride=0, device=-1,
+             inflight=0, variant=0, flags=0):
+    r, g, b = FORMATS[fmt] if isinstance(fmt, str) else fmt
+    pat = PATTERNS[pattern] if isinstance(pattern, str) else int(pattern)
+    return Cfg(ctypes.sizeof(Cfg), width, height, src_stride, dst_stride, pat, r, g, b,
+               device, inflight, variant, flags)
+
+
+class Pool:
+    """Round-robin frame sharding over HIP devices (mibayer_pool): frame g -> devices[g % N]."""
+
+    def __init__(self, devices, width, height, pattern="bggr", fmt="RGBx", inflight=2, flags=0):
+        pc = PoolCfg()
+        pc.struct_size = ctypes.sizeof(PoolCfg)
+        pc.stream = make_cfg(width, height, pattern, fmt, inflight=inflight, flags=flags)
+        pc.ndevices = len(devices)
+        for i, d in enumerate(devices):
+            pc.devices[i] = d
+        self._h = _vp()
+        _check(lib().mibayer_pool_create(ctypes.byref(pc), ctypes.byref(self._h)), "mibayer_pool_create")
+        self.capacity = lib().mibayer_pool_capacity(self._h)
+
+    def submit(self, src, dst, tag=0):
+        _check(lib().mibayer_pool_submit(self._h, _ptr(src), _ptr(dst), _vp(tag)), "mibayer_pool_submit")
+
+    def wait(self):
+        tag = _vp()
+        _check(lib().mibayer_pool_wait(self._h, ctypes.byref(tag)), "mibayer_pool_wait")
+        return tag.value or 0
+
+    def pending(self):
+        return lib().mibayer_pool_pending(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mibayer_pool_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One negotiated stream == one mibayer_ctx (what the element creates in set_caps).
 
@@ -169,11 +236,8 @@ class Context:
     """
 
     def __init__(self, width, height, pattern="bggr", fmt="RGBx", src_stride=0, dst_stride=0,
-                 device=-1, inflight=0, variant=0):
-        r, g, b = FORMATS[fmt] if isinstance(fmt, str) else fmt
-        pat = PATTERNS[pattern] if isinstance(pattern, str) else int(pattern)
-        cfg = Cfg(ctypes.sizeof(Cfg), width, height, src_stride, dst_stride, pat, r, g, b,
-                  device, inflight, variant, 0)
+                 device=-1, inflight=0, variant=0, flags=0):
+        cfg = make_cfg(width, height, pattern, fmt, src_stride, dst_stride, device, inflight, variant, flags)
         self._h = _vp()
         _check(lib().mibayer_create(ctypes.byref(cfg), ctypes.byref(self._h)), "mibayer_create")
         out = Cfg()

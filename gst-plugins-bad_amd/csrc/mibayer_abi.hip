@@ -69,6 +69,14 @@ struct Slot {
   hipEvent_t ev_kernel = nullptr; /* kernel done */
   hipEvent_t ev_out = nullptr;    /* D2H done   */
   void *tag = nullptr;
+  /* MIBAYER_FLAG_HIPGRAPH: the frame's upload -> kernel -> download chain as one
+   * instantiated graph, launched on the slot's own stream */
+  hipStream_t s_graph = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipGraphNode_t n_h2d = nullptr, n_kernel = nullptr, n_d2h = nullptr;
+  const void *g_src = nullptr;    /* host pointers currently baked into exec */
+  void *g_dst = nullptr;
 };
 
 int device_count_cached ()
@@ -180,6 +188,28 @@ static void fill_params (const mibayer_ctx *c, KParams &p, const void *d_src,
   p.swap_rows = c->swap_rows;
 }
 
+typedef void (*KernelFn) (KParams);
+
+/* everything a launch needs: arguments, kernel (16-byte fast path or generic),
+ * grid size */
+static int plan_launch (const mibayer_ctx *c, const void *d_src,
+    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
+    KParams &p, KernelFn &kern, unsigned &grid)
+{
+  fill_params (c, p, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes);
+  const mibayer_cfg &f = c->cfg;
+  const bool fast = (f.width % 16 == 0) && (f.src_stride % 16 == 0)
+      && (f.dst_stride % 16 == 0) && aligned16 (d_src) && aligned16 (d_dst)
+      && (nframes == 1 || (src_frame_bytes % 16 == 0
+              && dst_frame_bytes % 16 == 0));
+  kern = fast ? c->var->fast : c->var->generic;
+  const long long g = grid_blocks_for (p.tiles_x, p.tile_rows, p.band);
+  if (g > 0x7fffffffLL)
+    return MIBAYER_ERR_GEOMETRY;
+  grid = (unsigned) g;
+  return MIBAYER_OK;
+}
+
 static int launch (const mibayer_ctx *c, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     hipStream_t stream)
@@ -187,18 +217,13 @@ static int launch (const mibayer_ctx *c, const void *d_src,
   if (nframes == 0)
     return MIBAYER_OK;
   KParams p;
-  fill_params (c, p, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes);
-  const mibayer_cfg &f = c->cfg;
-  const bool fast = (f.width % 16 == 0) && (f.src_stride % 16 == 0)
-      && (f.dst_stride % 16 == 0) && aligned16 (d_src) && aligned16 (d_dst)
-      && (nframes == 1 || (src_frame_bytes % 16 == 0
-              && dst_frame_bytes % 16 == 0));
-  void (*kern) (KParams) = fast ? c->var->fast : c->var->generic;
-  const long long grid = grid_blocks_for (p.tiles_x, p.tile_rows, p.band);
-  if (grid > 0x7fffffffLL)
-    return MIBAYER_ERR_GEOMETRY;
-  hipLaunchKernelGGL (kern, dim3 ((unsigned) grid), dim3 (c->var->threads), 0,
-      stream, p);
+  KernelFn kern;
+  unsigned grid;
+  int rc = plan_launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes,
+      nframes, p, kern, grid);
+  if (rc != MIBAYER_OK)
+    return rc;
+  hipLaunchKernelGGL (kern, dim3 (grid), dim3 (c->var->threads), 0, stream, p);
   HIP_TRY (hipGetLastError ());
   return MIBAYER_OK;
 }
@@ -268,7 +293,7 @@ static int validate (const mibayer_cfg *in, mibayer_cfg *out)
   mibayer_cfg f = *in;
   if (f.pattern < MIBAYER_BGGR || f.pattern > MIBAYER_RGGB)
     return MIBAYER_ERR_ARG;
-  if (f.flags != 0)
+  if (f.flags & ~(uint32_t) MIBAYER_FLAG_HIPGRAPH)
     return MIBAYER_ERR_ARG;
   if (f.variant < 0 || f.variant >= variant_count ())
     return MIBAYER_ERR_ARG;
@@ -366,6 +391,12 @@ static void free_ring (mibayer_ctx *c)
       (void) hipEventDestroy (s.ev_kernel);
     if (s.ev_out)
       (void) hipEventDestroy (s.ev_out);
+    if (s.exec)
+      (void) hipGraphExecDestroy (s.exec);
+    if (s.graph)
+      (void) hipGraphDestroy (s.graph);
+    if (s.s_graph)
+      (void) hipStreamDestroy (s.s_graph);
   }
   c->ring.clear ();
 }
@@ -381,6 +412,9 @@ extern "C" void mibayer_destroy (mibayer_ctx *c)
     (void) hipStreamSynchronize (c->s_compute);
   if (c->s_d2h)
     (void) hipStreamSynchronize (c->s_d2h);
+  for (Slot &sl : c->ring)
+    if (sl.s_graph)
+      (void) hipStreamSynchronize (sl.s_graph);
   free_ring (c);
   if (c->ev_t0)
     (void) hipEventDestroy (c->ev_t0);
@@ -459,6 +493,61 @@ static int ensure_ring (mibayer_ctx *c)
   return MIBAYER_OK;
 }
 
+/* Graph form of one frame: H2D copy -> kernel -> D2H copy as three explicit
+ * nodes, instantiated once per ring slot.  Only the two host pointers change
+ * from frame to frame; they are patched into the instantiated graph
+ * (hipGraphExecMemcpyNodeSetParams1D), or the graph is re-instantiated if the
+ * runtime refuses the update. */
+static int graph_submit (mibayer_ctx *c, Slot &s, const uint8_t *src,
+    uint8_t *dst)
+{
+  if (!s.s_graph)
+    HIP_TRY (hipStreamCreateWithFlags (&s.s_graph, hipStreamNonBlocking));
+  if (s.exec && (s.g_src != src || s.g_dst != dst)) {
+    hipError_t e1 = hipGraphExecMemcpyNodeSetParams1D (s.exec, s.n_h2d,
+        s.d_src, src, c->src_bytes, hipMemcpyHostToDevice);
+    hipError_t e2 = hipGraphExecMemcpyNodeSetParams1D (s.exec, s.n_d2h, dst,
+        s.d_dst, c->dst_bytes, hipMemcpyDeviceToHost);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      (void) hipGetLastError ();
+      (void) hipGraphExecDestroy (s.exec);
+      (void) hipGraphDestroy (s.graph);
+      s.exec = nullptr;
+      s.graph = nullptr;
+    }
+  }
+  if (!s.exec) {
+    KParams p;
+    KernelFn kern;
+    unsigned grid;
+    int rc = plan_launch (c, s.d_src, c->src_bytes, s.d_dst, c->dst_bytes, 1,
+        p, kern, grid);
+    if (rc != MIBAYER_OK)
+      return rc;
+    HIP_TRY (hipGraphCreate (&s.graph, 0));
+    HIP_TRY (hipGraphAddMemcpyNode1D (&s.n_h2d, s.graph, NULL, 0, s.d_src, src,
+            c->src_bytes, hipMemcpyHostToDevice));
+    void *args[1] = { &p };
+    hipKernelNodeParams kp;
+    memset (&kp, 0, sizeof kp);
+    kp.func = (void *) kern;
+    kp.gridDim = dim3 (grid);
+    kp.blockDim = dim3 ((unsigned) c->var->threads);
+    kp.sharedMemBytes = 0;
+    kp.kernelParams = args;
+    kp.extra = NULL;
+    HIP_TRY (hipGraphAddKernelNode (&s.n_kernel, s.graph, &s.n_h2d, 1, &kp));
+    HIP_TRY (hipGraphAddMemcpyNode1D (&s.n_d2h, s.graph, &s.n_kernel, 1, dst,
+            s.d_dst, c->dst_bytes, hipMemcpyDeviceToHost));
+    HIP_TRY (hipGraphInstantiate (&s.exec, s.graph, NULL, NULL, 0));
+  }
+  s.g_src = src;
+  s.g_dst = dst;
+  HIP_TRY (hipGraphLaunch (s.exec, s.s_graph));
+  HIP_TRY (hipEventRecord (s.ev_out, s.s_graph));
+  return MIBAYER_OK;
+}
+
 static int submit_locked (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
     void *tag)
 {
@@ -468,6 +557,16 @@ static int submit_locked (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
   if (c->pending == (int) c->ring.size ())
     return MIBAYER_ERR_BUSY;
   Slot &s = c->ring[(size_t) c->head];
+  if ((c->cfg.flags & MIBAYER_FLAG_HIPGRAPH)
+      && c->cfg.dst_stride == 4 * c->cfg.width) {
+    rc = graph_submit (c, s, src, dst);
+    if (rc != MIBAYER_OK)
+      return rc;
+    s.tag = tag;
+    c->head = (c->head + 1) % (int) c->ring.size ();
+    c->pending++;
+    return MIBAYER_OK;
+  }
   /* upload -> kernel -> download, chained by events across three queues */
   HIP_TRY (hipMemcpyAsync (s.d_src, src, c->src_bytes, hipMemcpyHostToDevice,
           c->s_h2d));
@@ -549,6 +648,92 @@ extern "C" int mibayer_process_host (mibayer_ctx *c, const uint8_t *src,
   if (rc != MIBAYER_OK)
     return rc;
   return wait_locked (c, NULL);
+}
+
+/* ---- multi-GPU frame sharding ---------------------------------------------------------- */
+
+struct mibayer_pool {
+  std::vector<mibayer_ctx *> shards;
+  unsigned long long submitted = 0;     /* frames handed in  */
+  unsigned long long completed = 0;     /* frames handed back */
+};
+
+extern "C" int mibayer_pool_create (const mibayer_pool_cfg *cfg,
+    mibayer_pool **out)
+{
+  if (!out)
+    return MIBAYER_ERR_ARG;
+  *out = NULL;
+  if (!cfg || cfg->struct_size != sizeof (mibayer_pool_cfg))
+    return MIBAYER_ERR_ARG;
+  if (cfg->ndevices < 1 || cfg->ndevices > MIBAYER_MAX_SHARDS)
+    return MIBAYER_ERR_ARG;
+  mibayer_pool *pool = new (std::nothrow) mibayer_pool ();
+  if (!pool)
+    return MIBAYER_ERR_NOMEM;
+  for (int i = 0; i < cfg->ndevices; i++) {
+    mibayer_cfg one = cfg->stream;
+    one.device = cfg->devices[i];
+    if (one.device < 0) {
+      mibayer_pool_destroy (pool);
+      return MIBAYER_ERR_NO_DEVICE;
+    }
+    mibayer_ctx *c = NULL;
+    int rc = mibayer_create (&one, &c);
+    if (rc != MIBAYER_OK) {
+      mibayer_pool_destroy (pool);
+      return rc;
+    }
+    pool->shards.push_back (c);
+  }
+  *out = pool;
+  return MIBAYER_OK;
+}
+
+extern "C" void mibayer_pool_destroy (mibayer_pool *pool)
+{
+  if (!pool)
+    return;
+  for (mibayer_ctx *c : pool->shards)
+    mibayer_destroy (c);
+  delete pool;
+}
+
+extern "C" int mibayer_pool_capacity (const mibayer_pool *pool)
+{
+  if (!pool)
+    return MIBAYER_ERR_ARG;
+  return (int) pool->shards.size () * pool->shards[0]->cfg.inflight;
+}
+
+extern "C" int mibayer_pool_pending (const mibayer_pool *pool)
+{
+  return pool ? (int) (pool->submitted - pool->completed) : MIBAYER_ERR_ARG;
+}
+
+extern "C" int mibayer_pool_submit (mibayer_pool *pool, const uint8_t *src,
+    uint8_t *dst, void *tag)
+{
+  if (!pool)
+    return MIBAYER_ERR_ARG;
+  mibayer_ctx *c = pool->shards[pool->submitted % pool->shards.size ()];
+  int rc = mibayer_submit (c, src, dst, tag);
+  if (rc == MIBAYER_OK)
+    pool->submitted++;
+  return rc;
+}
+
+extern "C" int mibayer_pool_wait (mibayer_pool *pool, void **tag)
+{
+  if (!pool)
+    return MIBAYER_ERR_ARG;
+  if (pool->submitted == pool->completed)
+    return MIBAYER_ERR_EMPTY;
+  mibayer_ctx *c = pool->shards[pool->completed % pool->shards.size ()];
+  int rc = mibayer_wait (c, tag);
+  if (rc == MIBAYER_OK)
+    pool->completed++;
+  return rc;
 }
 
 /* ---- device-resident batch path ------------------------------------------------------ */

@@ -83,8 +83,13 @@ typedef struct mibayer_cfg {
                              mibayer_submit(); 0 = default (2)               */
   int32_t variant;        /* kernel variant; 0 = default.  Tuning knob, every
                              variant is bit-exact            */
-  uint32_t flags;         /* reserved, 0                                     */
+  uint32_t flags;         /* MIBAYER_FLAG_* or 0                             */
 } mibayer_cfg;
+
+/* Host path: run each frame's upload -> kernel -> download chain as one
+ * instantiated hipGraph per ring slot (one hipGraphLaunch per frame instead of
+ * three enqueues, two event waits and three event records). */
+#define MIBAYER_FLAG_HIPGRAPH 1u
 
 typedef struct mibayer_ctx mibayer_ctx;
 
@@ -123,6 +128,37 @@ int mibayer_submit (mibayer_ctx *ctx, const uint8_t *src, uint8_t *dst,
     void *tag);
 int mibayer_wait (mibayer_ctx *ctx, void **tag);
 int mibayer_pending (const mibayer_ctx *ctx);
+
+/* ---- multi-GPU frame sharding (host path) ------------------------------------ */
+
+/* Frames are independent (the reference keeps no state between frames,
+ * gstbayer2rgb.c:387-451), so a stream is sharded round-robin over GPUs with no
+ * collective: frame g goes to shard g % ndevices, every shard is a mibayer_ctx
+ * with its own streams, device ring and (optionally) graphs, and results are
+ * handed back in submission order.  One host thread drives all shards: with
+ * pinned buffers every call below only enqueues work.  Ordinals may repeat
+ * (N logical shards on one GPU). */
+#define MIBAYER_MAX_SHARDS 16
+typedef struct mibayer_pool_cfg {
+  uint32_t struct_size;         /* = sizeof (mibayer_pool_cfg)                  */
+  mibayer_cfg stream;           /* geometry, order, layout, inflight PER SHARD,
+                                   flags; .device is ignored                    */
+  int32_t ndevices;             /* 1 .. MIBAYER_MAX_SHARDS                      */
+  int32_t devices[MIBAYER_MAX_SHARDS];  /* HIP ordinals                         */
+} mibayer_pool_cfg;
+
+typedef struct mibayer_pool mibayer_pool;
+
+int mibayer_pool_create (const mibayer_pool_cfg *cfg, mibayer_pool **out);
+void mibayer_pool_destroy (mibayer_pool *pool);
+/* total frames that may be in flight = ndevices * stream.inflight */
+int mibayer_pool_capacity (const mibayer_pool *pool);
+int mibayer_pool_pending (const mibayer_pool *pool);
+/* MIBAYER_ERR_BUSY when the shard whose turn it is has its ring full */
+int mibayer_pool_submit (mibayer_pool *pool, const uint8_t *src, uint8_t *dst,
+    void *tag);
+/* oldest frame first */
+int mibayer_pool_wait (mibayer_pool *pool, void **tag);
 
 /* ---- device-resident batch path (roofline runs, GPU-side consumers) -------- */
 

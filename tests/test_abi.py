@@ -65,7 +65,7 @@ def test_cfg_validation_matches_reference_domain(pkg):
         assert create(pkg, make_cfg(pkg, r_off=r, g_off=g, b_off=b)) in ok_or_nodev
     for (r, g, b) in [(0, 2, 1), (1, 1, 1), (0, 1, 3), (4, 1, 0)]:
         assert create(pkg, make_cfg(pkg, r_off=r, g_off=g, b_off=b)) == pkg.ERR_LAYOUT
-    for kw in (dict(pattern=4), dict(pattern=-1), dict(flags=1), dict(variant=10 ** 6), dict(inflight=-1)):
+    for kw in (dict(pattern=4), dict(pattern=-1), dict(flags=2), dict(flags=0x80000000), dict(variant=10 ** 6), dict(inflight=-1)):
         assert create(pkg, make_cfg(pkg, **kw)) == pkg.ERR_ARG, kw
     bad = make_cfg(pkg)
     bad.struct_size = 8
@@ -130,3 +130,23 @@ def test_launch_geometry_needs_no_device_math(pkg):
     # pure host arithmetic check of the tile grid through the variant table
     names = pkg.variant_names()
     assert names[0] == "auto" and all(n.startswith(("lds_", "direct_")) for n in names[1:])
+
+
+def test_pool_cfg_validation(pkg):
+    L = pkg.lib()
+    h = ctypes.c_void_p()
+    pc = pkg.PoolCfg()
+    pc.struct_size = ctypes.sizeof(pkg.PoolCfg)
+    pc.stream = pkg.make_cfg(64, 48)
+    for n in (0, -1, pkg.MAX_SHARDS + 1):
+        pc.ndevices = n
+        assert L.mibayer_pool_create(ctypes.byref(pc), ctypes.byref(h)) == pkg.ERR_ARG
+    pc.ndevices = 2
+    pc.devices[0], pc.devices[1] = 0, -3
+    assert L.mibayer_pool_create(ctypes.byref(pc), ctypes.byref(h)) in (pkg.ERR_NO_DEVICE,)
+    pc.devices[1] = 0
+    pc.stream = pkg.make_cfg(63, 48)          # geometry errors of the shards surface unchanged
+    assert L.mibayer_pool_create(ctypes.byref(pc), ctypes.byref(h)) == pkg.ERR_GEOMETRY
+    pc.struct_size = 4
+    assert L.mibayer_pool_create(ctypes.byref(pc), ctypes.byref(h)) == pkg.ERR_ARG
+    assert L.mibayer_pool_pending(None) == pkg.ERR_ARG
