@@ -35,12 +35,20 @@ struct _GstBayer2RGB
   gint b_off;
   gint format;                  /* mibayer_pattern == reference enum :95-101 */
 
-  /* additive, optional properties (the reference has none) */
+  /* additive, optional properties (the reference has none); the defaults give
+   * the reference's behaviour: one device, strictly 1-in/1-out synchronous */
   gint device_id;
+  gchar *devices;               /* "0,1,2,..." round-robin frame sharding; NULL = device-id */
+  gint inflight;                /* frames in flight per device; 1 = synchronous */
+  gboolean use_hipgraph;
+  gboolean pinned_pool;
 
-  /* GPU context; (re)created when caps or the mapped output stride change */
-  mibayer_ctx *ctx;
-  gint ctx_dst_stride;
+  /* GPU side: one shard (mibayer_ctx) per device behind a round-robin pool;
+   * (re)created when caps or the mapped output stride change */
+  mibayer_pool *pool;
+  gint pool_dst_stride;
+  gint capacity;                /* frames the pool may hold in flight */
+  GQueue pending;               /* Bayer2RGBPending*, oldest first */
 };
 
 struct _GstBayer2RGBClass
