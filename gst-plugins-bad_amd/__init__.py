@@ -70,6 +70,7 @@ class Cfg(ctypes.Structure):
 
 MAX_SHARDS = 16
 FLAG_HIPGRAPH = 1
+FLAG_RGB2BAYER = 2
 
 
 class PoolCfg(ctypes.Structure):

@@ -102,6 +102,8 @@ struct mibayer_ctx {
   /* plan */
   uint32_t sel[4];
   int swap_rows = 0;
+  bool inverse = false;                 /* MIBAYER_FLAG_RGB2BAYER */
+  uint32_t r2b_lo[2], r2b_hi[2];        /* rgb2bayer v_perm selectors per row parity */
   const Variant *var = nullptr;         /* launch plan: tile shape ...                */
   int band_override = INT32_MIN;        /* ... and XCD band (INT32_MIN = the variant's);
                                            set by MIBAYER_XCD_BAND or mibayer_autotune() */
@@ -126,6 +128,31 @@ static bool layout_known (int r, int g, int b)
 {
   return (r == 2 && g == 1 && b == 0) || (r == 3 && g == 2 && b == 1)
       || (r == 1 && g == 2 && b == 3) || (r == 0 && g == 1 && b == 2);
+}
+
+/* rgb2bayer: which input byte each CFA site takes -- reference
+ * gstrgb2bayer.c:259-266 with the hard-coded ARGB offsets (+3 blue, +1 red,
+ * +2 green) generalised to (r_off, g_off, b_off). */
+static void make_inverse_plan (mibayer_ctx *c)
+{
+  const mibayer_cfg &f = c->cfg;
+  for (int par = 0; par < 2; par++) {
+    int off[2];
+    for (int col = 0; col < 2; col++) {
+      const int site = (par << 1) | col;          /* "is_blue" in the reference */
+      if (site == f.pattern)
+        off[col] = f.b_off;
+      else if ((site ^ 3) == f.pattern)
+        off[col] = f.r_off;
+      else
+        off[col] = f.g_off;
+    }
+    /* perm (S0 = odd pixel, S1 = even pixel): byte idx 0-3 = S1, 4-7 = S0 */
+    c->r2b_lo[par] = (uint32_t) off[0] | ((uint32_t) (4 + off[1]) << 8)
+        | (0x0cu << 16) | (0x0cu << 24);
+    c->r2b_hi[par] = 0x0cu | (0x0cu << 8) | ((uint32_t) off[0] << 16)
+        | ((uint32_t) (4 + off[1]) << 24);
+  }
 }
 
 static void make_plan (mibayer_ctx *c)
@@ -216,6 +243,28 @@ static int launch (const mibayer_ctx *c, const void *d_src,
 {
   if (nframes == 0)
     return MIBAYER_OK;
+  if (c->inverse) {
+    const mibayer_cfg &f = c->cfg;
+    R2BParams q;
+    q.src = (const uint8_t *) d_src;
+    q.dst = (uint8_t *) d_dst;
+    q.src_frame_bytes = src_frame_bytes;
+    q.dst_frame_bytes = dst_frame_bytes;
+    q.width = f.width;
+    q.height = f.height;
+    q.src_stride = f.src_stride;
+    q.dst_stride = f.dst_stride;
+    q.out_dwords = ((f.width + 3) & ~3) / 4;
+    q.total_rows = (long long) nframes * f.height;
+    for (int k = 0; k < 2; k++) {
+      q.sel_lo[k] = c->r2b_lo[k];
+      q.sel_hi[k] = c->r2b_hi[k];
+    }
+    const bool vec16 = (f.width % 4 == 0) && (f.src_stride % 16 == 0)
+        && aligned16 (d_src) && (nframes == 1 || src_frame_bytes % 16 == 0);
+    HIP_TRY (launch_rgb2bayer (q, vec16, stream));
+    return MIBAYER_OK;
+  }
   KParams p;
   KernelFn kern;
   unsigned grid;
@@ -293,8 +342,34 @@ static int validate (const mibayer_cfg *in, mibayer_cfg *out)
   mibayer_cfg f = *in;
   if (f.pattern < MIBAYER_BGGR || f.pattern > MIBAYER_RGGB)
     return MIBAYER_ERR_ARG;
-  if (f.flags & ~(uint32_t) MIBAYER_FLAG_HIPGRAPH)
+  if (f.flags & ~(uint32_t) (MIBAYER_FLAG_HIPGRAPH | MIBAYER_FLAG_RGB2BAYER))
     return MIBAYER_ERR_ARG;
+  if (f.flags & MIBAYER_FLAG_RGB2BAYER) {
+    /* inverse direction: src = 4 B/pixel, dst = mosaic.  The reference loop
+     * (gstrgb2bayer.c:254-268) has no neighbourhood, so any size >= 1 is valid */
+    if (f.width < 1 || f.height < 1 || f.width > (1 << 28)
+        || f.height > (1 << 28))
+      return MIBAYER_ERR_GEOMETRY;
+    if (f.variant != 0 || f.inflight < 0 || f.inflight > 64)
+      return MIBAYER_ERR_ARG;
+    if (f.src_stride == 0)
+      f.src_stride = 4 * f.width;
+    if (f.dst_stride == 0)
+      f.dst_stride = (f.width + 3) & ~3;          /* gstrgb2bayer.c:179, :255 */
+    if (f.src_stride < 4 * f.width || (f.src_stride & 3))
+      return MIBAYER_ERR_GEOMETRY;
+    if (f.dst_stride < ((f.width + 3) & ~3) || (f.dst_stride & 3))
+      return MIBAYER_ERR_GEOMETRY;
+    for (int v : { f.r_off, f.g_off, f.b_off })
+      if (v < 0 || v > 3)
+        return MIBAYER_ERR_LAYOUT;
+    if (f.r_off == f.g_off || f.g_off == f.b_off || f.r_off == f.b_off)
+      return MIBAYER_ERR_LAYOUT;
+    if (f.inflight == 0)
+      f.inflight = 2;
+    *out = f;
+    return MIBAYER_OK;
+  }
   if (f.variant < 0 || f.variant >= variant_count ())
     return MIBAYER_ERR_ARG;
   if (f.inflight < 0 || f.inflight > 64)
@@ -347,12 +422,16 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   c->device = dev;
   c->src_bytes = (size_t) f.src_stride * f.height;
   c->dst_bytes = (size_t) f.dst_stride * f.height;
+  c->inverse = (f.flags & MIBAYER_FLAG_RGB2BAYER) != 0;
   c->var = &variant (resolve_variant (f.variant, f.width));
   if (const char *e = getenv ("MIBAYER_XCD_BAND"))
     c->band_override = atoi (e);
   if (const char *e = getenv ("MIBAYER_XCD_ROT"))
     c->xcd_rot = atoi (e) & 7;
-  make_plan (c);
+  if (c->inverse)
+    make_inverse_plan (c);
+  else
+    make_plan (c);
 
   DeviceGuard guard (dev);
   if (!guard.ok) {
@@ -557,8 +636,10 @@ static int submit_locked (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
   if (c->pending == (int) c->ring.size ())
     return MIBAYER_ERR_BUSY;
   Slot &s = c->ring[(size_t) c->head];
-  if ((c->cfg.flags & MIBAYER_FLAG_HIPGRAPH)
-      && c->cfg.dst_stride == 4 * c->cfg.width) {
+  const size_t row_bytes = c->inverse ? (size_t) ((c->cfg.width + 3) & ~3)
+      : (size_t) 4 * c->cfg.width;      /* bytes of a destination row that are written */
+  if ((c->cfg.flags & MIBAYER_FLAG_HIPGRAPH) && !c->inverse
+      && (size_t) c->cfg.dst_stride == row_bytes) {
     rc = graph_submit (c, s, src, dst);
     if (rc != MIBAYER_OK)
       return rc;
@@ -578,15 +659,15 @@ static int submit_locked (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
     return rc;
   HIP_TRY (hipEventRecord (s.ev_kernel, c->s_compute));
   HIP_TRY (hipStreamWaitEvent (c->s_d2h, s.ev_kernel, 0));
-  if (c->cfg.dst_stride == 4 * c->cfg.width) {
+  if ((size_t) c->cfg.dst_stride == row_bytes) {
     HIP_TRY (hipMemcpyAsync (dst, s.d_dst, c->dst_bytes, hipMemcpyDeviceToHost,
             c->s_d2h));
   } else {
     /* padded destination rows: only the 4*width written bytes of each row may
      * be touched (the reference never writes the padding either) */
     HIP_TRY (hipMemcpy2DAsync (dst, (size_t) c->cfg.dst_stride, s.d_dst,
-            (size_t) c->cfg.dst_stride, (size_t) 4 * c->cfg.width,
-            (size_t) c->cfg.height, hipMemcpyDeviceToHost, c->s_d2h));
+            (size_t) c->cfg.dst_stride, row_bytes, (size_t) c->cfg.height,
+            hipMemcpyDeviceToHost, c->s_d2h));
   }
   HIP_TRY (hipEventRecord (s.ev_out, c->s_d2h));
   s.tag = tag;
@@ -813,7 +894,7 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     char *report, size_t report_len)
 {
-  if (!c || !d_src || !d_dst || nframes < 1)
+  if (!c || !d_src || !d_dst || nframes < 1 || c->inverse)
     return MIBAYER_ERR_ARG;
   if (report && report_len)
     report[0] = 0;
@@ -948,7 +1029,7 @@ extern "C" int mibayer_fill_synthetic (mibayer_ctx *c, void *d_src,
     size_t src_frame_bytes, uint32_t first_frame, int nframes, uint32_t seed,
     void *hip_stream)
 {
-  if (!c || !d_src || nframes < 0)
+  if (!c || !d_src || nframes < 0 || c->inverse)
     return MIBAYER_ERR_ARG;
   if (nframes > 1 && src_frame_bytes < c->src_bytes)
     return MIBAYER_ERR_GEOMETRY;

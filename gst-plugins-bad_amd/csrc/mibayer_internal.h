@@ -88,6 +88,23 @@ int variant_count ();
 const Variant &variant (int id);
 int resolve_variant (int id, int width);        /* 0 ("auto") -> a concrete id */
 
+/* rgb2bayer (reference gst/bayer/gstrgb2bayer.c:230-278) */
+struct R2BParams {
+  const uint8_t *src;           /* 4 B/pixel */
+  uint8_t *dst;                 /* 1 B/pixel mosaic */
+  unsigned long long src_frame_bytes;
+  unsigned long long dst_frame_bytes;
+  int width;
+  int height;
+  int src_stride;
+  int dst_stride;
+  int out_dwords;               /* ROUND_UP_4(width) / 4 */
+  long long total_rows;         /* nframes * height */
+  uint32_t sel_lo[2];           /* v_perm selectors per row parity: pixels 0,1 */
+  uint32_t sel_hi[2];           /*                                  pixels 2,3 */
+};
+hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream);
+
 /* synthetic mosaic generator kernel launcher */
 hipError_t launch_fill_synthetic (uint8_t *d_buf, int width, int height,
     int stride, unsigned long long frame_bytes, uint32_t first_frame,

@@ -521,6 +521,83 @@ int resolve_variant (int id, int width)
 }
 
 /* ------------------------------------------------------------------------- */
+/* rgb2bayer: the sibling element's per-pixel gather                           */
+/* ------------------------------------------------------------------------- */
+/* Reference gst/bayer/gstrgb2bayer.c:254-268: output byte (j,i) is one channel
+ * of input pixel (j,i), chosen by the CFA site ((j&1)<<1)|(i&1).  4 B read +
+ * 1 B written per pixel: a read-dominated HBM stream.  A lane converts 4 pixels
+ * (16 B in, one dword out); a 256-thread block walks R2B_ROWS rows of a
+ * 1024-pixel column strip so every lane keeps several 16-byte loads in flight.
+ * The two v_perm_b32 selectors per row parity come from the host. */
+constexpr int R2B_ROWS = 8;
+
+template <bool VEC16>
+__global__ void __launch_bounds__ (256)
+rgb2bayer_kernel (R2BParams p)
+{
+  const int xd = blockIdx.y * 256 + threadIdx.x;        /* output dword in the row */
+  if (xd >= p.out_dwords)
+    return;
+  const long long row0 = (long long) blockIdx.x * R2B_ROWS;
+  const int x0 = xd * 4;
+  u32x4 px[R2B_ROWS];
+#pragma unroll
+  for (int k = 0; k < R2B_ROWS; k++) {
+    const long long row = row0 + k;
+    px[k] = (u32x4) (0u);
+    if (row < p.total_rows) {
+      const long long f = row / p.height;
+      const int y = (int) (row - f * p.height);
+      const uint8_t *s = p.src + f * p.src_frame_bytes
+          + (size_t) y * p.src_stride + (size_t) x0 * 4;
+      if constexpr (VEC16) {
+        px[k] = *(const u32x4 *) s;
+      } else {
+        const uint32_t *q = (const uint32_t *) s;
+        if (x0 + 0 < p.width) px[k].x = q[0];
+        if (x0 + 1 < p.width) px[k].y = q[1];
+        if (x0 + 2 < p.width) px[k].z = q[2];
+        if (x0 + 3 < p.width) px[k].w = q[3];
+      }
+    }
+  }
+  /* columns >= width inside the last dword are written as 0 */
+  const int valid = p.width - x0;
+  const uint32_t keep = valid >= 4 ? 0xffffffffu : ((1u << (8 * valid)) - 1u);
+#pragma unroll
+  for (int k = 0; k < R2B_ROWS; k++) {
+    const long long row = row0 + k;
+    if (row < p.total_rows) {
+      const long long f = row / p.height;
+      const int y = (int) (row - f * p.height);
+      const int par = y & 1;
+      const uint32_t lo = __builtin_amdgcn_perm (px[k].y, px[k].x, p.sel_lo[par]);
+      const uint32_t hi = __builtin_amdgcn_perm (px[k].w, px[k].z, p.sel_hi[par]);
+      uint32_t *d = (uint32_t *) (p.dst + f * p.dst_frame_bytes
+          + (size_t) y * p.dst_stride + (size_t) x0);
+      __builtin_nontemporal_store ((lo | hi) & keep, d);
+    }
+  }
+}
+
+hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream)
+{
+  if (p.total_rows <= 0 || p.out_dwords <= 0)
+    return hipSuccess;
+  const long long gx = (p.total_rows + R2B_ROWS - 1) / R2B_ROWS;
+  const int gy = (p.out_dwords + 255) / 256;
+  if (gx > 0x7fffffffLL || gy > 65535)
+    return hipErrorInvalidValue;
+  if (vec16)
+    hipLaunchKernelGGL (rgb2bayer_kernel<true>, dim3 ((unsigned) gx, gy),
+        dim3 (256), 0, stream, p);
+  else
+    hipLaunchKernelGGL (rgb2bayer_kernel<false>, dim3 ((unsigned) gx, gy),
+        dim3 (256), 0, stream, p);
+  return hipGetLastError ();
+}
+
+/* ------------------------------------------------------------------------- */
 /* synthetic mosaic (counter-based, stateless per byte)                        */
 /* ------------------------------------------------------------------------- */
 

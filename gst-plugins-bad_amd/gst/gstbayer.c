@@ -1,14 +1,13 @@
 /* Plugin `bayer`: entry point.
  *
  * Drop-in for reference gst/bayer/gstbayer.c:28-43: same plugin name ("bayer"),
- * same description, same element factory name ("bayer2rgb", GST_RANK_NONE).
- * The sibling element rgb2bayer (reference gstrgb2bayer.c) is not on the
- * accelerated path and is not provided by this build (DESIGN.md "Out of
- * scope"); install this plugin ahead of the stock one with GST_PLUGIN_PATH.
+ * same description, same two element factories ("bayer2rgb" and "rgb2bayer",
+ * both GST_RANK_NONE).  Install ahead of the stock plugin with GST_PLUGIN_PATH.
  */
 #include <gst/gst.h>
 
 #include "gstbayer2rgb.h"
+#include "gstrgb2bayer.h"
 
 #ifndef PACKAGE
 #define PACKAGE "gst-plugins-bad_amd"
@@ -20,7 +19,11 @@
 static gboolean
 plugin_init (GstPlugin * plugin)
 {
-  return gst_bayer2rgb_register (plugin);
+  gboolean ok = FALSE;
+
+  ok |= gst_bayer2rgb_register (plugin);
+  ok |= gst_rgb2bayer_register (plugin);
+  return ok;
 }
 
 GST_PLUGIN_DEFINE (GST_VERSION_MAJOR, GST_VERSION_MINOR, bayer,

@@ -91,6 +91,16 @@ typedef struct mibayer_cfg {
  * three enqueues, two event waits and three event records). */
 #define MIBAYER_FLAG_HIPGRAPH 1u
 
+/* Inverse direction, the plugin's sibling element rgb2bayer (reference
+ * gst/bayer/gstrgb2bayer.c:230-278): the source is 4 B/pixel (src_stride
+ * default 4*width), the destination the 8-bit mosaic (dst_stride default
+ * ROUND_UP_4(width), :179/:255); output byte (j,i) = the R, G or B byte of input
+ * pixel (j,i) selected by the CFA site, with (r_off,g_off,b_off) = byte offsets
+ * inside the INPUT pixel (the reference accepts ARGB only: 1,2,3).  Any
+ * width/height >= 1.  Every host/device/pool entry point works unchanged;
+ * variant must be 0; mibayer_autotune / mibayer_fill_synthetic do not apply. */
+#define MIBAYER_FLAG_RGB2BAYER 2u
+
 typedef struct mibayer_ctx mibayer_ctx;
 
 /* ---- global ------------------------------------------------------------- */

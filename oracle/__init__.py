@@ -36,6 +36,7 @@ def lib():
         frame_args = [_u8p, ctypes.c_int, _u8p, ctypes.c_int] + [ctypes.c_int] * 6
         L.oracle_bayer2rgb.argtypes = frame_args
         L.oracle_bayer2rgb_refrows.argtypes = frame_args
+        L.oracle_rgb2bayer.argtypes = frame_args
         L.oracle_load_ref_rows.argtypes = [ctypes.c_char_p]
         L.oracle_bayer2rgb_batch.argtypes = [
             _u8p, ctypes.c_size_t, ctypes.c_int, _u8p, ctypes.c_size_t, ctypes.c_int,
@@ -80,6 +81,21 @@ def bayer2rgb(src, width, pattern, r_off, g_off, b_off, dst_stride=None, ref_row
     rc = fn(_p(dst), dstride, _p(src), sstride, width, H, pattern, r_off, g_off, b_off)
     if rc != 0:
         raise ValueError("oracle rejected geometry/layout (rc=%d)" % rc)
+    return dst
+
+
+def rgb2bayer(src, width, pattern, r_off=1, g_off=2, b_off=3, dst_stride=None):
+    """src: (H, src_stride) uint8 with 4 B/pixel rows -> (H, dst_stride) uint8 mosaic via the C oracle.
+    Destination bytes beyond `width` keep the 0xA5 guard fill (the reference never writes them)."""
+    if isinstance(pattern, str):
+        pattern = PATTERNS[pattern]
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    H, sstride = src.shape
+    dstride = ((width + 3) & ~3) if dst_stride is None else dst_stride
+    dst = np.full((H, dstride), 0xA5, np.uint8)
+    rc = lib().oracle_rgb2bayer(_p(dst), dstride, _p(src), sstride, width, H, pattern, r_off, g_off, b_off)
+    if rc != 0:
+        raise ValueError("oracle rejected geometry (rc=%d)" % rc)
     return dst
 
 

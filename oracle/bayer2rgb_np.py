@@ -87,6 +87,17 @@ def bayer2rgb(S, pattern, r_off, g_off, b_off):
     return out
 
 
+def rgb2bayer(P, pattern, r_off=1, g_off=2, b_off=3):
+    """Inverse element (gst/bayer/gstrgb2bayer.c:254-268).  P: (H, W, 4) uint8 -> (H, W) uint8.
+    Parity unpinned (see bayer2rgb_oracle.h)."""
+    if isinstance(pattern, str):
+        pattern = PATTERNS[pattern]
+    P = np.asarray(P, dtype=np.uint8)
+    H, W, _ = P.shape
+    site = ((np.arange(H) & 1)[:, None] << 1) | (np.arange(W) & 1)[None, :]
+    return np.where(site == pattern, P[..., b_off], np.where((site ^ 3) == pattern, P[..., r_off], P[..., g_off]))
+
+
 def synthetic_frames(W, H, nframes, seed, first_frame=0, stride=None):
     """SURVEY.md Appendix C counter-based generator -> (nframes, H, stride)."""
     stride = W if stride is None else stride

@@ -359,6 +359,33 @@ oracle_bayer2rgb_batch (uint8_t *dst, size_t dst_frame_bytes, int dst_stride,
   return rc;
 }
 
+/* ---- rgb2bayer --------------------------------------------------------------- */
+
+/* gst_rgb2bayer_transform, gstrgb2bayer.c:254-268 (parity unpinned, see header) */
+int
+oracle_rgb2bayer (uint8_t *dst, int dst_stride, const uint8_t *src,
+    int src_stride, int width, int height, int pattern, int r_off, int g_off,
+    int b_off)
+{
+  int i, j;
+  if (width < 1 || height < 1 || pattern < 0 || pattern > 3)
+    return -1;
+  for (j = 0; j < height; j++) {
+    uint8_t *d = dst + (size_t) j * dst_stride;
+    const uint8_t *s = src + (size_t) j * src_stride;
+    for (i = 0; i < width; i++) {
+      int site = ((j & 1) << 1) | (i & 1);      /* "is_blue", :259 */
+      if (site == pattern)
+        d[i] = s[4 * i + b_off];                /* :261, +3 for ARGB */
+      else if ((site ^ 3) == pattern)
+        d[i] = s[4 * i + r_off];                /* :263, +1 */
+      else
+        d[i] = s[4 * i + g_off];                /* :265, +2 */
+    }
+  }
+  return 0;
+}
+
 /* ---- synthetic input --------------------------------- */
 
 static inline uint32_t

@@ -58,6 +58,17 @@ int oracle_bayer2rgb_batch (uint8_t *dst, size_t dst_frame_bytes, int dst_stride
     int width, int height, int pattern, int r_off, int g_off, int b_off,
     int nframes, int nthreads, int use_ref_rows);
 
+/* Inverse element rgb2bayer, reference gst/bayer/gstrgb2bayer.c:254-268: output
+ * byte (j,i) is byte r_off / g_off / b_off of input pixel (j,i) according to the
+ * CFA site ((j&1)<<1)|(i&1); the reference hard-codes ARGB (r,g,b = 1,2,3).
+ * Padding bytes of a destination row are left untouched, as in the reference.
+ * PARITY UNPINNED for this function: the reference element cannot be built
+ * here (GStreamer >= 1.20 macros) and its tests hold no vectors for it; the
+ * restatement is a line-by-line reading of an 11-line loop. */
+int oracle_rgb2bayer (uint8_t *dst, int dst_stride, const uint8_t *src,
+    int src_stride, int width, int height, int pattern, int r_off, int g_off,
+    int b_off);
+
 /* Counter-based synthetic frames, SURVEY.md Appendix C:
  * byte(f,y,x) = fmix32((f*H*W + y*W + x) * 2654435761 + seed*0x9E3779B9) & 0xff.
  * Padding bytes (x >= W) are written as 0. */

@@ -65,7 +65,7 @@ def test_cfg_validation_matches_reference_domain(pkg):
         assert create(pkg, make_cfg(pkg, r_off=r, g_off=g, b_off=b)) in ok_or_nodev
     for (r, g, b) in [(0, 2, 1), (1, 1, 1), (0, 1, 3), (4, 1, 0)]:
         assert create(pkg, make_cfg(pkg, r_off=r, g_off=g, b_off=b)) == pkg.ERR_LAYOUT
-    for kw in (dict(pattern=4), dict(pattern=-1), dict(flags=2), dict(flags=0x80000000), dict(variant=10 ** 6), dict(inflight=-1)):
+    for kw in (dict(pattern=4), dict(pattern=-1), dict(flags=4), dict(flags=0x80000000), dict(variant=10 ** 6), dict(inflight=-1)):
         assert create(pkg, make_cfg(pkg, **kw)) == pkg.ERR_ARG, kw
     bad = make_cfg(pkg)
     bad.struct_size = 8
@@ -150,3 +150,18 @@ def test_pool_cfg_validation(pkg):
     pc.struct_size = 4
     assert L.mibayer_pool_create(ctypes.byref(pc), ctypes.byref(h)) == pkg.ERR_ARG
     assert L.mibayer_pool_pending(None) == pkg.ERR_ARG
+
+
+def test_rgb2bayer_cfg_validation(pkg):
+    """MIBAYER_FLAG_RGB2BAYER: the reference loop has no neighbourhood, so every size >= 1 is in the domain;
+    strides default to 4*W in / ROUND_UP_4(W) out (gstrgb2bayer.c:179, :255)."""
+    ok_or_nodev = (pkg.OK, pkg.ERR_NO_DEVICE)
+    F = pkg.FLAG_RGB2BAYER
+    for (w, h) in [(1, 1), (3, 2), (5, 7), (640, 480)]:
+        assert create(pkg, make_cfg(pkg, width=w, height=h, r_off=1, g_off=2, b_off=3, flags=F)) in ok_or_nodev
+    for kw in (dict(width=0), dict(height=0), dict(src_stride=4 * 64 - 4), dict(src_stride=4 * 64 + 2),
+               dict(dst_stride=60), dict(dst_stride=66)):
+        assert create(pkg, make_cfg(pkg, r_off=1, g_off=2, b_off=3, flags=F, **kw)) == pkg.ERR_GEOMETRY, kw
+    for (r, g, b) in [(1, 1, 3), (4, 2, 3), (-1, 2, 3)]:
+        assert create(pkg, make_cfg(pkg, r_off=r, g_off=g, b_off=b, flags=F)) == pkg.ERR_LAYOUT
+    assert create(pkg, make_cfg(pkg, r_off=1, g_off=2, b_off=3, flags=F, variant=1)) == pkg.ERR_ARG

@@ -1,0 +1,85 @@
+"""GPU tests of the inverse direction (MIBAYER_FLAG_RGB2BAYER; reference gst/bayer/gstrgb2bayer.c:230-278):
+bit-exact against the oracle, exact left inverse of bayer2rgb at full size, and through the element."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_gst_element import GST_LAUNCH, gst_env, needs_gst, plugin  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+PATTERNS = ("bggr", "gbrg", "grbg", "rggb")
+
+
+def test_rgb2bayer_matches_oracle_all_sizes(gpu_pkg, oracle):
+    rng = np.random.default_rng(9)
+    for (w, h) in [(1, 1), (2, 3), (3, 2), (5, 7), (16, 9), (66, 50), (257, 5), (1024, 9), (1030, 17), (1920, 31)]:
+        src = rng.integers(0, 256, (h, 4 * w), dtype=np.uint8)
+        for pat in PATTERNS:
+            for (r, g, b) in [(1, 2, 3), (0, 1, 2), (2, 1, 0), (3, 2, 1)]:
+                want = oracle.rgb2bayer(src, w, pat, r, g, b)
+                with gpu_pkg.Context(w, h, pat, (r, g, b), flags=gpu_pkg.FLAG_RGB2BAYER) as ctx:
+                    assert ctx.src_stride == 4 * w and ctx.dst_stride == (w + 3) & ~3
+                    got_h = ctx.process_host(src)
+                    got_d = ctx.process_batch_via_device(src[None])[0]
+                for got in (got_h, got_d):
+                    assert np.array_equal(got[:, :w], want[:, :w]), (w, h, pat, (r, g, b))
+                assert (got_d[:, w:] == 0).all()         # padding columns are written as zero on the device
+
+
+def test_rgb2bayer_padded_source_rows_and_batch(gpu_pkg, oracle):
+    rng = np.random.default_rng(10)
+    w, h, n = 130, 21, 5
+    src = rng.integers(0, 256, (n, h, 4 * w + 24), dtype=np.uint8)       # GstVideoMeta-style padded rows
+    with gpu_pkg.Context(w, h, "grbg", (1, 2, 3), src_stride=4 * w + 24, flags=gpu_pkg.FLAG_RGB2BAYER) as ctx:
+        got = ctx.process_batch_via_device(src)
+    for f in range(n):
+        want = oracle.rgb2bayer(src[f], w, "grbg", 1, 2, 3)
+        assert np.array_equal(got[f][:, :w], want[:, :w])
+
+
+def test_round_trip_4k_batch_is_identity(gpu_pkg):
+    """Size-independent property at BASELINE size: rgb2bayer(bayer2rgb(S)) == S for every order and layout,
+    because bayer2rgb keeps each original sample at its own CFA site (4K x 8 frames, device-resident)."""
+    w, h, n = 3840, 2160, 8
+    for pat, fmt in (("bggr", "RGBx"), ("rggb", "BGRx"), ("grbg", "xRGB"), ("gbrg", "xBGR")):
+        with gpu_pkg.Context(w, h, pat, fmt) as fwd, \
+                gpu_pkg.Context(w, h, pat, gpu_pkg.FORMATS[fmt], flags=gpu_pkg.FLAG_RGB2BAYER) as inv:
+            d_src = fwd.device_alloc(n * fwd.src_bytes)
+            d_rgb = fwd.device_alloc(n * fwd.dst_bytes)
+            d_back = fwd.device_alloc(n * inv.dst_bytes)
+            fwd.fill_synthetic(d_src, n, seed=2)
+            fwd.process_device(d_src, d_rgb, n)
+            fwd.sync()
+            inv.process_device(d_rgb, d_back, n)
+            inv.sync()
+            a = fwd.from_device(d_src, n * fwd.src_bytes)
+            b = inv.from_device(d_back, n * inv.dst_bytes)
+            assert np.array_equal(a, b), (pat, fmt)
+            for p in (d_src, d_rgb, d_back):
+                fwd.device_free(p)
+
+
+@needs_gst
+def test_rgb2bayer_element_and_plugin_round_trip(plugin, gpu_pkg, oracle, tmp_path):
+    """videotestsrc ARGB -> rgb2bayer -> bayer2rgb through one pipeline; the mosaic equals the oracle's
+    rgb2bayer of the ARGB frames and the final RGBx equals the oracle's bayer2rgb of that mosaic
+    (the reference's own pipeline test for this element only asserts EOS:
+    tests/check/elements/autovideoconvert.c:98-110)."""
+    w, h, n = 320, 240, 3
+    argb, mosaic, rgb = (str(tmp_path / f) for f in ("argb.raw", "mosaic.raw", "rgb.raw"))
+    pipeline = ("videotestsrc num-buffers=%d ! video/x-raw,format=ARGB,width=%d,height=%d,framerate=30/1 "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! rgb2bayer "
+                "! video/x-bayer,format=grbg ! tee name=u u. ! queue ! filesink location=%s "
+                "u. ! queue ! bayer2rgb ! video/x-raw,format=RGBx ! filesink location=%s"
+                % (n, w, h, argb, mosaic, rgb))
+    res = subprocess.run([GST_LAUNCH, "-q"] + pipeline.split(), capture_output=True, text=True,
+                         env=gst_env(tmp_path), timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    A = np.fromfile(argb, np.uint8).reshape(n, h, 4 * w)
+    M = np.fromfile(mosaic, np.uint8).reshape(n, h, w)
+    R = np.fromfile(rgb, np.uint8).reshape(n, h, 4 * w)
+    for f in range(n):
+        assert np.array_equal(M[f], oracle.rgb2bayer(A[f], w, "grbg", 1, 2, 3)[:, :w])
+        assert np.array_equal(R[f], oracle.bayer2rgb(M[f], w, "grbg", 0, 1, 2))

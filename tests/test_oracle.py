@@ -150,3 +150,26 @@ def test_domain_is_rejected(oracle):
             oracle.bayer2rgb(src, w, "bggr", 0, 1, 2)
     with pytest.raises(ValueError):
         oracle.bayer2rgb(ok, 4, "bggr", 0, 2, 1)    # not one of the reference's 4 layouts
+
+
+def test_rgb2bayer_oracle_forms_agree_and_invert_bayer2rgb(oracle):
+    """rgb2bayer (gstrgb2bayer.c:254-268; parity unpinned) in C and NumPy agree, and it is the exact left
+    inverse of bayer2rgb: every output pixel of bayer2rgb carries the original sample at its own CFA site."""
+    rng = np.random.default_rng(8)
+    for (w, h) in [(1, 1), (3, 2), (5, 7), (16, 9), (66, 50)]:
+        P = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        for pat in PATTERNS:
+            for (r, g, b) in [(1, 2, 3), (0, 1, 2), (2, 1, 0), (3, 2, 1)]:
+                a = oracle.rgb2bayer(P.reshape(h, 4 * w), w, pat, r, g, b)
+                assert np.array_equal(a[:, :w], oracle.np_oracle.rgb2bayer(P, pat, r, g, b))
+                assert (a[:, w:] == 0xA5).all()
+    for (w, h) in [(4, 3), (66, 50), (130, 21)]:
+        S = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        src = np.zeros((h, (w + 3) & ~3), np.uint8)
+        src[:, :w] = S
+        for pat in PATTERNS:
+            for lay in LAYOUTS:
+                r, g, b = oracle.LAYOUTS[lay]
+                rgb = oracle.bayer2rgb(src, w, pat, r, g, b)
+                back = oracle.rgb2bayer(rgb, w, pat, r, g, b)
+                assert np.array_equal(back[:, :w], S), (w, h, pat, lay)
