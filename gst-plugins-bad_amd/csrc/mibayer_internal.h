@@ -100,6 +100,9 @@ struct R2BParams {
   int dst_stride;
   int out_dwords;               /* ROUND_UP_4(width) / 4 */
   long long total_rows;         /* nframes * height */
+  int tiles_x;                  /* filled by launch_rgb2bayer: 1024-px column strips */
+  long long tile_rows;          /*                            groups of R2B_ROWS rows */
+  int band;                     /* XCD band map (see block_to_tile); -1 = one chunk per XCD */
   uint32_t sel_lo[2];           /* v_perm selectors per row parity: pixels 0,1 */
   uint32_t sel_hi[2];           /*                                  pixels 2,3 */
 };

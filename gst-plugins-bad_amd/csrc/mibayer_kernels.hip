@@ -535,10 +535,17 @@ template <bool VEC16>
 __global__ void __launch_bounds__ (256)
 rgb2bayer_kernel (R2BParams p)
 {
-  const int xd = blockIdx.y * 256 + threadIdx.x;        /* output dword in the row */
+  /* same XCD-aware block -> tile map as the demosaic kernel: a "tile" is
+   * R2B_ROWS rows x 1024 pixels, tile rows run through the whole batch */
+  const long long tile = block_to_tile (blockIdx.x, p.tiles_x, p.tile_rows,
+      p.band);
+  if (tile < 0)
+    return;
+  const long long trow = tile / p.tiles_x;
+  const int xd = (int) (tile - trow * p.tiles_x) * 256 + threadIdx.x;   /* output dword in the row */
   if (xd >= p.out_dwords)
     return;
-  const long long row0 = (long long) blockIdx.x * R2B_ROWS;
+  const long long row0 = trow * R2B_ROWS;
   const int x0 = xd * 4;
   u32x4 px[R2B_ROWS];
 #pragma unroll
@@ -584,16 +591,20 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream)
 {
   if (p.total_rows <= 0 || p.out_dwords <= 0)
     return hipSuccess;
-  const long long gx = (p.total_rows + R2B_ROWS - 1) / R2B_ROWS;
-  const int gy = (p.out_dwords + 255) / 256;
-  if (gx > 0x7fffffffLL || gy > 65535)
+  R2BParams q = p;
+  q.tile_rows = (p.total_rows + R2B_ROWS - 1) / R2B_ROWS;
+  q.tiles_x = (p.out_dwords + 255) / 256;
+  if (q.band < 0)               /* one contiguous chunk of tile rows per XCD */
+    q.band = (int) ((q.tile_rows + kNumXcd - 1) / kNumXcd);
+  const long long grid = grid_blocks_for (q.tiles_x, q.tile_rows, q.band);
+  if (grid > 0x7fffffffLL)
     return hipErrorInvalidValue;
   if (vec16)
-    hipLaunchKernelGGL (rgb2bayer_kernel<true>, dim3 ((unsigned) gx, gy),
-        dim3 (256), 0, stream, p);
+    hipLaunchKernelGGL (rgb2bayer_kernel<true>, dim3 ((unsigned) grid),
+        dim3 (256), 0, stream, q);
   else
-    hipLaunchKernelGGL (rgb2bayer_kernel<false>, dim3 ((unsigned) gx, gy),
-        dim3 (256), 0, stream, p);
+    hipLaunchKernelGGL (rgb2bayer_kernel<false>, dim3 ((unsigned) grid),
+        dim3 (256), 0, stream, q);
   return hipGetLastError ();
 }
 
