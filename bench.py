@@ -178,22 +178,38 @@ def host_path_note(pkg, device):
                     "frames; bound by PCIe (5 B/pixel over a Gen5 x16 link), not HBM; never `value`"}
 
 
+def setup_distributed(args):
+    """(world, rank, device ordinal, dist-or-None).  One rank per GPU over RCCL ("nccl"); --backend gloo with
+    --share-gpu exists only to exercise the N > 1 code path on a 1-GPU box (ranks then share GPU 0)."""
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no MI355X visible; the bayer2rgb path has no CPU fallback")
+    device = local_rank % torch.cuda.device_count() if args.share_gpu else local_rank
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist_mod.init_process_group(args.backend)
+        dist = dist_mod
+    return world, rank, device, dist
+
+
 def run_stream(args):
     """BASELINE.json configs[4]: 3840x2160 steady-state stream, pinned double-buffered H2D/D2H + hipGraph launch,
     1000 frames sharded round-robin over the ranks.  PCIe/host-DRAM-bound by construction."""
     import torch
     import __graft_entry__ as entry
     pkg = entry.load_package()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
+    world, rank, local_rank, dist = setup_distributed(args)
     total = 1000
     mine = len(shard_frames(total, world, rank))
     def timed(flags):
@@ -202,7 +218,7 @@ def run_stream(args):
         torch.cuda.synchronize()
         _, e = host_path_rate(pkg, local_rank, mine, 2, flags)
         if dist is not None:
-            t = torch.tensor([e], dtype=torch.float64, device="cuda")
+            t = torch.tensor([e], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e = float(t.item())
         return e
@@ -236,20 +252,9 @@ def run(args):
     import __graft_entry__ as entry
     pkg = entry.load_package()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available() or pkg.device_count() < 1:
+    if pkg.device_count() < 1:
         raise SystemExit("bench.py: no MI355X visible; the bayer2rgb path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
+    world, rank, local_rank, dist = setup_distributed(args)
 
     variant = args.variant
     ctxs = {o: pkg.Context(WIDTH, HEIGHT, o, FORMAT, device=local_rank, variant=variant) for o in ORDERS}
@@ -357,6 +362,10 @@ def main():
     ap.add_argument("--mode", choices=("batch", "stream"), default="batch",
                     help="batch = the headline device-resident metric (default); stream = configs[4] host-fed stream")
     ap.add_argument("--no-graph", action="store_true", help="stream mode: streams+events instead of hipGraph")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend for the barrier / max-reduce (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing only: ranks share the visible GPUs (use with --backend gloo on a 1-GPU box)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # convenience: self-launch one rank per GPU the way the driver does
