@@ -1,0 +1,150 @@
+/* GstHarness / pipeline driver for the MI355X bayer plugin, used by tests/test_gst_harness.py.
+ *
+ * Follows the reference's element-test conventions: GstHarness with hand-built buffers and byte-for-byte
+ * comparison (tests/check/elements/vkcolorconvert.c:61-113), state cycling of a whole pipeline
+ * (tests/check/generic/states.c:106-216), no fork after the GPU runtime is initialised
+ * (tests/check/elements/cudaconvert.c:194-195).
+ *
+ *   element_harness convert <launchline> <sinkcaps> <in.raw> <framebytes> <out.raw>
+ *        push every frame of in.raw through the element, then EOS; write every buffer that comes out
+ *   element_harness flush <launchline> <sinkcaps> <in.raw> <framebytes> <out.raw> <nbefore>
+ *        push <nbefore> frames, FLUSH_START/FLUSH_STOP, push the rest, EOS; write what comes out
+ *   element_harness states <pipeline> <cycles>
+ *        NULL -> PLAYING -> (EOS) -> NULL, <cycles> times, on ONE pipeline instance
+ */
+#include <gst/gst.h>
+#include <gst/check/gstharness.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static int
+drain_to_file (GstHarness * h, FILE * out)
+{
+  GstBuffer *buf;
+  int n = 0;
+
+  while ((buf = gst_harness_try_pull (h)) != NULL) {
+    GstMapInfo map;
+
+    if (!gst_buffer_map (buf, &map, GST_MAP_READ))
+      return -1;
+    fwrite (map.data, 1, map.size, out);
+    gst_buffer_unmap (buf, &map);
+    gst_buffer_unref (buf);
+    n++;
+  }
+  return n;
+}
+
+static int
+run_harness (int argc, char **argv, int flush_after)
+{
+  const char *launch = argv[2], *caps = argv[3], *in_path = argv[4];
+  size_t frame_bytes = (size_t) atol (argv[5]);
+  const char *out_path = argv[6];
+  GstHarness *h = gst_harness_new_parse (launch);
+  FILE *in = fopen (in_path, "rb"), *out = fopen (out_path, "wb");
+  guint8 *frame = g_malloc (frame_bytes);
+  int pushed = 0, pulled = 0, n;
+
+  if (!h || !in || !out) {
+    fprintf (stderr, "setup failed\n");
+    return 2;
+  }
+  gst_harness_set_src_caps_str (h, caps);
+  while (fread (frame, 1, frame_bytes, in) == frame_bytes) {
+    GstBuffer *buf = gst_buffer_new_allocate (NULL, frame_bytes, NULL);
+
+    gst_buffer_fill (buf, 0, frame, frame_bytes);
+    GST_BUFFER_PTS (buf) = (GstClockTime) pushed * GST_SECOND / 30;
+    if (gst_harness_push (h, buf) != GST_FLOW_OK) {
+      fprintf (stderr, "push %d failed\n", pushed);
+      return 3;
+    }
+    pushed++;
+    if (flush_after > 0 && pushed == flush_after) {
+      /* everything still inside the element must be dropped, nothing may leak out later */
+      int before = drain_to_file (h, out);
+      gst_harness_push_event (h, gst_event_new_flush_start ());
+      gst_harness_push_event (h, gst_event_new_flush_stop (TRUE));
+      fprintf (stdout, "before_flush_pulled=%d\n", before);
+      pulled += before;
+      /* a segment must follow a flush before new buffers */
+      {
+        GstSegment seg;
+        gst_segment_init (&seg, GST_FORMAT_TIME);
+        gst_harness_push_event (h, gst_event_new_segment (&seg));
+      }
+    }
+    n = drain_to_file (h, out);
+    if (n < 0)
+      return 4;
+    pulled += n;
+  }
+  gst_harness_push_event (h, gst_event_new_eos ());
+  n = drain_to_file (h, out);
+  pulled += n;
+  fprintf (stdout, "pushed=%d pulled=%d\n", pushed, pulled);
+  fclose (in);
+  fclose (out);
+  g_free (frame);
+  gst_harness_teardown (h);
+  return 0;
+}
+
+static int
+run_states (const char *desc, int cycles)
+{
+  GError *err = NULL;
+  GstElement *pipe = gst_parse_launch (desc, &err);
+  GstBus *bus;
+  int c;
+
+  if (!pipe) {
+    fprintf (stderr, "parse: %s\n", err ? err->message : "?");
+    return 2;
+  }
+  bus = gst_element_get_bus (pipe);
+  for (c = 0; c < cycles; c++) {
+    GstMessage *msg;
+
+    if (gst_element_set_state (pipe, GST_STATE_PLAYING) == GST_STATE_CHANGE_FAILURE) {
+      fprintf (stderr, "cycle %d: cannot go to PLAYING\n", c);
+      return 3;
+    }
+    msg = gst_bus_timed_pop_filtered (bus, 60 * GST_SECOND,
+        GST_MESSAGE_EOS | GST_MESSAGE_ERROR);
+    if (!msg || GST_MESSAGE_TYPE (msg) == GST_MESSAGE_ERROR) {
+      if (msg) {
+        gchar *dbg = NULL;
+        gst_message_parse_error (msg, &err, &dbg);
+        fprintf (stderr, "cycle %d: %s (%s)\n", c, err->message, dbg ? dbg : "");
+      } else
+        fprintf (stderr, "cycle %d: timeout\n", c);
+      return 4;
+    }
+    gst_message_unref (msg);
+    gst_element_set_state (pipe, GST_STATE_NULL);
+    gst_bus_set_flushing (bus, TRUE);
+    gst_bus_set_flushing (bus, FALSE);
+  }
+  fprintf (stdout, "cycles_ok=%d\n", cycles);
+  gst_object_unref (bus);
+  gst_object_unref (pipe);
+  return 0;
+}
+
+int
+main (int argc, char **argv)
+{
+  gst_init (&argc, &argv);
+  if (argc >= 7 && strcmp (argv[1], "convert") == 0)
+    return run_harness (argc, argv, 0);
+  if (argc >= 8 && strcmp (argv[1], "flush") == 0)
+    return run_harness (argc, argv, atoi (argv[7]));
+  if (argc >= 4 && strcmp (argv[1], "states") == 0)
+    return run_states (argv[2], atoi (argv[3]));
+  fprintf (stderr, "usage: see the header of element_harness.c\n");
+  return 64;
+}
