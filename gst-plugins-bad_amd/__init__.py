@@ -118,6 +118,10 @@ ABI = {
     "mibayer_device_free": (None, [_vp, _vp]),
     "mibayer_copy_to_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     "mibayer_copy_from_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    "mibayer_dev_alloc": (_vp, [ctypes.c_int, ctypes.c_size_t]),
+    "mibayer_dev_free": (None, [ctypes.c_int, _vp]),
+    "mibayer_dev_upload": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_size_t]),
+    "mibayer_dev_download": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_size_t]),
     "mibayer_fill_synthetic": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_uint32,
                                               ctypes.c_int, ctypes.c_uint32, _vp]),
     "mibayer_variant_count": (ctypes.c_int, []),

@@ -1028,6 +1028,55 @@ extern "C" int mibayer_copy_from_device (mibayer_ctx *c, void *dst,
   return MIBAYER_OK;
 }
 
+extern "C" void *mibayer_dev_alloc (int device, size_t bytes)
+{
+  if (device < 0 || device >= device_count_cached ())
+    return NULL;
+  DeviceGuard guard (device);
+  if (!guard.ok)
+    return NULL;
+  void *p = NULL;
+  if (hip_failed (hipMalloc (&p, bytes ? bytes : 1), "hipMalloc"))
+    return NULL;
+  return p;
+}
+
+extern "C" void mibayer_dev_free (int device, void *d_ptr)
+{
+  if (!d_ptr || device < 0 || device >= device_count_cached ())
+    return;
+  DeviceGuard guard (device);
+  (void) hipFree (d_ptr);
+}
+
+extern "C" int mibayer_dev_upload (int device, void *d_dst, const void *src,
+    size_t bytes)
+{
+  if (!d_dst || !src)
+    return MIBAYER_ERR_ARG;
+  if (device < 0 || device >= device_count_cached ())
+    return MIBAYER_ERR_NO_DEVICE;
+  DeviceGuard guard (device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  HIP_TRY (hipMemcpy (d_dst, src, bytes, hipMemcpyHostToDevice));
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_dev_download (int device, void *dst, const void *d_src,
+    size_t bytes)
+{
+  if (!dst || !d_src)
+    return MIBAYER_ERR_ARG;
+  if (device < 0 || device >= device_count_cached ())
+    return MIBAYER_ERR_NO_DEVICE;
+  DeviceGuard guard (device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  HIP_TRY (hipMemcpy (dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return MIBAYER_OK;
+}
+
 extern "C" int mibayer_fill_synthetic (mibayer_ctx *c, void *d_src,
     size_t src_frame_bytes, uint32_t first_frame, int nframes, uint32_t seed,
     void *hip_stream)

@@ -1,0 +1,643 @@
+/* Plugin `mihip`: elements that keep video frames in MI355X device memory
+ * (caps feature memory:HIPMemory), SURVEY.md section 8(f) rank 4:
+ *
+ *   hipupload      video/x-raw | video/x-bayer            -> same caps (memory:HIPMemory)
+ *   hipdownload    same caps (memory:HIPMemory)           -> system memory
+ *   hipbayer2rgb   video/x-bayer(memory:HIPMemory)        -> video/x-raw(memory:HIPMemory)
+ *
+ * so that   ... ! hipupload ! hipbayer2rgb ! <GPU consumer>   never moves the
+ * 4 B/pixel output over PCIe -- the only way a *pipeline* gets near the HBM
+ * roofline of the kernel.  They live in their own plugin so that plugin `bayer`
+ * keeps exactly the reference's two element factories.
+ *
+ * Pattern in the reference tree (its NVIDIA path): sys/nvcodec/gstcudaupload.c,
+ * gstcudadownload.c, gstcudabasetransform.c:436-587 (allocation queries).
+ * hipbayer2rgb's caps logic is that of bayer2rgb (gst/bayer/gstbayer2rgb.c:237-352)
+ * with the caps feature carried through.
+ */
+#ifdef HAVE_CONFIG_H
+#include "config.h"
+#endif
+
+#include <string.h>
+
+#include <gst/gst.h>
+#include <gst/base/gstbasetransform.h>
+#include <gst/video/video.h>
+
+#include "gstmihipmemory.h"
+#include "gstmihostpool.h"
+#include "mibayer.h"
+
+GST_DEBUG_CATEGORY_STATIC (gst_mi_hip_debug);
+#define GST_CAT_DEFAULT gst_mi_hip_debug
+
+#define HIP_CAPS(media) media "(" GST_CAPS_FEATURE_MEMORY_HIP ")"
+
+enum
+{
+  PROP_0,
+  PROP_DEVICE_ID
+};
+
+/* bytes of one frame for either media type; same rules as bayer2rgb's
+ * get_unit_size (reference gstbayer2rgb.c:324-352) for the two it knows */
+static gboolean
+frame_size_from_caps (GstCaps * caps, gsize * size)
+{
+  GstStructure *s = gst_caps_get_structure (caps, 0);
+  gint w, h;
+
+  if (gst_structure_has_name (s, "video/x-bayer")) {
+    if (!gst_structure_get_int (s, "width", &w)
+        || !gst_structure_get_int (s, "height", &h))
+      return FALSE;
+    *size = (gsize) GST_ROUND_UP_4 (w) * h;
+    return TRUE;
+  } else {
+    GstVideoInfo info;
+
+    if (!gst_video_info_from_caps (&info, caps))
+      return FALSE;
+    *size = GST_VIDEO_INFO_SIZE (&info);
+    return TRUE;
+  }
+}
+
+static GstCaps *
+caps_with_feature (GstCaps * caps, const gchar * feature)
+{
+  GstCaps *out = gst_caps_copy (caps);
+  guint i, n = gst_caps_get_size (out);
+
+  for (i = 0; i < n; i++)
+    gst_caps_set_features (out, i, feature ? gst_caps_features_new (feature,
+            NULL) : gst_caps_features_new_empty ());
+  return out;
+}
+
+static GstBufferPool *
+configured_pool (GstBufferPool * pool, GstCaps * caps, guint size, guint min)
+{
+  GstStructure *config = gst_buffer_pool_get_config (pool);
+
+  gst_buffer_pool_config_set_params (config, caps, size, min, 0);
+  if (!gst_buffer_pool_set_config (pool, config)) {
+    gst_object_unref (pool);
+    return NULL;
+  }
+  return pool;
+}
+
+/* the single GstMiHipMemory of a buffer, or NULL */
+static GstMemory *
+buffer_hip_memory (GstBuffer * buf)
+{
+  GstMemory *mem;
+
+  if (gst_buffer_n_memory (buf) != 1)
+    return NULL;
+  mem = gst_buffer_peek_memory (buf, 0);
+  return gst_is_mi_hip_memory (mem) ? mem : NULL;
+}
+
+/* ======================================================================== */
+/* hipupload / hipdownload                                                   */
+/* ======================================================================== */
+
+typedef struct
+{
+  GstBaseTransform parent;
+  gint device_id;
+} GstMiHipXfer;
+
+typedef struct
+{
+  GstBaseTransformClass parent_class;
+  gboolean to_device;           /* TRUE: hipupload, FALSE: hipdownload */
+} GstMiHipXferClass;
+
+#define GST_MI_HIP_XFER(obj) ((GstMiHipXfer *) (obj))
+#define GST_MI_HIP_XFER_GET_CLASS(obj) \
+  ((GstMiHipXferClass *) G_OBJECT_GET_CLASS (obj))
+
+G_DEFINE_ABSTRACT_TYPE (GstMiHipXfer, gst_mi_hip_xfer, GST_TYPE_BASE_TRANSFORM);
+
+static void
+xfer_set_property (GObject * object, guint prop_id, const GValue * value,
+    GParamSpec * pspec)
+{
+  if (prop_id == PROP_DEVICE_ID)
+    GST_MI_HIP_XFER (object)->device_id = g_value_get_int (value);
+  else
+    G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
+}
+
+static void
+xfer_get_property (GObject * object, guint prop_id, GValue * value,
+    GParamSpec * pspec)
+{
+  if (prop_id == PROP_DEVICE_ID)
+    g_value_set_int (value, GST_MI_HIP_XFER (object)->device_id);
+  else
+    G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
+}
+
+static GstCaps *
+xfer_transform_caps (GstBaseTransform * trans, GstPadDirection direction,
+    GstCaps * caps, GstCaps * filter)
+{
+  gboolean to_device = GST_MI_HIP_XFER_GET_CLASS (trans)->to_device;
+  /* the pad we produce caps FOR is the other one */
+  gboolean want_device = (direction == GST_PAD_SINK) ? to_device : !to_device;
+  GstCaps *result = caps_with_feature (caps,
+      want_device ? GST_CAPS_FEATURE_MEMORY_HIP : NULL);
+
+  if (filter) {
+    GstCaps *tmp = result;
+
+    result = gst_caps_intersect_full (filter, tmp, GST_CAPS_INTERSECT_FIRST);
+    gst_caps_unref (tmp);
+  }
+  return result;
+}
+
+static gboolean
+xfer_get_unit_size (GstBaseTransform * trans, GstCaps * caps, gsize * size)
+{
+  return frame_size_from_caps (caps, size);
+}
+
+/* upstream allocates system memory: offer it pinned memory (upload only) */
+static gboolean
+xfer_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query,
+    GstQuery * query)
+{
+  GstCaps *caps = NULL;
+  gsize size = 0;
+
+  if (!GST_BASE_TRANSFORM_CLASS (gst_mi_hip_xfer_parent_class)->propose_allocation
+      (trans, decide_query, query))
+    return FALSE;
+  if (!GST_MI_HIP_XFER_GET_CLASS (trans)->to_device
+      || mibayer_device_count () <= 0)
+    return TRUE;
+  gst_query_parse_allocation (query, &caps, NULL);
+  if (caps && frame_size_from_caps (caps, &size)) {
+    GstBufferPool *pool = configured_pool (gst_mi_host_pool_new (), caps,
+        (guint) size, 2);
+
+    if (pool) {
+      gst_query_add_allocation_pool (query, pool, (guint) size, 2, 0);
+      gst_object_unref (pool);
+    }
+  }
+  return TRUE;
+}
+
+/* our own output: device memory (upload) or pinned host memory (download) */
+static gboolean
+xfer_decide_allocation (GstBaseTransform * trans, GstQuery * query)
+{
+  GstMiHipXfer *self = GST_MI_HIP_XFER (trans);
+  gboolean to_device = GST_MI_HIP_XFER_GET_CLASS (trans)->to_device;
+  GstCaps *caps = NULL;
+  gsize size = 0;
+
+  gst_query_parse_allocation (query, &caps, NULL);
+  if (caps && frame_size_from_caps (caps, &size)
+      && mibayer_device_count () > 0) {
+    GstBufferPool *pool = NULL;
+
+    if (to_device) {
+      /* device memory is the only thing our src caps allow: replace whatever
+       * downstream proposed */
+      while (gst_query_get_n_allocation_pools (query) > 0)
+        gst_query_remove_nth_allocation_pool (query, 0);
+      pool = configured_pool (gst_mi_hip_pool_new (self->device_id), caps,
+          (guint) size, 2);
+    } else if (gst_query_get_n_allocation_pools (query) == 0) {
+      pool = configured_pool (gst_mi_host_pool_new (), caps, (guint) size, 2);
+    }
+    if (pool) {
+      gst_query_add_allocation_pool (query, pool, (guint) size, 2, 0);
+      gst_object_unref (pool);
+    }
+  }
+  return GST_BASE_TRANSFORM_CLASS (gst_mi_hip_xfer_parent_class)->decide_allocation
+      (trans, query);
+}
+
+static GstFlowReturn
+xfer_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
+{
+  GstMiHipXfer *self = GST_MI_HIP_XFER (trans);
+  gboolean to_device = GST_MI_HIP_XFER_GET_CLASS (trans)->to_device;
+  GstBuffer *host_buf = to_device ? inbuf : outbuf;
+  GstBuffer *dev_buf = to_device ? outbuf : inbuf;
+  GstMemory *dev_mem = buffer_hip_memory (dev_buf);
+  GstMapInfo host_map, dev_map;
+  GstFlowReturn ret = GST_FLOW_OK;
+  gsize n;
+  int rc;
+
+  if (dev_mem == NULL) {
+    GST_ELEMENT_ERROR (self, CORE, NEGOTIATION,
+        ("%s buffer does not hold HIP device memory", to_device ? "output"
+            : "input"), (NULL));
+    return GST_FLOW_ERROR;
+  }
+  if (!gst_buffer_map (host_buf, &host_map,
+          to_device ? GST_MAP_READ : GST_MAP_WRITE))
+    return GST_FLOW_ERROR;
+  if (!gst_memory_map (dev_mem, &dev_map,
+          (to_device ? GST_MAP_WRITE : GST_MAP_READ) | GST_MAP_HIP)) {
+    gst_buffer_unmap (host_buf, &host_map);
+    return GST_FLOW_ERROR;
+  }
+  n = MIN (host_map.size, dev_map.size);
+  if (to_device)
+    rc = mibayer_dev_upload (((GstMiHipMemory *) dev_mem)->device,
+        dev_map.data, host_map.data, n);
+  else
+    rc = mibayer_dev_download (((GstMiHipMemory *) dev_mem)->device,
+        host_map.data, dev_map.data, n);
+  if (rc != MIBAYER_OK) {
+    GST_ELEMENT_ERROR (self, RESOURCE, FAILED, ("HIP copy failed"),
+        ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
+    ret = GST_FLOW_ERROR;
+  }
+  gst_memory_unmap (dev_mem, &dev_map);
+  gst_buffer_unmap (host_buf, &host_map);
+  return ret;
+}
+
+static void
+gst_mi_hip_xfer_class_init (GstMiHipXferClass * klass)
+{
+  GObjectClass *object_class = G_OBJECT_CLASS (klass);
+  GstBaseTransformClass *transform_class = GST_BASE_TRANSFORM_CLASS (klass);
+
+  object_class->set_property = xfer_set_property;
+  object_class->get_property = xfer_get_property;
+  g_object_class_install_property (object_class, PROP_DEVICE_ID,
+      g_param_spec_int ("device-id", "Device ID", "HIP ordinal of the MI355X",
+          0, G_MAXINT, 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  transform_class->passthrough_on_same_caps = FALSE;
+  transform_class->transform_caps = GST_DEBUG_FUNCPTR (xfer_transform_caps);
+  transform_class->get_unit_size = GST_DEBUG_FUNCPTR (xfer_get_unit_size);
+  transform_class->propose_allocation =
+      GST_DEBUG_FUNCPTR (xfer_propose_allocation);
+  transform_class->decide_allocation =
+      GST_DEBUG_FUNCPTR (xfer_decide_allocation);
+  transform_class->transform = GST_DEBUG_FUNCPTR (xfer_transform);
+}
+
+static void
+gst_mi_hip_xfer_init (GstMiHipXfer * self)
+{
+  self->device_id = 0;
+}
+
+#define SYS_CAPS "video/x-raw; video/x-bayer"
+#define DEV_CAPS HIP_CAPS ("video/x-raw") "; " HIP_CAPS ("video/x-bayer")
+
+typedef GstMiHipXfer GstMiHipUpload;
+typedef GstMiHipXferClass GstMiHipUploadClass;
+typedef GstMiHipXfer GstMiHipDownload;
+typedef GstMiHipXferClass GstMiHipDownloadClass;
+
+GType gst_mi_hip_upload_get_type (void);
+GType gst_mi_hip_download_get_type (void);
+G_DEFINE_TYPE (GstMiHipUpload, gst_mi_hip_upload, gst_mi_hip_xfer_get_type ());
+G_DEFINE_TYPE (GstMiHipDownload, gst_mi_hip_download,
+    gst_mi_hip_xfer_get_type ());
+
+static void
+xfer_add_templates (GstElementClass * element_class, const gchar * sink_caps,
+    const gchar * src_caps)
+{
+  gst_element_class_add_pad_template (element_class,
+      gst_pad_template_new ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
+          gst_caps_from_string (sink_caps)));
+  gst_element_class_add_pad_template (element_class,
+      gst_pad_template_new ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
+          gst_caps_from_string (src_caps)));
+}
+
+static void
+gst_mi_hip_upload_class_init (GstMiHipUploadClass * klass)
+{
+  klass->to_device = TRUE;
+  xfer_add_templates (GST_ELEMENT_CLASS (klass), SYS_CAPS, DEV_CAPS);
+  gst_element_class_set_static_metadata (GST_ELEMENT_CLASS (klass),
+      "HIP uploader", "Filter/Video",
+      "Copies video frames into MI355X device memory (memory:HIPMemory)",
+      "gst-plugins-bad_amd");
+}
+
+static void
+gst_mi_hip_upload_init (GstMiHipUpload * self)
+{
+}
+
+static void
+gst_mi_hip_download_class_init (GstMiHipDownloadClass * klass)
+{
+  klass->to_device = FALSE;
+  xfer_add_templates (GST_ELEMENT_CLASS (klass), DEV_CAPS, SYS_CAPS);
+  gst_element_class_set_static_metadata (GST_ELEMENT_CLASS (klass),
+      "HIP downloader", "Filter/Video",
+      "Copies video frames from MI355X device memory to (pinned) system memory",
+      "gst-plugins-bad_amd");
+}
+
+static void
+gst_mi_hip_download_init (GstMiHipDownload * self)
+{
+}
+
+/* ======================================================================== */
+/* hipbayer2rgb                                                              */
+/* ======================================================================== */
+
+typedef struct
+{
+  GstBaseTransform parent;
+  GstVideoInfo info;
+  gint width, height, r_off, g_off, b_off, format;
+  gint device_id;
+  mibayer_ctx *ctx;
+} GstMiHipBayer2RGB;
+
+typedef struct
+{
+  GstBaseTransformClass parent_class;
+} GstMiHipBayer2RGBClass;
+
+GType gst_mi_hip_bayer2rgb_get_type (void);
+G_DEFINE_TYPE (GstMiHipBayer2RGB, gst_mi_hip_bayer2rgb, GST_TYPE_BASE_TRANSFORM);
+
+#define HB2R_SINK_CAPS HIP_CAPS ("video/x-bayer") \
+  ",format=(string){bggr,grbg,gbrg,rggb}," \
+  "width=(int)[1,MAX],height=(int)[1,MAX],framerate=(fraction)[0/1,MAX]"
+#define HB2R_SRC_CAPS GST_VIDEO_CAPS_MAKE_WITH_FEATURES ( \
+    GST_CAPS_FEATURE_MEMORY_HIP, \
+    "{ RGBx, xRGB, BGRx, xBGR, RGBA, ARGB, BGRA, ABGR }")
+
+static void
+hb2r_drop_ctx (GstMiHipBayer2RGB * self)
+{
+  if (self->ctx) {
+    mibayer_destroy (self->ctx);
+    self->ctx = NULL;
+  }
+}
+
+static void
+hb2r_set_property (GObject * object, guint prop_id, const GValue * value,
+    GParamSpec * pspec)
+{
+  if (prop_id == PROP_DEVICE_ID)
+    ((GstMiHipBayer2RGB *) object)->device_id = g_value_get_int (value);
+  else
+    G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
+}
+
+static void
+hb2r_get_property (GObject * object, guint prop_id, GValue * value,
+    GParamSpec * pspec)
+{
+  if (prop_id == PROP_DEVICE_ID)
+    g_value_set_int (value, ((GstMiHipBayer2RGB *) object)->device_id);
+  else
+    G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
+}
+
+static void
+hb2r_finalize (GObject * object)
+{
+  hb2r_drop_ctx ((GstMiHipBayer2RGB *) object);
+  G_OBJECT_CLASS (gst_mi_hip_bayer2rgb_parent_class)->finalize (object);
+}
+
+/* bayer2rgb's caps transform (reference :289-322); caps features survive the
+ * structure rename because they are stored beside the structure */
+static GstCaps *
+hb2r_transform_caps (GstBaseTransform * trans, GstPadDirection direction,
+    GstCaps * caps, GstCaps * filter)
+{
+  GstCaps *result = gst_caps_copy (caps);
+  guint i, n = gst_caps_get_size (result);
+
+  for (i = 0; i < n; i++) {
+    GstStructure *s = gst_caps_get_structure (result, i);
+
+    if (direction == GST_PAD_SINK) {
+      gst_structure_set_name (s, "video/x-raw");
+      gst_structure_remove_field (s, "format");
+    } else {
+      gst_structure_set_name (s, "video/x-bayer");
+      gst_structure_remove_fields (s, "format", "colorimetry", "chroma-site",
+          NULL);
+    }
+  }
+  if (filter) {
+    GstCaps *tmp = result;
+
+    result = gst_caps_intersect_full (filter, tmp, GST_CAPS_INTERSECT_FIRST);
+    gst_caps_unref (tmp);
+  }
+  return result;
+}
+
+static gboolean
+hb2r_get_unit_size (GstBaseTransform * trans, GstCaps * caps, gsize * size)
+{
+  GstStructure *s = gst_caps_get_structure (caps, 0);
+  gint w, h;
+
+  if (!gst_structure_get_int (s, "width", &w)
+      || !gst_structure_get_int (s, "height", &h))
+    return FALSE;
+  *size = gst_structure_has_name (s, "video/x-raw") ? (gsize) w * h * 4
+      : (gsize) GST_ROUND_UP_4 (w) * h;
+  return TRUE;
+}
+
+static gboolean
+hb2r_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
+{
+  static const gchar *orders[] = { "bggr", "gbrg", "grbg", "rggb" };     /* mibayer_pattern order */
+  GstMiHipBayer2RGB *self = (GstMiHipBayer2RGB *) trans;
+  GstStructure *s = gst_caps_get_structure (incaps, 0);
+  const gchar *order = gst_structure_get_string (s, "format");
+  GstVideoInfo info;
+  mibayer_cfg cfg;
+  gint i;
+  int rc;
+
+  if (!gst_structure_get_int (s, "width", &self->width)
+      || !gst_structure_get_int (s, "height", &self->height) || !order)
+    return FALSE;
+  for (i = 0; i < 4 && !g_str_equal (order, orders[i]); i++);
+  if (i == 4)
+    return FALSE;
+  self->format = i;
+  if (!gst_video_info_from_caps (&info, outcaps))
+    return FALSE;
+  self->info = info;
+  self->r_off = GST_VIDEO_INFO_COMP_OFFSET (&info, 0);
+  self->g_off = GST_VIDEO_INFO_COMP_OFFSET (&info, 1);
+  self->b_off = GST_VIDEO_INFO_COMP_OFFSET (&info, 2);
+
+  hb2r_drop_ctx (self);
+  memset (&cfg, 0, sizeof cfg);
+  cfg.struct_size = sizeof cfg;
+  cfg.width = self->width;
+  cfg.height = self->height;
+  cfg.pattern = self->format;
+  cfg.r_off = self->r_off;
+  cfg.g_off = self->g_off;
+  cfg.b_off = self->b_off;
+  cfg.device = self->device_id;
+  rc = mibayer_create (&cfg, &self->ctx);
+  if (rc != MIBAYER_OK) {
+    self->ctx = NULL;
+    GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
+        ("hipbayer2rgb: cannot create GPU context"),
+        ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
+    return FALSE;
+  }
+  return TRUE;
+}
+
+static gboolean
+hb2r_decide_allocation (GstBaseTransform * trans, GstQuery * query)
+{
+  GstMiHipBayer2RGB *self = (GstMiHipBayer2RGB *) trans;
+  GstCaps *caps = NULL;
+  gsize size = 0;
+
+  gst_query_parse_allocation (query, &caps, NULL);
+  if (caps && hb2r_get_unit_size (trans, caps, &size)) {
+    GstBufferPool *pool;
+
+    while (gst_query_get_n_allocation_pools (query) > 0)
+      gst_query_remove_nth_allocation_pool (query, 0);
+    pool = configured_pool (gst_mi_hip_pool_new (self->device_id), caps,
+        (guint) size, 2);
+    if (pool) {
+      gst_query_add_allocation_pool (query, pool, (guint) size, 2, 0);
+      gst_object_unref (pool);
+    }
+  }
+  return GST_BASE_TRANSFORM_CLASS (gst_mi_hip_bayer2rgb_parent_class)->decide_allocation
+      (trans, query);
+}
+
+static GstFlowReturn
+hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
+{
+  GstMiHipBayer2RGB *self = (GstMiHipBayer2RGB *) trans;
+  GstMemory *in_mem = buffer_hip_memory (inbuf);
+  GstMemory *out_mem = buffer_hip_memory (outbuf);
+  GstMapInfo in_map, out_map;
+  GstFlowReturn ret = GST_FLOW_OK;
+  int rc;
+
+  if (!in_mem || !out_mem || !self->ctx) {
+    GST_ELEMENT_ERROR (self, CORE, NEGOTIATION,
+        ("hipbayer2rgb needs HIP device memory on both pads"), (NULL));
+    return GST_FLOW_ERROR;
+  }
+  if (!gst_memory_map (in_mem, &in_map, GST_MAP_READ | GST_MAP_HIP))
+    return GST_FLOW_ERROR;
+  if (!gst_memory_map (out_mem, &out_map, GST_MAP_WRITE | GST_MAP_HIP)) {
+    gst_memory_unmap (in_mem, &in_map);
+    return GST_FLOW_ERROR;
+  }
+  /* device-resident call: no PCIe traffic at all */
+  rc = mibayer_process_device (self->ctx, in_map.data, 0, out_map.data, 0, 1,
+      mibayer_ctx_stream (self->ctx));
+  if (rc == MIBAYER_OK)
+    rc = mibayer_sync (self->ctx);
+  if (rc != MIBAYER_OK) {
+    GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
+        ("hipbayer2rgb: GPU conversion failed"),
+        ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
+    ret = GST_FLOW_ERROR;
+  }
+  gst_memory_unmap (out_mem, &out_map);
+  gst_memory_unmap (in_mem, &in_map);
+  return ret;
+}
+
+static gboolean
+hb2r_stop (GstBaseTransform * trans)
+{
+  hb2r_drop_ctx ((GstMiHipBayer2RGB *) trans);
+  return TRUE;
+}
+
+static void
+gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
+{
+  GObjectClass *object_class = G_OBJECT_CLASS (klass);
+  GstElementClass *element_class = GST_ELEMENT_CLASS (klass);
+  GstBaseTransformClass *transform_class = GST_BASE_TRANSFORM_CLASS (klass);
+
+  object_class->set_property = hb2r_set_property;
+  object_class->get_property = hb2r_get_property;
+  object_class->finalize = hb2r_finalize;
+  g_object_class_install_property (object_class, PROP_DEVICE_ID,
+      g_param_spec_int ("device-id", "Device ID", "HIP ordinal of the MI355X",
+          0, G_MAXINT, 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  xfer_add_templates (element_class, HB2R_SINK_CAPS, HB2R_SRC_CAPS);
+  gst_element_class_set_static_metadata (element_class,
+      "Bayer to RGB decoder (HIP device memory)", "Filter/Converter/Video",
+      "Converts video/x-bayer to video/x-raw without leaving MI355X memory",
+      "gst-plugins-bad_amd");
+  transform_class->transform_caps = GST_DEBUG_FUNCPTR (hb2r_transform_caps);
+  transform_class->get_unit_size = GST_DEBUG_FUNCPTR (hb2r_get_unit_size);
+  transform_class->set_caps = GST_DEBUG_FUNCPTR (hb2r_set_caps);
+  transform_class->decide_allocation =
+      GST_DEBUG_FUNCPTR (hb2r_decide_allocation);
+  transform_class->transform = GST_DEBUG_FUNCPTR (hb2r_transform);
+  transform_class->stop = GST_DEBUG_FUNCPTR (hb2r_stop);
+}
+
+static void
+gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
+{
+  gst_video_info_init (&self->info);
+  self->device_id = 0;
+  self->ctx = NULL;
+}
+
+/* ======================================================================== */
+
+#ifndef PACKAGE
+#define PACKAGE "gst-plugins-bad_amd"
+#endif
+#ifndef VERSION
+#define VERSION "0.1.0"
+#endif
+
+static gboolean
+plugin_init (GstPlugin * plugin)
+{
+  GST_DEBUG_CATEGORY_INIT (gst_mi_hip_debug, "mihip", 0,
+      "MI355X device-memory elements");
+  return gst_element_register (plugin, "hipupload", GST_RANK_NONE,
+      gst_mi_hip_upload_get_type ())
+      && gst_element_register (plugin, "hipdownload", GST_RANK_NONE,
+      gst_mi_hip_download_get_type ())
+      && gst_element_register (plugin, "hipbayer2rgb", GST_RANK_NONE,
+      gst_mi_hip_bayer2rgb_get_type ());
+}
+
+GST_PLUGIN_DEFINE (GST_VERSION_MAJOR, GST_VERSION_MINOR, mihip,
+    "MI355X device-memory video elements", plugin_init, VERSION, "LGPL",
+    "gst-plugins-bad_amd (MI355X-native bayer2rgb)",
+    "https://gstreamer.freedesktop.org/")

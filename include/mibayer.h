@@ -222,6 +222,14 @@ int mibayer_copy_to_device (mibayer_ctx *ctx, void *d_dst, const void *src,
 int mibayer_copy_from_device (mibayer_ctx *ctx, void *dst, const void *d_src,
     size_t bytes);
 
+/* Context-free device memory helpers (for a GstAllocator of device memory, the
+ * `memory:HIPMemory` caps feature of gst/gstmihipmemory.c): synchronous. */
+void *mibayer_dev_alloc (int device, size_t bytes);
+void mibayer_dev_free (int device, void *d_ptr);
+int mibayer_dev_upload (int device, void *d_dst, const void *src, size_t bytes);
+int mibayer_dev_download (int device, void *dst, const void *d_src,
+    size_t bytes);
+
 /* Counter-based synthetic mosaic generated on the device (stateless per byte;
  * definition in DESIGN.md "Synthetic input"): frames first_frame ..
  * first_frame+nframes-1 with the context's width/height/src_stride. */

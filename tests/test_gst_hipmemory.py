@@ -1,0 +1,74 @@
+"""plugin `mihip` -- device-resident video frames (caps feature memory:HIPMemory),
+hipupload / hipdownload / hipbayer2rgb.  Pipelines in the style of the reference's GPU-element tests
+(tests/check/elements/cudaconvert.c:50-76), but comparing bytes, not just reaching EOS."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_gst_element import GST_INSPECT, GST_LAUNCH, gst_env, md5, needs_gst, plugin  # noqa: F401
+
+pytestmark = needs_gst
+
+
+def launch(tmp, pipeline, debug=None):
+    env = gst_env(tmp)
+    if debug:
+        env.update({"GST_DEBUG": debug, "GST_DEBUG_NO_COLOR": "1"})
+    return subprocess.run([GST_LAUNCH, "-q"] + pipeline.split(), capture_output=True, text=True, env=env, timeout=300)
+
+
+def test_mihip_plugin_registers_three_elements(plugin, tmp_path):
+    out = subprocess.run([GST_INSPECT, "mihip"], capture_output=True, text=True, env=gst_env(tmp_path),
+                         timeout=120).stdout
+    for name in ("hipupload", "hipdownload", "hipbayer2rgb"):
+        assert name + ":" in out
+    out = subprocess.run([GST_INSPECT, "hipbayer2rgb"], capture_output=True, text=True, env=gst_env(tmp_path),
+                         timeout=120).stdout
+    assert "video/x-bayer(memory:HIPMemory)" in out and "video/x-raw(memory:HIPMemory)" in out
+    # plugin `bayer` keeps exactly the reference's two factories
+    out = subprocess.run([GST_INSPECT, "bayer"], capture_output=True, text=True, env=gst_env(tmp_path),
+                         timeout=120).stdout
+    assert "2 elements" in out and "hip" not in out.split("Plugin Details")[-1].lower().replace("gst-plugins", "")
+
+
+@pytest.mark.gpu
+def test_upload_convert_download_pipeline(plugin, gpu_pkg, oracle, tmp_path):
+    w, h, n = 1920, 1080, 5
+    inp, outp = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
+    res = launch(tmp_path,
+                 "videotestsrc num-buffers=%d pattern=snow ! video/x-bayer,format=rggb,width=%d,height=%d,framerate=30/1 "
+                 "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! hipupload ! hipbayer2rgb ! hipdownload "
+                 "! video/x-raw,format=BGRx ! filesink location=%s" % (n, w, h, inp, outp))
+    assert res.returncode == 0, res.stderr[-2000:]
+    src = np.fromfile(inp, np.uint8).reshape(n, h, w)
+    got = np.fromfile(outp, np.uint8).reshape(n, h, 4 * w)
+    want = oracle.bayer2rgb_batch(src, w, "rggb", 2, 1, 0, nthreads=2)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_device_memory_is_cpu_mappable_through_staging(plugin, gpu_pkg, oracle, tmp_path):
+    """No hipdownload: filesink maps the HIPMemory buffers for READ, which stages them through pinned memory."""
+    w, h = 640, 480
+    inp, outp = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
+    res = launch(tmp_path,
+                 "videotestsrc num-buffers=3 ! video/x-bayer,format=bggr,width=%d,height=%d "
+                 "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! hipupload ! hipbayer2rgb "
+                 "! video/x-raw(memory:HIPMemory),format=xRGB ! filesink location=%s" % (w, h, inp, outp))
+    assert res.returncode == 0, res.stderr[-2000:]
+    src = np.fromfile(inp, np.uint8).reshape(3, h, w)
+    got = np.fromfile(outp, np.uint8).reshape(3, h, 4 * w)
+    for f in range(3):
+        assert np.array_equal(got[f], oracle.bayer2rgb(src[f], w, "bggr", 1, 2, 3))
+
+
+@pytest.mark.gpu
+def test_upload_download_is_identity_on_raw_video(plugin, gpu_pkg, tmp_path):
+    a, b = str(tmp_path / "a.raw"), str(tmp_path / "b.raw")
+    res = launch(tmp_path,
+                 "videotestsrc num-buffers=4 ! video/x-raw,format=I420,width=322,height=242 ! tee name=t "
+                 "t. ! queue ! filesink location=%s t. ! queue ! hipupload ! hipdownload ! filesink location=%s" % (a, b))
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert os.path.getsize(a) > 0 and open(a, "rb").read() == open(b, "rb").read()
