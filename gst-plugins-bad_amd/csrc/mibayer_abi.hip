@@ -258,7 +258,7 @@ static int launch (const mibayer_ctx *c, const void *d_src,
     q.total_rows = (long long) nframes * f.height;
     q.tiles_x = 0;
     q.tile_rows = 0;
-    q.band = c->band_override != INT32_MIN ? c->band_override : -1;
+    q.band = c->band_override != INT32_MIN ? c->band_override : 0;
     for (int k = 0; k < 2; k++) {
       q.sel_lo[k] = c->r2b_lo[k];
       q.sel_hi[k] = c->r2b_hi[k];

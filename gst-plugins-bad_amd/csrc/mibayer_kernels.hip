@@ -39,6 +39,8 @@
  */
 #include "mibayer_internal.h"
 
+#include <stdlib.h>
+
 namespace mibayer {
 
 typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
@@ -529,9 +531,7 @@ int resolve_variant (int id, int width)
  * (16 B in, one dword out); a 256-thread block walks R2B_ROWS rows of a
  * 1024-pixel column strip so every lane keeps several 16-byte loads in flight.
  * The two v_perm_b32 selectors per row parity come from the host. */
-constexpr int R2B_ROWS = 8;
-
-template <bool VEC16>
+template <bool VEC16, int R2B_ROWS>
 __global__ void __launch_bounds__ (256)
 rgb2bayer_kernel (R2BParams p)
 {
@@ -592,6 +592,15 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream)
   if (p.total_rows <= 0 || p.out_dwords <= 0)
     return hipSuccess;
   R2BParams q = p;
+  /* rows per block: 2 with the identity block order measured best on MI355X
+   * (74 % of peak vs 67-71 % for the other arms, profiles/r01_rgb2bayer.log);
+   * MIBAYER_R2B_ROWS / MIBAYER_XCD_BAND are tuning overrides */
+  static const int rows_per_block = [] {
+    const char *e = getenv ("MIBAYER_R2B_ROWS");
+    const int v = e ? atoi (e) : 2;
+    return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 2;
+  } ();
+  const int R2B_ROWS = rows_per_block;
   q.tile_rows = (p.total_rows + R2B_ROWS - 1) / R2B_ROWS;
   q.tiles_x = (p.out_dwords + 255) / 256;
   if (q.band < 0)               /* one contiguous chunk of tile rows per XCD */
@@ -599,12 +608,19 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream)
   const long long grid = grid_blocks_for (q.tiles_x, q.tile_rows, q.band);
   if (grid > 0x7fffffffLL)
     return hipErrorInvalidValue;
-  if (vec16)
-    hipLaunchKernelGGL (rgb2bayer_kernel<true>, dim3 ((unsigned) grid),
-        dim3 (256), 0, stream, q);
-  else
-    hipLaunchKernelGGL (rgb2bayer_kernel<false>, dim3 ((unsigned) grid),
-        dim3 (256), 0, stream, q);
+#define R2B_LAUNCH(V, R) hipLaunchKernelGGL ((rgb2bayer_kernel<V, R>), \
+      dim3 ((unsigned) grid), dim3 (256), 0, stream, q)
+  switch (R2B_ROWS * 2 + (vec16 ? 1 : 0)) {
+    case 2 * 2 + 1: R2B_LAUNCH (true, 2); break;
+    case 2 * 2 + 0: R2B_LAUNCH (false, 2); break;
+    case 4 * 2 + 1: R2B_LAUNCH (true, 4); break;
+    case 4 * 2 + 0: R2B_LAUNCH (false, 4); break;
+    case 8 * 2 + 1: R2B_LAUNCH (true, 8); break;
+    case 8 * 2 + 0: R2B_LAUNCH (false, 8); break;
+    case 16 * 2 + 1: R2B_LAUNCH (true, 16); break;
+    default: R2B_LAUNCH (false, 16); break;
+  }
+#undef R2B_LAUNCH
   return hipGetLastError ();
 }
 

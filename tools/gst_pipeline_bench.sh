@@ -1,0 +1,20 @@
+#!/bin/bash
+# Development tool: element-level throughput of bayer2rgb inside a GStreamer pipeline (4K, fakesrc -> fakesink),
+# for the synchronous default and the queued modes.  Run on the GPU box.
+R=${GRAFT_REPO_ROOT:-$PWD}
+export GST_PLUGIN_SYSTEM_PATH_1_0=/opt/conda/lib/gstreamer-1.0 GST_PLUGIN_PATH_1_0=$R/gst-plugins-bad_amd \
+       GST_PLUGIN_SCANNER=/opt/conda/libexec/gstreamer-1.0/gst-plugin-scanner GST_REGISTRY=/tmp/gst_bench.reg
+N=${1:-600}
+/opt/conda/bin/gst-inspect-1.0 bayer2rgb >/dev/null 2>&1   # build the registry before timing anything
+W=3840; H=2160
+run () {
+  local t0=$(date +%s.%N)
+  /opt/conda/bin/gst-launch-1.0 -q fakesrc num-buffers=$1 sizetype=fixed sizemax=$((W*H)) filltype=nothing \
+     ! video/x-bayer,format=rggb,width=$W,height=$H,framerate=0/1 ! $2 ! video/x-raw,format=BGRx ! fakesink sync=false >/dev/null 2>&1
+  local t1=$(date +%s.%N)
+  echo "$t0 $t1" | awk '{print $2-$1}'
+}
+for mode in "bayer2rgb" "bayer2rgb inflight=2" "bayer2rgb inflight=4" "bayer2rgb inflight=3 devices=0,0" "bayer2rgb inflight=4 hipgraph=true" "bayer2rgb pinned-pool=false" "identity"; do
+  a=$(run 20 "$mode"); b=$(run $((N+20)) "$mode")
+  echo "$mode | $a $b $N" | awk -F'|' '{split($2,v," "); dt=v[2]-v[1]; printf "%-44s %7.1f fps  %8.1f Mpix/s  (%.3f s for %d frames)\n", $1, v[3]/dt, v[3]*3840*2160/dt/1e6, dt, v[3]}'
+done
