@@ -6,8 +6,7 @@
  */
 #include <gst/gst.h>
 
-#include "gstbayer2rgb.h"
-#include "gstrgb2bayer.h"
+#include "gstmibayer.h"
 
 #ifndef PACKAGE
 #define PACKAGE "gst-plugins-bad_amd"

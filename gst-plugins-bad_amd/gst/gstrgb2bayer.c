@@ -12,7 +12,41 @@
 
 #include <string.h>
 
-#include "gstrgb2bayer.h"
+#include <gst/gst.h>
+#include <gst/base/gstbasetransform.h>
+#include <gst/video/video.h>
+
+#include "mibayer.h"
+#include "gstmibayer.h"
+
+/* ---- type (private to this file) ------------------------------------------------ */
+
+#define GST_TYPE_RGB_2_BAYER (gst_rgb2bayer_get_type ())
+#define GST_RGB_2_BAYER(obj) \
+  (G_TYPE_CHECK_INSTANCE_CAST ((obj), GST_TYPE_RGB_2_BAYER, GstRGB2Bayer))
+
+typedef struct _GstRGB2Bayer GstRGB2Bayer;
+typedef struct _GstRGB2BayerClass GstRGB2BayerClass;
+
+struct _GstRGB2Bayer
+{
+  GstBaseTransform base_rgb2bayer;
+
+  GstVideoInfo info;            /* input video info */
+  gint width, height;
+  gint format;                  /* mibayer_pattern == reference enum, gstrgb2bayer.h:36-41 */
+
+  gint device_id;               /* additive property */
+  mibayer_ctx *ctx;
+  gint ctx_src_stride;
+};
+
+struct _GstRGB2BayerClass
+{
+  GstBaseTransformClass base_rgb2bayer_class;
+};
+
+GType gst_rgb2bayer_get_type (void);
 
 GST_DEBUG_CATEGORY_STATIC (gst_rgb2bayer_debug);
 #define GST_CAT_DEFAULT gst_rgb2bayer_debug
