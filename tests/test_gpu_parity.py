@@ -387,3 +387,23 @@ def test_hipgraph_host_path_with_changing_pointers(gpu_pkg, oracle):
             ctx.wait()
         for i in range(6):
             assert np.array_equal(outs[i], want[i]), i
+
+
+def test_randomised_geometries_strides_variants(gpu_pkg, oracle):
+    """Seeded fuzz over the whole configuration space of the ABI: even widths 4..4100, heights 3..130, padded
+    source and destination strides, all orders and formats, every kernel variant, host and device paths."""
+    rng = np.random.default_rng(20260926)
+    nvar = len(gpu_pkg.variant_names())
+    for case in range(60):
+        w = int(rng.integers(2, 2051)) * 2
+        h = int(rng.integers(3, 131))
+        if case % 10 == 0:
+            w = int(rng.choice([4, 254, 256, 258, 1022, 1024, 1026, 4096, 4100]))
+        pat = PATTERNS[int(rng.integers(0, 4))]
+        fmt = ALL_FORMATS[int(rng.integers(0, 8))]
+        sstride = ((w + 3) & ~3) + 4 * int(rng.integers(0, 5)) * int(rng.integers(0, 2))
+        dstride = 4 * w + 4 * int(rng.integers(0, 9)) * int(rng.integers(0, 2))
+        variant = int(rng.integers(0, nvar))
+        via = "host" if rng.integers(0, 2) else "device"
+        src = rng.integers(0, 256, (h, sstride), dtype=np.uint8)
+        check(gpu_pkg, oracle, src, w, pat, fmt, variant=variant, dst_stride=dstride, via=via)
