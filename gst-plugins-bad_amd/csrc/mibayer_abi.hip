@@ -108,6 +108,8 @@ struct mibayer_ctx {
   int band_override = INT32_MIN;        /* ... and XCD band (INT32_MIN = the variant's);
                                            set by MIBAYER_XCD_BAND or mibayer_autotune() */
   int xcd_rot = 0;                      /* MIBAYER_XCD_ROT (tuning) */
+  int num_cus = 256;                    /* hipDeviceProp_t.multiProcessorCount */
+  int persist_wgs_per_cu = 4;           /* MIBAYER_PERSIST_WGS (tuning), persistent arms */
   /* streams: uploads, kernels and downloads each get their own queue so that
    * frame n+1's H2D overlaps frame n's kernel and frame n-1's D2H */
   hipStream_t s_h2d = nullptr;
@@ -230,6 +232,19 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
       && (nframes == 1 || (src_frame_bytes % 16 == 0
               && dst_frame_bytes % 16 == 0));
   kern = fast ? c->var->fast : c->var->generic;
+  if (fast && c->var->persistent) {
+    /* persistent arm: only "one chunk per XCD" or "identity" make sense, and
+     * the grid is a fixed number of workgroups per CU */
+    if (p.band > 0)
+      p.band = (int) ((p.tile_rows + kNumXcd - 1) / kNumXcd);
+    const long long ntiles = p.tile_rows * p.tiles_x;
+    long long g = (long long) c->num_cus * c->persist_wgs_per_cu;
+    g -= g % kNumXcd;
+    if (g > ntiles)
+      g = (ntiles + kNumXcd - 1) / kNumXcd * kNumXcd;
+    grid = (unsigned) (g > 0 ? g : kNumXcd);
+    return MIBAYER_OK;
+  }
   const long long g = grid_blocks_for (p.tiles_x, p.tile_rows, p.band);
   if (g > 0x7fffffffLL)
     return MIBAYER_ERR_GEOMETRY;
@@ -431,6 +446,14 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
     c->band_override = atoi (e);
   if (const char *e = getenv ("MIBAYER_XCD_ROT"))
     c->xcd_rot = atoi (e) & 7;
+  if (const char *e = getenv ("MIBAYER_PERSIST_WGS"))
+    c->persist_wgs_per_cu = atoi (e) > 0 ? atoi (e) : 4;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount,
+            dev) == hipSuccess && cus > 0)
+      c->num_cus = cus;
+  }
   if (c->inverse)
     make_inverse_plan (c);
   else

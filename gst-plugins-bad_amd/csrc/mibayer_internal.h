@@ -80,6 +80,8 @@ struct Variant {
   int threads;
   int band;                     /* XCD band map: tile rows per band; 0 = identity, -1 = one
                                    contiguous chunk per XCD */
+  int persistent;               /* 1: `fast` is a persistent kernel launched with a
+                                   CU-count-sized grid that loops over the tiles */
   void (*fast) (KParams);       /* W%16==0, 16-byte aligned rows both sides */
   void (*generic) (KParams);    /* any even W >= 4, 4-byte aligned rows     */
 };

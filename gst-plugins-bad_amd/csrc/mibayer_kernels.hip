@@ -461,15 +461,178 @@ bayer2rgb_direct_kernel (KParams p)
 }
 
 /* ------------------------------------------------------------------------- */
+/* persistent, double-buffered form of the LDS kernel (experiment arm)          */
+/* ------------------------------------------------------------------------- */
+/* One workgroup per CU slot loops over its share of the tiles; the global loads
+ * of tile n+1 are issued before tile n is computed and stored, so the HBM read
+ * latency hides under the store phase instead of under other workgroups
+ * (Little's-law check: the per-tile kernel keeps ~25 of 32 waves resident and
+ * they spend 57 % of their life parked on memory, profiles/r01_sq_counters.md).
+ * Fast path only (W % 16 == 0, aligned rows); same arithmetic, same stores.
+ * MEASURED SLOWER (-12 points): one barrier per tile makes all 8 waves of a
+ * workgroup load, then store, in lock step, while independent small workgroups
+ * keep the memory pipes evenly fed.  Kept as an A/B arm, not used by "auto".  */
+template <int WX, int WY, int RPW, int ST>
+__global__ void __launch_bounds__ (64 * WX * WY)
+bayer2rgb_persist_kernel (KParams p)
+{
+  constexpr int NTHREADS = 64 * WX * WY;
+  constexpr int TW = 256 * WX;
+  constexpr int TR = WY * RPW;
+  constexpr int NROWS = TR + 2;
+  constexpr int PITCH = TW + 32;
+  constexpr int MAIN = 16;
+  constexpr int TPR = TW / 16;
+  constexpr int RPP = NTHREADS / TPR;
+  constexpr int NPASS = (NROWS + RPP - 1) / RPP;
+  static_assert (RPW % 2 == 0, "row parity is derived from the in-tile row");
+  static_assert (2 * NROWS <= NTHREADS, "one halo dword per thread");
+
+  __shared__ __attribute__ ((aligned (16))) uint8_t lds[2][NROWS * PITCH];
+
+  /* this workgroup's tile sequence: first, first+step, ... < end */
+  const long long ntiles = p.tile_rows * p.tiles_x;
+  long long first, step, end;
+  if (p.band <= 0) {
+    first = blockIdx.x;
+    step = gridDim.x;
+    end = ntiles;
+  } else {                      /* one contiguous chunk of tile rows per XCD */
+    const long long xcd = blockIdx.x % kNumXcd;
+    const long long chunk = (long long) p.band * p.tiles_x;
+    first = xcd * chunk + blockIdx.x / kNumXcd;
+    step = gridDim.x / kNumXcd;
+    end = (xcd + 1) * chunk < ntiles ? (xcd + 1) * chunk : ntiles;
+  }
+  if (first >= end)
+    return;
+
+  const int tid = threadIdx.x;
+  const int c16 = (tid % TPR) * 16;
+  const int rr = tid / TPR;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wx = wave % WX;
+  const int wy = wave / WX;
+  const int xl = 256 * wx + 4 * lane;
+  const int edge_off = (lane == 0) ? -4 : 4;
+  const int r0 = wy * RPW;
+
+  struct Tile { const uint8_t *src; uint8_t *dst; int tile_x, tile_y; };
+  auto decode = [&](long long tile) -> Tile {
+    const int tx = (int) (tile % p.tiles_x);
+    const long long trest = tile / p.tiles_x;
+    const int ty = (int) (trest % p.tiles_y);
+    const long long frame = trest / p.tiles_y;
+    Tile t;
+    t.src = p.src + frame * p.src_frame_bytes;
+    t.dst = p.dst + frame * p.dst_frame_bytes;
+    t.tile_x = tx * TW;
+    t.tile_y = ty * TR;
+    return t;
+  };
+
+  u32x4 v[NPASS];
+  uint32_t hv = 0u;
+  auto issue = [&](const Tile &t) {
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int r = i * RPP + rr;
+      const int y = t.tile_y - 1 + r;
+      v[i] = (u32x4) (0u);
+      if (r < NROWS && y <= p.height && t.tile_x + c16 < p.width)
+        v[i] = *(const u32x4 *) (t.src
+            + (size_t) map_row (y, p.height, p.dn_last) * p.src_stride
+            + t.tile_x + c16);
+    }
+    hv = 0u;
+    if (tid < 2 * NROWS) {
+      const int r = tid >> 1;
+      const int y = t.tile_y - 1 + r;
+      const int col = (tid & 1) ? t.tile_x + TW : t.tile_x - 4;
+      if (y <= p.height && col >= 0 && col < p.wlimit4)
+        hv = *(const uint32_t *) (t.src
+            + (size_t) map_row (y, p.height, p.dn_last) * p.src_stride + col);
+    }
+  };
+  auto commit = [&](uint8_t *buf) {
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int r = i * RPP + rr;
+      if (r < NROWS)
+        *(u32x4 *) &buf[r * PITCH + MAIN + c16] = v[i];
+    }
+    if (tid < 2 * NROWS)
+      *(uint32_t *) &buf[(tid >> 1) * PITCH + ((tid & 1) ? MAIN + TW : MAIN - 4)]
+          = hv;
+  };
+  auto compute = [&](const Tile &t, const uint8_t *buf) {
+    const int x0 = t.tile_x + xl;
+    const bool first_lane = (x0 == 0);
+    const int lastmode = (x0 + 4 == p.width) ? 1 : 0;
+    const bool active = x0 < p.width;
+    const uint8_t *lrow = &buf[MAIN + xl];
+    auto lines_of = [&](int r) -> Lines {
+      const uint8_t *q = lrow + r * PITCH;
+      const uint32_t c = *(const uint32_t *) q;
+      const uint32_t edge = *(const uint32_t *) (q + edge_off);
+      return row_lines<true, false> (c, from_lane_below (edge, c),
+          from_lane_above (edge, c), first_lane, lastmode);
+    };
+    Lines up = lines_of (r0);
+    Lines cur = lines_of (r0 + 1);
+    uint8_t *out = t.dst + (size_t) (t.tile_y + r0) * p.dst_stride
+        + (size_t) x0 * 4;
+    const int nrows = p.height - (t.tile_y + r0);
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+      const Lines dn = lines_of (r0 + k + 2);
+      const int type = (k & 1) ^ p.swap_rows;
+      const u32x4 px = merge_rows<true> (up, cur, dn, type, p.sel);
+      if (active && k < nrows)
+        store_pixels<ST, false> (out, px, lastmode);
+      out += p.dst_stride;
+      up = cur;
+      cur = dn;
+    }
+  };
+
+  Tile cur_tile = decode (first);
+  issue (cur_tile);
+  commit (lds[0]);
+  __syncthreads ();
+  int b = 0;
+  for (long long t = first; t < end; t += step) {
+    const long long nxt = t + step;
+    const bool has_next = nxt < end;
+    Tile next_tile = cur_tile;
+    if (has_next) {
+      next_tile = decode (nxt);
+      issue (next_tile);                /* loads stay in flight across compute */
+    }
+    compute (cur_tile, lds[b]);
+    if (has_next)
+      commit (lds[b ^ 1]);
+    __syncthreads ();
+    b ^= 1;
+    cur_tile = next_tile;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* variant table                                                               */
 /* ------------------------------------------------------------------------- */
 
+#define PERSIST_VARIANT(name, WX, WY, RPW, ST)                                 \
+  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1, 1,                   \
+    bayer2rgb_persist_kernel<WX, WY, RPW, ST>,                                 \
+    bayer2rgb_lds_kernel<WX, WY, RPW, 0, ST, true, true> }
 #define LDS_VARIANT(name, WX, WY, RPW, NEIGH, ST, INTRIN)                      \
-  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1,                      \
+  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1, 0,                   \
     bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, false>,               \
     bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, true> }
 #define DIRECT_VARIANT(name, WX, WY, RPW, ST, INTRIN)                          \
-  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1,                      \
+  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1, 0,                   \
     bayer2rgb_direct_kernel<WX, WY, RPW, ST, INTRIN, false>,                   \
     bayer2rgb_direct_kernel<WX, WY, RPW, ST, INTRIN, true> }
 
@@ -480,7 +643,7 @@ bayer2rgb_direct_kernel (KParams p)
  * ds_bpermute and LDS neighbour reads tie; the no-LDS arm loses 15 points. */
 static const Variant kVariants[] = {
   /* 0: "auto" -- resolved per stream width by resolve_variant() below */
-  { "auto", 0, 0, 0, -1, nullptr, nullptr },
+  { "auto", 0, 0, 0, -1, 0, nullptr, nullptr },
   /* 1-3: the production shapes (tile 1024x8, 512x16, 256x32; 512 threads) */
   LDS_VARIANT ("lds_4x2_r4_dpp_nt", 4, 2, 4, 0, 1, true),
   LDS_VARIANT ("lds_2x4_r4_dpp_nt", 2, 4, 4, 0, 1, true),
@@ -496,6 +659,10 @@ static const Variant kVariants[] = {
   LDS_VARIANT ("lds_1x8_r2_dpp_nt", 1, 8, 2, 0, 1, true),
   LDS_VARIANT ("lds_4x1_r16_dpp_nt", 4, 1, 16, 0, 1, true),
   DIRECT_VARIANT ("direct_1x4_r8_nt", 1, 4, 8, 1, true),
+  /* negative result kept as a verified arm: 64-68 % of peak vs 77-80 % for the
+   * per-tile kernels in the same interleaved run (profiles/r01_sweep_persistent.log) */
+  PERSIST_VARIANT ("persist_4x2_r4_nt", 4, 2, 4, 1),
+  PERSIST_VARIANT ("persist_1x8_r4_nt", 1, 8, 4, 1),
 };
 
 int variant_count ()
