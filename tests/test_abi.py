@@ -129,7 +129,7 @@ def test_xcd_block_to_tile_is_a_bijection(pkg):
 def test_launch_geometry_needs_no_device_math(pkg):
     # pure host arithmetic check of the tile grid through the variant table
     names = pkg.variant_names()
-    assert names[0] == "auto" and all(n.startswith(("lds_", "direct_")) for n in names[1:])
+    assert names[0] == "auto" and all(n.startswith(("lds_", "direct_", "persist_")) for n in names[1:])
 
 
 def test_pool_cfg_validation(pkg):
