@@ -659,6 +659,8 @@ static const Variant kVariants[] = {
   LDS_VARIANT ("lds_1x8_r2_dpp_nt", 1, 8, 2, 0, 1, true),
   LDS_VARIANT ("lds_4x1_r16_dpp_nt", 4, 1, 16, 0, 1, true),
   DIRECT_VARIANT ("direct_1x4_r8_nt", 1, 4, 8, 1, true),
+  LDS_VARIANT ("lds_1x1_r4_dpp_nt", 1, 1, 4, 0, 1, true),
+  LDS_VARIANT ("lds_1x4_r4_dpp_nt", 1, 4, 4, 0, 1, true),
   /* negative result kept as a verified arm: 64-68 % of peak vs 77-80 % for the
    * per-tile kernels in the same interleaved run (profiles/r01_sweep_persistent.log) */
   PERSIST_VARIANT ("persist_4x2_r4_nt", 4, 2, 4, 1),
