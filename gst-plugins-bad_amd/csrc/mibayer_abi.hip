@@ -554,7 +554,16 @@ extern "C" int mibayer_launch_geometry (const mibayer_ctx *c, int nframes,
   if (!c || nframes < 0)
     return MIBAYER_ERR_ARG;
   KParams p;
-  fill_params (c, p, NULL, 0, NULL, 0, nframes);
+  KernelFn kern;
+  unsigned grid = 0;
+  /* aligned dummy pointers: report the plan of the 16-byte fast path when the
+   * geometry allows it */
+  int rc = plan_launch (c, (const void *) 256, c->src_bytes, (void *) 256,
+      c->dst_bytes, nframes > 0 ? nframes : 1, p, kern, grid);
+  if (rc != MIBAYER_OK)
+    return rc;
+  if (nframes == 0)
+    grid = 0;
   if (tile_w)
     *tile_w = c->var->tile_w;
   if (tile_h)
@@ -562,11 +571,11 @@ extern "C" int mibayer_launch_geometry (const mibayer_ctx *c, int nframes,
   if (tiles_x)
     *tiles_x = p.tiles_x;
   if (tile_rows)
-    *tile_rows = p.tile_rows;
+    *tile_rows = nframes > 0 ? p.tile_rows : 0;
   if (band)
     *band = p.band;
   if (grid_blocks)
-    *grid_blocks = grid_blocks_for (p.tiles_x, p.tile_rows, p.band);
+    *grid_blocks = grid;
   return MIBAYER_OK;
 }
 
