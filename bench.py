@@ -90,18 +90,26 @@ def cpu_baseline(budget_s=12.0, sample_frames=32):
     r, g, b = oracle.LAYOUTS[FORMAT]
     oracle.bayer2rgb_batch(src[:1], WIDTH, "rggb", r, g, b, nthreads=1)      # warm-up / page-in
 
-    def run(nthreads, budget):
+    def run(nthreads, budget, ref_rows=False):
         reps, t0 = 0, time.perf_counter()
         while True:
-            oracle.bayer2rgb_batch(src, WIDTH, ORDERS[reps % 4], r, g, b, nthreads=nthreads)
+            oracle.bayer2rgb_batch(src, WIDTH, ORDERS[reps % 4], r, g, b, nthreads=nthreads, ref_rows=ref_rows)
             reps += 1
             el = time.perf_counter() - t0
             if el >= budget:
                 return WIDTH * HEIGHT * sample_frames * reps / el / 1e6, reps, el
 
-    v1, reps1, el1 = run(1, budget_s * 0.6)
+    v1, reps1, el1 = run(1, budget_s * 0.5)
     nthreads = min(ncores, sample_frames)
-    vn, repsn, eln = run(nthreads, budget_s * 0.4)
+    vn, repsn, eln = run(nthreads, budget_s * 0.25)
+    ref = None
+    if oracle.have_ref_rows():
+        # the reference's own compiled row kernels (gstbayerorc-dist.c, -DDISABLE_ORC = its C backup path)
+        # under the restated frame driver; prebuilt in the build container, travels as a binary
+        vr, repsr, elr = run(1, budget_s * 0.25, ref_rows=True)
+        ref = {"value": round(vr, 1), "cores": 1, "kind": "reference", "passes": repsr,
+               "note": "oracle/_ref row kernels = reference gstbayerorc-dist.c built -DDISABLE_ORC -O2 (the "
+                       "reference's no-ORC C path, not the ORC JIT), restated frame driver"}
     return {
         "value": round(v1, 1), "unit": "Mpix/s", "cores": 1, "kind": "port",
         "sample": "%d of the %d 4K frames (seed %d, frames 0-%d) -> %s, all 4 orders cycled, "
@@ -110,6 +118,7 @@ def cpu_baseline(budget_s=12.0, sample_frames=32):
                       sample_frames, BATCH, SEED, sample_frames - 1, FORMAT, reps1, el1),
         "all_cores": {"value": round(vn, 1), "cores": nthreads, "host_cores": ncores, "passes": repsn,
                       "note": "frame-parallel pthreads, one frame per thread"},
+        "reference_c_path": ref,
     }
 
 
