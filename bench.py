@@ -272,19 +272,8 @@ def run(args):
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
-    if args.alloc == "hip":     # A/B arm: raw hipMalloc instead of torch's caching allocator
-        class _Raw:
-            def __init__(self, n):
-                self.p, self.n = ctx0.device_alloc(n), n
-            def data_ptr(self):
-                return self.p
-            def __getitem__(self, sl):
-                import numpy as np
-                return torch.from_numpy(np.array(ctx0.from_device(self.p + sl.start, sl.stop - sl.start)))
-        d_src, d_dst = _Raw(BATCH * ctx0.src_bytes), _Raw(BATCH * ctx0.dst_bytes)
-    else:
-        d_src = torch.empty(BATCH * ctx0.src_bytes, dtype=torch.uint8, device="cuda")
-        d_dst = torch.empty(BATCH * ctx0.dst_bytes, dtype=torch.uint8, device="cuda")
+    d_src = torch.empty(BATCH * ctx0.src_bytes, dtype=torch.uint8, device="cuda")
+    d_dst = torch.empty(BATCH * ctx0.dst_bytes, dtype=torch.uint8, device="cuda")
     # synthetic frames generated in HBM: this rank's i-th frame is global frame rank + i*world
     for i, gframe in enumerate(shard_frames(BATCH * world, world, rank)):
         ctx0.fill_synthetic(d_src.data_ptr() + i * ctx0.src_bytes, 1, SEED, first_frame=gframe,
@@ -366,7 +355,6 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
-    ap.add_argument("--alloc", choices=("torch", "hip"), default="torch")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--mode", choices=("batch", "stream"), default="batch",
                     help="batch = the headline device-resident metric (default); stream = configs[4] host-fed stream")

@@ -157,9 +157,9 @@ static void make_inverse_plan (mibayer_ctx *c)
   }
 }
 
-static void make_plan (mibayer_ctx *c)
+static void plan_selectors (const mibayer_cfg &f, uint32_t sel[4],
+    int &swap_rows)
 {
-  const mibayer_cfg &f = c->cfg;
   int rp = f.r_off, bp = f.b_off, gp = f.g_off;
   /* "For RGGB, we swap the red offset and blue offset in the output.  For
    * GRBG, we swap the order of the merge functions.  For GBRG, do both."
@@ -169,7 +169,7 @@ static void make_plan (mibayer_ctx *c)
     rp = bp;
     bp = t;
   }
-  c->swap_rows = (f.pattern == MIBAYER_GRBG || f.pattern == MIBAYER_GBRG);
+  swap_rows = (f.pattern == MIBAYER_GRBG || f.pattern == MIBAYER_GBRG);
   const int ap = 6 - rp - gp - bp;
   /* output pixel k = v_perm_b32 (M, G, sel[k]) with
    *   M = [r' b' r' b'] of pixels (k&~1), (k|1)  -> bytes 4..7 of {M,G}
@@ -181,8 +181,13 @@ static void make_plan (mibayer_ctx *c)
     s |= (uint32_t) (5 + 2 * (k & 1)) << (8 * bp);
     s |= (uint32_t) k << (8 * gp);
     s |= (uint32_t) 0x0d << (8 * ap);
-    c->sel[k] = s;
+    sel[k] = s;
   }
+}
+
+static void make_plan (mibayer_ctx *c)
+{
+  plan_selectors (c->cfg, c->sel, c->swap_rows);
 }
 
 static bool aligned16 (const void *p)
@@ -532,6 +537,21 @@ extern "C" void mibayer_destroy (mibayer_ctx *c)
   if (c->s_d2h)
     (void) hipStreamDestroy (c->s_d2h);
   delete c;
+}
+
+extern "C" int mibayer_plan_selectors (const mibayer_cfg *cfg, uint32_t sel[4],
+    int *swap_rows)
+{
+  if (!sel || !swap_rows)
+    return MIBAYER_ERR_ARG;
+  mibayer_cfg f;
+  int rc = validate (cfg, &f);
+  if (rc != MIBAYER_OK)
+    return rc;
+  if (f.flags & MIBAYER_FLAG_RGB2BAYER)
+    return MIBAYER_ERR_ARG;
+  plan_selectors (f, sel, *swap_rows);
+  return MIBAYER_OK;
 }
 
 extern "C" const char *mibayer_ctx_variant_name (const mibayer_ctx *c)

@@ -245,6 +245,14 @@ int mibayer_variant_count (void);
 const char *mibayer_variant_name (int variant);
 /* name of the concrete variant the context resolved to */
 const char *mibayer_ctx_variant_name (const mibayer_ctx *ctx);
+/* Pure host arithmetic, no device needed: the four v_perm_b32 selectors (output
+ * pixel k = perm ({R'B' pair word, G word}, sel[k])) and the row-type swap that
+ * mibayer_create() derives from (pattern, r_off, g_off, b_off) -- the kernel's
+ * replacement for the reference's merge-function table and pointer swaps
+ * (gstbayer2rgb.c:400-427).  Lets the byte-placement logic be checked on a CPU. */
+int mibayer_plan_selectors (const mibayer_cfg *cfg, uint32_t sel[4],
+    int *swap_rows);
+
 /* Launch geometry the context would use for nframes frames: tile size in
  * pixels, tiles per tile row, tile rows in the batch (nframes * tiles_y), the
  * XCD band (tile rows per XCD band, 0 = identity map) and the grid size.  Any
