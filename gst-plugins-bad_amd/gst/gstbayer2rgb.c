@@ -716,6 +716,44 @@ gst_bayer2rgb_sink_event (GstBaseTransform * base, GstEvent * event)
       (base, event);
 }
 
+/* queued mode holds up to `capacity` frames back: report that to live pipelines */
+static gboolean
+gst_bayer2rgb_query (GstBaseTransform * base, GstPadDirection direction,
+    GstQuery * query)
+{
+  GstBayer2RGB *self = GST_BAYER2RGB (base);
+
+  if (direction == GST_PAD_SRC && GST_QUERY_TYPE (query) == GST_QUERY_LATENCY
+      && bayer2rgb_is_queued_mode (self)) {
+    gboolean live = FALSE;
+    GstClockTime min = 0, max = GST_CLOCK_TIME_NONE;
+    gint fps_n = GST_VIDEO_INFO_FPS_N (&self->info);
+    gint fps_d = GST_VIDEO_INFO_FPS_D (&self->info);
+
+    if (!gst_pad_peer_query (GST_BASE_TRANSFORM_SINK_PAD (base), query))
+      return FALSE;
+    gst_query_parse_latency (query, &live, &min, &max);
+    if (fps_n > 0 && fps_d > 0) {
+      mibayer_pool_cfg pc;
+      GstClockTime held;
+
+      if (!bayer2rgb_parse_devices (self, &pc))
+        pc.ndevices = 1;
+      held = gst_util_uint64_scale_int (GST_SECOND * (guint64) (self->inflight
+              * pc.ndevices), fps_d, fps_n);
+      min += held;
+      if (GST_CLOCK_TIME_IS_VALID (max))
+        max += held;
+      GST_DEBUG_OBJECT (self, "queued mode adds %" GST_TIME_FORMAT " latency",
+          GST_TIME_ARGS (held));
+    }
+    gst_query_set_latency (query, live, min, max);
+    return TRUE;
+  }
+  return GST_BASE_TRANSFORM_CLASS (gst_bayer2rgb_parent_class)->query (base,
+      direction, query);
+}
+
 static gboolean
 gst_bayer2rgb_stop (GstBaseTransform * base)
 {
@@ -782,6 +820,7 @@ gst_bayer2rgb_class_init (GstBayer2RGBClass * klass)
   transform_class->generate_output =
       GST_DEBUG_FUNCPTR (gst_bayer2rgb_generate_output);
   transform_class->sink_event = GST_DEBUG_FUNCPTR (gst_bayer2rgb_sink_event);
+  transform_class->query = GST_DEBUG_FUNCPTR (gst_bayer2rgb_query);
   transform_class->propose_allocation =
       GST_DEBUG_FUNCPTR (gst_bayer2rgb_propose_allocation);
   transform_class->decide_allocation =
