@@ -225,3 +225,14 @@ def test_pinned_pools_are_proposed_and_used(plugin, gpu_pkg, oracle, tmp_path):
                           timeout=300)
     assert res2.returncode == 0, res2.stderr[-2000:]
     assert open(outp, "rb").read() == open(out2, "rb").read()
+
+
+@pytest.mark.gpu
+@needs_gst
+def test_out_of_domain_geometry_is_a_clear_error(plugin, gpu_pkg, tmp_path):
+    """Odd widths are where the reference reads stale scratch (gstbayer2rgb.c:365-380): this element refuses them
+    with a STREAM/FORMAT error instead of producing undefined pixels."""
+    res = launch(tmp_path, "videotestsrc num-buffers=1 ! video/x-bayer,format=bggr,width=65,height=48 "
+                           "! bayer2rgb ! fakesink")
+    assert res.returncode != 0
+    assert "unsupported frame geometry 65x48" in res.stderr + res.stdout
