@@ -407,3 +407,32 @@ def test_randomised_geometries_strides_variants(gpu_pkg, oracle):
         via = "host" if rng.integers(0, 2) else "device"
         src = rng.integers(0, 256, (h, sstride), dtype=np.uint8)
         check(gpu_pkg, oracle, src, w, pat, fmt, variant=variant, dst_stride=dstride, via=via)
+
+
+def test_guard_bands_around_the_destination_stay_intact(gpu_pkg, oracle):
+    """No out-of-bounds stores: 4 KiB guard bands before and after the device destination (and the row padding
+    inside it) keep their fill for edge geometries, both kernel paths, every production shape and the A/B arms."""
+    rng = np.random.default_rng(77)
+    guard = 4096
+    names = gpu_pkg.variant_names()
+    cases = [(4, 3), (6, 5), (254, 9), (258, 33), (1022, 8), (1026, 17), (2050, 12), (3840, 10), (512, 64)]
+    for (w, h) in cases:
+        sstride = (w + 3) & ~3
+        dstride = 4 * w + 32
+        src = rng.integers(0, 256, (h, sstride), dtype=np.uint8)
+        want = oracle.bayer2rgb(src, w, "grbg", 2, 1, 0)
+        for v in range(len(names)):
+            with gpu_pkg.Context(w, h, "grbg", "BGRx", src_stride=sstride, dst_stride=dstride, variant=v) as ctx:
+                d_src = ctx.device_alloc(ctx.src_bytes)
+                d_all = ctx.device_alloc(ctx.dst_bytes + 2 * guard)
+                ctx.to_device(d_src, src)
+                ctx.to_device(d_all, np.full(ctx.dst_bytes + 2 * guard, 0xC3, np.uint8))
+                ctx.process_device(d_src, d_all + guard, 1)
+                ctx.sync()
+                out = ctx.from_device(d_all, ctx.dst_bytes + 2 * guard)
+                ctx.device_free(d_src)
+                ctx.device_free(d_all)
+            assert (out[:guard] == 0xC3).all() and (out[-guard:] == 0xC3).all(), (w, h, names[v])
+            body = out[guard:-guard].reshape(h, dstride)
+            assert np.array_equal(body[:, :4 * w], want), (w, h, names[v])
+            assert (body[:, 4 * w:] == 0xC3).all(), (w, h, names[v])
