@@ -195,8 +195,15 @@ static bool aligned16 (const void *p)
   return (((uintptr_t) p) & 15u) == 0;
 }
 
-static void fill_params (const mibayer_ctx *c, KParams &p, const void *d_src,
-    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes)
+/* tile grid of one launch (host side; the kernel gets the division-free TileMap) */
+struct Geometry {
+  int tiles_x, tiles_y, band;
+  long long tile_rows;
+};
+
+static void fill_params (const mibayer_ctx *c, KParams &p, Geometry &g,
+    const void *d_src, size_t src_frame_bytes, void *d_dst,
+    size_t dst_frame_bytes, int nframes)
 {
   const mibayer_cfg &f = c->cfg;
   p.src = (const uint8_t *) d_src;
@@ -209,14 +216,13 @@ static void fill_params (const mibayer_ctx *c, KParams &p, const void *d_src,
   p.dst_stride = f.dst_stride;
   p.wlimit4 = (f.width + 3) & ~3;
   p.dn_last = f.height >= 4 ? f.height - 4 : 1;   /* ring slot reuse, :430-447 */
-  p.tiles_x = (f.width + c->var->tile_w - 1) / c->var->tile_w;
-  p.tiles_y = (f.height + c->var->tile_h - 1) / c->var->tile_h;
-  p.tile_rows = (long long) nframes * p.tiles_y;
+  g.tiles_x = (f.width + c->var->tile_w - 1) / c->var->tile_w;
+  g.tiles_y = (f.height + c->var->tile_h - 1) / c->var->tile_h;
+  g.tile_rows = (long long) nframes * g.tiles_y;
   int band = c->band_override != INT32_MIN ? c->band_override : c->var->band;
   if (band < 0)                 /* one contiguous chunk of tile rows per XCD */
-    band = (int) ((p.tile_rows + kNumXcd - 1) / kNumXcd);
-  p.band = band;
-  p.xcd_rot = c->xcd_rot;
+    band = (int) ((g.tile_rows + kNumXcd - 1) / kNumXcd);
+  g.band = band;
   for (int k = 0; k < 4; k++)
     p.sel[k] = c->sel[k];
   p.swap_rows = c->swap_rows;
@@ -228,9 +234,13 @@ typedef void (*KernelFn) (KParams);
  * grid size */
 static int plan_launch (const mibayer_ctx *c, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
-    KParams &p, KernelFn &kern, unsigned &grid)
+    KParams &p, KernelFn &kern, unsigned &grid, Geometry *geom = nullptr)
 {
-  fill_params (c, p, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes);
+  Geometry g;
+  fill_params (c, p, g, d_src, src_frame_bytes, d_dst, dst_frame_bytes,
+      nframes);
+  if (g.tile_rows * g.tiles_x > 0x7fffffffLL)
+    return MIBAYER_ERR_GEOMETRY;
   const mibayer_cfg &f = c->cfg;
   const bool fast = (f.width % 16 == 0) && (f.src_stride % 16 == 0)
       && (f.dst_stride % 16 == 0) && aligned16 (d_src) && aligned16 (d_dst)
@@ -240,20 +250,23 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
   if (fast && c->var->persistent) {
     /* persistent arm: only "one chunk per XCD" or "identity" make sense, and
      * the grid is a fixed number of workgroups per CU */
-    if (p.band > 0)
-      p.band = (int) ((p.tile_rows + kNumXcd - 1) / kNumXcd);
-    const long long ntiles = p.tile_rows * p.tiles_x;
-    long long g = (long long) c->num_cus * c->persist_wgs_per_cu;
-    g -= g % kNumXcd;
-    if (g > ntiles)
-      g = (ntiles + kNumXcd - 1) / kNumXcd * kNumXcd;
-    grid = (unsigned) (g > 0 ? g : kNumXcd);
-    return MIBAYER_OK;
+    if (g.band > 0)
+      g.band = (int) ((g.tile_rows + kNumXcd - 1) / kNumXcd);
+    const long long ntiles = g.tile_rows * g.tiles_x;
+    long long n = (long long) c->num_cus * c->persist_wgs_per_cu;
+    n -= n % kNumXcd;
+    if (n > ntiles)
+      n = (ntiles + kNumXcd - 1) / kNumXcd * kNumXcd;
+    grid = (unsigned) (n > 0 ? n : kNumXcd);
+  } else {
+    const long long n = grid_blocks_for (g.tiles_x, g.tile_rows, g.band);
+    if (n > 0x7fffffffLL)
+      return MIBAYER_ERR_GEOMETRY;
+    grid = (unsigned) n;
   }
-  const long long g = grid_blocks_for (p.tiles_x, p.tile_rows, p.band);
-  if (g > 0x7fffffffLL)
-    return MIBAYER_ERR_GEOMETRY;
-  grid = (unsigned) g;
+  p.map = make_tile_map (g.tiles_x, g.tiles_y, g.tile_rows, g.band, c->xcd_rot);
+  if (geom)
+    *geom = g;
   return MIBAYER_OK;
 }
 
@@ -276,8 +289,6 @@ static int launch (const mibayer_ctx *c, const void *d_src,
     q.dst_stride = f.dst_stride;
     q.out_dwords = ((f.width + 3) & ~3) / 4;
     q.total_rows = (long long) nframes * f.height;
-    q.tiles_x = 0;
-    q.tile_rows = 0;
     q.band = c->band_override != INT32_MIN ? c->band_override : 0;
     for (int k = 0; k < 2; k++) {
       q.sel_lo[k] = c->r2b_lo[k];
@@ -351,9 +362,15 @@ extern "C" const char *mibayer_variant_name (int v)
 extern "C" int64_t mibayer_block_to_tile (int64_t block, int tiles_x,
     int64_t tile_rows, int band)
 {
-  if (block < 0 || tiles_x <= 0 || tile_rows <= 0)
+  if (block < 0 || block > 0x7fffffffLL || tiles_x <= 0 || tile_rows <= 0
+      || tile_rows * tiles_x > 0x7fffffffLL)
     return -1;
-  return block_to_tile (block, tiles_x, tile_rows, band);
+  /* the very function the kernels run */
+  const TileMap m = make_tile_map (tiles_x, 1, tile_rows, band, 0);
+  const TileId t = block_to_tile ((uint32_t) block, m);
+  if (band <= 0 && block >= tile_rows * tiles_x)
+    return -1;
+  return t.valid ? (int64_t) t.row * tiles_x + t.tx : -1;
 }
 
 /* ---- context -------------------------------------------------------------------- */
@@ -576,10 +593,11 @@ extern "C" int mibayer_launch_geometry (const mibayer_ctx *c, int nframes,
   KParams p;
   KernelFn kern;
   unsigned grid = 0;
+  Geometry g;
   /* aligned dummy pointers: report the plan of the 16-byte fast path when the
    * geometry allows it */
   int rc = plan_launch (c, (const void *) 256, c->src_bytes, (void *) 256,
-      c->dst_bytes, nframes > 0 ? nframes : 1, p, kern, grid);
+      c->dst_bytes, nframes > 0 ? nframes : 1, p, kern, grid, &g);
   if (rc != MIBAYER_OK)
     return rc;
   if (nframes == 0)
@@ -589,11 +607,11 @@ extern "C" int mibayer_launch_geometry (const mibayer_ctx *c, int nframes,
   if (tile_h)
     *tile_h = c->var->tile_h;
   if (tiles_x)
-    *tiles_x = p.tiles_x;
+    *tiles_x = g.tiles_x;
   if (tile_rows)
-    *tile_rows = nframes > 0 ? p.tile_rows : 0;
+    *tile_rows = nframes > 0 ? g.tile_rows : 0;
   if (band)
-    *band = p.band;
+    *band = g.band;
   if (grid_blocks)
     *grid_blocks = grid;
   return MIBAYER_OK;

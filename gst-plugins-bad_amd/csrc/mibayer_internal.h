@@ -10,6 +10,114 @@ namespace mibayer {
 
 constexpr int kNumXcd = 8;      /* MI355X: 8 XCDs, block b is dispatched to XCD b % 8 */
 
+/* Unsigned 32-bit division by a launch-time constant without a divide
+ * (Granlund & Montgomery): 3 scalar instructions instead of the ~100-instruction
+ * 64-bit division sequence the compiler emits for `a / b` with runtime b. */
+struct FastDiv {
+  uint32_t d;                   /* the divisor          */
+  uint32_t mul;                 /* magic multiplier     */
+  uint32_t sh1, sh2;            /* post-shifts          */
+};
+
+inline FastDiv make_fastdiv (uint32_t d)
+{
+  FastDiv f;
+  f.d = d ? d : 1;
+  uint32_t l = 0;               /* ceil (log2 d) */
+  while (l < 32 && (1ull << l) < f.d)
+    l++;
+  f.mul = (uint32_t) ((((1ull << l) - f.d) << 32) / f.d + 1);
+  f.sh1 = l < 1 ? l : 1;
+  f.sh2 = l > 0 ? l - 1 : 0;
+  return f;
+}
+
+__host__ __device__ inline uint32_t fastdiv (uint32_t n, const FastDiv &f)
+{
+  const uint32_t t = (uint32_t) (((unsigned long long) n * f.mul) >> 32);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
+/* XCD-aware block -> tile map, identical on host and device.
+ *
+ * Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8) and
+ * each XCD has a private 4 MiB L2.  With the identity map horizontally adjacent
+ * tiles land on different XCDs, so every tile's left/right halo dword drags a
+ * full 128-byte line of its neighbour through the fabric a second time
+ * (measured: L2->fabric reads = 2.0x the algorithmic bytes for 256-px tiles).
+ *
+ * The band map hands XCD k whole tile rows: tile row R (counted through the
+ * batch, R = frame * tiles_y + ty) belongs to XCD (R / band) % 8, and an XCD
+ * walks its rows left to right.  band = ceil (tile_rows / 8) gives every XCD one
+ * contiguous chunk of the batch; band = 0 selects the identity map.
+ * Everything is 32-bit (grids are < 2^31 blocks) and division-free. */
+struct TileMap {
+  FastDiv tiles_x;              /* tiles per tile row                           */
+  FastDiv tiles_y;              /* tile rows per frame                          */
+  FastDiv per_group;            /* band * tiles_x                               */
+  uint32_t tile_rows;           /* nframes * tiles_y                            */
+  int band;                     /* tile rows per XCD band; 0 = identity map     */
+  int rot;                      /* tuning: XCD k takes the bands of XCD (k+rot)%8 */
+};
+
+struct TileId {
+  uint32_t row;                 /* tile row in the batch */
+  uint32_t tx;
+  bool valid;
+};
+
+__host__ __device__ inline TileId block_to_tile (uint32_t block, const TileMap &m)
+{
+  TileId t;
+  if (m.band <= 0) {
+    t.row = fastdiv (block, m.tiles_x);
+    t.tx = block - t.row * m.tiles_x.d;
+  } else {
+    const uint32_t xcd = (block + (uint32_t) m.rot) & (kNumXcd - 1);
+    const uint32_t i = block / kNumXcd;         /* i-th block of this XCD */
+    const uint32_t group = fastdiv (i, m.per_group);
+    const uint32_t in_group = i - group * m.per_group.d;
+    const uint32_t r_local = fastdiv (in_group, m.tiles_x);
+    t.tx = in_group - r_local * m.tiles_x.d;
+    t.row = (group * kNumXcd + xcd) * (uint32_t) m.band + r_local;
+  }
+  t.valid = t.row < m.tile_rows;
+  return t;
+}
+
+/* linear tile index (row * tiles_x + tx) -> TileId, for the persistent arm */
+__host__ __device__ inline TileId linear_to_tile (uint32_t tile, const TileMap &m)
+{
+  TileId t;
+  t.row = fastdiv (tile, m.tiles_x);
+  t.tx = tile - t.row * m.tiles_x.d;
+  t.valid = t.row < m.tile_rows;
+  return t;
+}
+
+inline long long grid_blocks_for (int tiles_x, long long tile_rows, int band)
+{
+  if (band <= 0)
+    return tile_rows * tiles_x;
+  const long long group_rows = (long long) kNumXcd * band;
+  const long long groups = (tile_rows + group_rows - 1) / group_rows;
+  return groups * group_rows * tiles_x;
+}
+
+inline TileMap make_tile_map (int tiles_x, int tiles_y, long long tile_rows,
+    int band, int rot)
+{
+  TileMap m;
+  m.tiles_x = make_fastdiv ((uint32_t) tiles_x);
+  m.tiles_y = make_fastdiv ((uint32_t) tiles_y);
+  m.per_group = make_fastdiv ((uint32_t) (band > 0 ? band : 1)
+      * (uint32_t) tiles_x);
+  m.tile_rows = (uint32_t) tile_rows;
+  m.band = band;
+  m.rot = rot;
+  return m;
+}
+
 /* Kernel arguments (passed by value -> SGPRs). */
 struct KParams {
   const uint8_t *src;
@@ -22,56 +130,10 @@ struct KParams {
   int dst_stride;
   int wlimit4;                  /* ROUND_UP_4(width): last readable column + 1 */
   int dn_last;                  /* source row standing in for row `height`     */
-  int tiles_x;
-  int tiles_y;
-  long long tile_rows;          /* nframes * tiles_y                            */
-  int band;                     /* tile rows per XCD band; 0 = identity map     */
-  int xcd_rot;                  /* tuning: XCD k takes the bands of XCD (k+rot)%8 */
+  TileMap map;
   uint32_t sel[4];              /* v_perm_b32 selectors of output pixel 0..3   */
   int swap_rows;                /* 1 for grbg / gbrg                           */
 };
-
-/* XCD-aware block -> tile map, identical on host and device.
- *
- * Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8) and
- * each XCD has a private 4 MiB L2.  With the identity map horizontally adjacent
- * tiles land on different XCDs, so every tile's left/right halo dword drags a
- * full 128-byte line of its neighbour through the fabric a second time
- * (measured: L2->fabric reads = 2.0x the algorithmic bytes for 256-px tiles).
- *
- * The band map hands XCD k whole tile rows: tile row R (counted through the
- * batch, R = frame * tiles_y + ty) belongs to XCD (R / band) % 8, and an XCD
- * walks its rows left to right.  Horizontal neighbours (and, inside a band,
- * vertical neighbours) then share an L2, while all 8 XCDs still work within
- * 8*band consecutive tile rows of the same frame, which keeps the DRAM write
- * stream compact.  band = 0 selects the identity map. */
-__host__ __device__ inline long long
-block_to_tile (long long block, int tiles_x, long long tile_rows, int band,
-    int rot = 0)
-{
-  if (band <= 0) {
-    return block < tile_rows * tiles_x ? block : -1;
-  }
-  const long long xcd = (block + rot) % kNumXcd;
-  const long long i = block / kNumXcd;          /* i-th block of this XCD */
-  const long long per_group = (long long) band * tiles_x;
-  const long long group = i / per_group;
-  const long long in_group = i - group * per_group;
-  const long long r_local = in_group / tiles_x;
-  const long long tx = in_group - r_local * tiles_x;
-  const long long row = (group * kNumXcd + xcd) * band + r_local;
-  return row < tile_rows ? row * tiles_x + tx : -1;
-}
-
-__host__ __device__ inline long long
-grid_blocks_for (int tiles_x, long long tile_rows, int band)
-{
-  if (band <= 0)
-    return tile_rows * tiles_x;
-  const long long group_rows = (long long) kNumXcd * band;
-  const long long groups = (tile_rows + group_rows - 1) / group_rows;
-  return groups * group_rows * tiles_x;
-}
 
 struct Variant {
   const char *name;
@@ -102,9 +164,9 @@ struct R2BParams {
   int dst_stride;
   int out_dwords;               /* ROUND_UP_4(width) / 4 */
   long long total_rows;         /* nframes * height */
-  int tiles_x;                  /* filled by launch_rgb2bayer: 1024-px column strips */
-  long long tile_rows;          /*                            groups of R2B_ROWS rows */
   int band;                     /* XCD band map (see block_to_tile); -1 = one chunk per XCD */
+  TileMap map;                  /* filled by launch_rgb2bayer: tiles = R rows x 1024 px */
+  FastDiv div_height;
   uint32_t sel_lo[2];           /* v_perm selectors per row parity: pixels 0,1 */
   uint32_t sel_hi[2];           /*                                  pixels 2,3 */
 };

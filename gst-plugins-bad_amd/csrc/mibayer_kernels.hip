@@ -247,17 +247,14 @@ bayer2rgb_lds_kernel (KParams p)
 
   __shared__ __attribute__ ((aligned (16))) uint8_t lds[NROWS * PITCH];
 
-  const long long tile = block_to_tile (blockIdx.x, p.tiles_x, p.tile_rows,
-      p.band, p.xcd_rot);
-  if (tile < 0)
+  const TileId tile = block_to_tile (blockIdx.x, p.map);
+  if (!tile.valid)
     return;
-  const int tx = (int) (tile % p.tiles_x);
-  const long long trest = tile / p.tiles_x;
-  const int ty = (int) (trest % p.tiles_y);
-  const long long frame = trest / p.tiles_y;
+  const uint32_t frame = fastdiv (tile.row, p.map.tiles_y);
+  const int ty = (int) (tile.row - frame * p.map.tiles_y.d);
   const uint8_t *src = p.src + frame * p.src_frame_bytes;
   uint8_t *dst = p.dst + frame * p.dst_frame_bytes;
-  const int tile_x = tx * TW;
+  const int tile_x = (int) tile.tx * TW;
   const int tile_y = ty * TR;
   const int tid = threadIdx.x;
 
@@ -395,14 +392,12 @@ bayer2rgb_direct_kernel (KParams p)
   constexpr int TR = WY * RPW;
   static_assert (RPW % 2 == 0, "row parity is derived from the in-tile row");
 
-  const long long tile = block_to_tile (blockIdx.x, p.tiles_x, p.tile_rows,
-      p.band, p.xcd_rot);
-  if (tile < 0)
+  const TileId tile = block_to_tile (blockIdx.x, p.map);
+  if (!tile.valid)
     return;
-  const int tx = (int) (tile % p.tiles_x);
-  const long long trest = tile / p.tiles_x;
-  const int ty = (int) (trest % p.tiles_y);
-  const long long frame = trest / p.tiles_y;
+  const uint32_t frame = fastdiv (tile.row, p.map.tiles_y);
+  const int ty = (int) (tile.row - frame * p.map.tiles_y.d);
+  const int tx = (int) tile.tx;
   const uint8_t *src = p.src + frame * p.src_frame_bytes;
   uint8_t *dst = p.dst + frame * p.dst_frame_bytes;
   const int tid = threadIdx.x;
@@ -490,16 +485,16 @@ bayer2rgb_persist_kernel (KParams p)
 
   __shared__ __attribute__ ((aligned (16))) uint8_t lds[2][NROWS * PITCH];
 
-  /* this workgroup's tile sequence: first, first+step, ... < end */
-  const long long ntiles = p.tile_rows * p.tiles_x;
-  long long first, step, end;
-  if (p.band <= 0) {
+  /* this workgroup's tile sequence: first, first+step, ... < end (linear tile ids) */
+  const uint32_t ntiles = p.map.tile_rows * p.map.tiles_x.d;
+  uint32_t first, step, end;
+  if (p.map.band <= 0) {
     first = blockIdx.x;
     step = gridDim.x;
     end = ntiles;
   } else {                      /* one contiguous chunk of tile rows per XCD */
-    const long long xcd = blockIdx.x % kNumXcd;
-    const long long chunk = (long long) p.band * p.tiles_x;
+    const uint32_t xcd = blockIdx.x % kNumXcd;
+    const uint32_t chunk = (uint32_t) p.map.band * p.map.tiles_x.d;
     first = xcd * chunk + blockIdx.x / kNumXcd;
     step = gridDim.x / kNumXcd;
     end = (xcd + 1) * chunk < ntiles ? (xcd + 1) * chunk : ntiles;
@@ -519,11 +514,11 @@ bayer2rgb_persist_kernel (KParams p)
   const int r0 = wy * RPW;
 
   struct Tile { const uint8_t *src; uint8_t *dst; int tile_x, tile_y; };
-  auto decode = [&](long long tile) -> Tile {
-    const int tx = (int) (tile % p.tiles_x);
-    const long long trest = tile / p.tiles_x;
-    const int ty = (int) (trest % p.tiles_y);
-    const long long frame = trest / p.tiles_y;
+  auto decode = [&](uint32_t tile) -> Tile {
+    const TileId id = linear_to_tile (tile, p.map);
+    const uint32_t frame = fastdiv (id.row, p.map.tiles_y);
+    const int ty = (int) (id.row - frame * p.map.tiles_y.d);
+    const int tx = (int) id.tx;
     Tile t;
     t.src = p.src + frame * p.src_frame_bytes;
     t.dst = p.dst + frame * p.dst_frame_bytes;
@@ -602,8 +597,8 @@ bayer2rgb_persist_kernel (KParams p)
   commit (lds[0]);
   __syncthreads ();
   int b = 0;
-  for (long long t = first; t < end; t += step) {
-    const long long nxt = t + step;
+  for (uint32_t t = first; t < end; t += step) {
+    const uint32_t nxt = t + step;
     const bool has_next = nxt < end;
     Tile next_tile = cur_tile;
     if (has_next) {
@@ -706,24 +701,29 @@ rgb2bayer_kernel (R2BParams p)
 {
   /* same XCD-aware block -> tile map as the demosaic kernel: a "tile" is
    * R2B_ROWS rows x 1024 pixels, tile rows run through the whole batch */
-  const long long tile = block_to_tile (blockIdx.x, p.tiles_x, p.tile_rows,
-      p.band);
-  if (tile < 0)
+  const TileId tile = block_to_tile (blockIdx.x, p.map);
+  if (!tile.valid)
     return;
-  const long long trow = tile / p.tiles_x;
-  const int xd = (int) (tile - trow * p.tiles_x) * 256 + threadIdx.x;   /* output dword in the row */
+  const int xd = (int) tile.tx * 256 + threadIdx.x;     /* output dword in the row */
   if (xd >= p.out_dwords)
     return;
-  const long long row0 = trow * R2B_ROWS;
+  const long long row0 = (long long) tile.row * R2B_ROWS;
   const int x0 = xd * 4;
+  /* (frame, y) of row0; later rows only increment */
+  const uint32_t f0 = fastdiv ((uint32_t) row0, p.div_height);
+  const int y0 = (int) ((uint32_t) row0 - f0 * p.div_height.d);
   u32x4 px[R2B_ROWS];
 #pragma unroll
   for (int k = 0; k < R2B_ROWS; k++) {
     const long long row = row0 + k;
     px[k] = (u32x4) (0u);
     if (row < p.total_rows) {
-      const long long f = row / p.height;
-      const int y = (int) (row - f * p.height);
+      int y = y0 + k;
+      uint32_t f = f0;
+      while (y >= p.height) {
+        y -= p.height;
+        f++;
+      }
       const uint8_t *s = p.src + f * p.src_frame_bytes
           + (size_t) y * p.src_stride + (size_t) x0 * 4;
       if constexpr (VEC16) {
@@ -744,8 +744,12 @@ rgb2bayer_kernel (R2BParams p)
   for (int k = 0; k < R2B_ROWS; k++) {
     const long long row = row0 + k;
     if (row < p.total_rows) {
-      const long long f = row / p.height;
-      const int y = (int) (row - f * p.height);
+      int y = y0 + k;
+      uint32_t f = f0;
+      while (y >= p.height) {
+        y -= p.height;
+        f++;
+      }
       const int par = y & 1;
       const uint32_t lo = __builtin_amdgcn_perm (px[k].y, px[k].x, p.sel_lo[par]);
       const uint32_t hi = __builtin_amdgcn_perm (px[k].w, px[k].z, p.sel_hi[par]);
@@ -770,13 +774,15 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream)
     return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 2;
   } ();
   const int R2B_ROWS = rows_per_block;
-  q.tile_rows = (p.total_rows + R2B_ROWS - 1) / R2B_ROWS;
-  q.tiles_x = (p.out_dwords + 255) / 256;
+  const long long tile_rows = (p.total_rows + R2B_ROWS - 1) / R2B_ROWS;
+  const int tiles_x = (p.out_dwords + 255) / 256;
   if (q.band < 0)               /* one contiguous chunk of tile rows per XCD */
-    q.band = (int) ((q.tile_rows + kNumXcd - 1) / kNumXcd);
-  const long long grid = grid_blocks_for (q.tiles_x, q.tile_rows, q.band);
-  if (grid > 0x7fffffffLL)
+    q.band = (int) ((tile_rows + kNumXcd - 1) / kNumXcd);
+  const long long grid = grid_blocks_for (tiles_x, tile_rows, q.band);
+  if (grid > 0x7fffffffLL || p.total_rows > 0x7fffffffLL)
     return hipErrorInvalidValue;
+  q.map = make_tile_map (tiles_x, 1, tile_rows, q.band, 0);
+  q.div_height = make_fastdiv ((uint32_t) p.height);
 #define R2B_LAUNCH(V, R) hipLaunchKernelGGL ((rgb2bayer_kernel<V, R>), \
       dim3 ((unsigned) grid), dim3 (256), 0, stream, q)
   switch (R2B_ROWS * 2 + (vec16 ? 1 : 0)) {
