@@ -436,3 +436,52 @@ def test_guard_bands_around_the_destination_stay_intact(gpu_pkg, oracle):
             body = out[guard:-guard].reshape(h, dstride)
             assert np.array_equal(body[:, :4 * w], want), (w, h, names[v])
             assert (body[:, 4 * w:] == 0xC3).all(), (w, h, names[v])
+
+
+GRAPH_SCRIPT = r"""
+import sys
+import numpy as np
+import torch                      # first: the process then runs on torch's bundled HIP runtime (as bench.py does)
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as entry
+pkg, oracle = entry.load_package(), entry.load_oracle()
+w, h, n = 1280, 720, 4
+src = oracle.fill_synthetic(w, h, n, seed=81)
+want = oracle.bayer2rgb_batch(src, w, "rggb", 2, 1, 0, nthreads=2)
+d_src = torch.from_numpy(src.reshape(-1)).cuda()
+d_dst = torch.zeros(n * h * 4 * w, dtype=torch.uint8, device="cuda")
+with pkg.Context(w, h, "rggb", "BGRx", device=0) as ctx:
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        ctx.process_device(d_src.data_ptr(), d_dst.data_ptr(), n, stream=side.cuda_stream)      # warm-up
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            for f in range(n):                   # four single-frame launches inside one graph
+                ctx.process_device(d_src.data_ptr() + f * ctx.src_bytes, d_dst.data_ptr() + f * ctx.dst_bytes, 1,
+                                   stream=side.cuda_stream)
+    d_dst.zero_()
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(d_dst.cpu().numpy().reshape(want.shape), want), "first replay"
+    src2 = oracle.fill_synthetic(w, h, n, seed=82)             # new input, same graph
+    d_src.copy_(torch.from_numpy(src2.reshape(-1)))
+    graph.replay()
+    torch.cuda.synchronize()
+    want2 = oracle.bayer2rgb_batch(src2, w, "rggb", 2, 1, 0, nthreads=2)
+    assert np.array_equal(d_dst.cpu().numpy().reshape(want2.shape), want2), "second replay"
+print("graph replay ok")
+"""
+
+
+def test_device_launch_can_be_captured_in_a_hipgraph(gpu_pkg):
+    """mibayer_process_device only enqueues a kernel on the caller's stream, so a caller may capture it in a
+    hipGraph (here through torch.cuda.graph) and replay it: BASELINE.json configs[4] "hipGraph-captured launch"
+    for device-resident consumers.  Runs in its own process with torch imported first, the way bench.py runs
+    (one HIP runtime per process: whichever of torch's bundled libamdhip64 / the system one is loaded first)."""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, "-c", GRAPH_SCRIPT, ROOT], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-2000:]
+    assert "graph replay ok" in res.stdout
