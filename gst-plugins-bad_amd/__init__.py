@@ -22,7 +22,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libmibayer.so")
+LIB_PATH = os.environ.get("MIBAYER_LIB_PATH") or os.path.join(HERE, "libmibayer.so")   # override: A/B of two builds
 PLUGIN_PATH = os.path.join(HERE, "libgstbayer.so")
 HEADER_PATH = os.path.join(ROOT, "include", "mibayer.h")
 
@@ -126,6 +126,7 @@ ABI = {
                                               ctypes.c_int, ctypes.c_uint32, _vp]),
     "mibayer_variant_count": (ctypes.c_int, []),
     "mibayer_variant_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "mibayer_auto_variant": (ctypes.c_int, [ctypes.c_int]),
     "mibayer_ctx_variant_name": (ctypes.c_char_p, [_vp]),
     "mibayer_plan_selectors": (ctypes.c_int, [ctypes.POINTER(Cfg), ctypes.POINTER(ctypes.c_uint32 * 4),
                                               ctypes.POINTER(ctypes.c_int)]),

@@ -110,6 +110,12 @@ struct mibayer_ctx {
   int xcd_rot = 0;                      /* MIBAYER_XCD_ROT (tuning) */
   int num_cus = 256;                    /* hipDeviceProp_t.multiProcessorCount */
   int persist_wgs_per_cu = 4;           /* MIBAYER_PERSIST_WGS (tuning), persistent arms */
+  int dyn_lds = 0;                      /* MIBAYER_DYN_LDS (tuning): extra LDS bytes per
+                                           workgroup, only to lower the occupancy */
+  int start_sleep = -1;                 /* s_sleep(1) iterations before a workgroup's first load;
+                                           -1 = automatic (kStartSleepChunk with a band map on
+                                           large grids, else 0); MIBAYER_START_SLEEP overrides */
+  int start_stagger = 0;                /* MIBAYER_START_STAGGER (tuning) */
   /* streams: uploads, kernels and downloads each get their own queue so that
    * frame n+1's H2D overlaps frame n's kernel and frame n-1's D2H */
   hipStream_t s_h2d = nullptr;
@@ -226,9 +232,13 @@ static void fill_params (const mibayer_ctx *c, KParams &p, Geometry &g,
   for (int k = 0; k < 4; k++)
     p.sel[k] = c->sel[k];
   p.swap_rows = c->swap_rows;
+  p.start_sleep = c->start_sleep > 0 ? c->start_sleep : 0;      /* auto: plan_launch */
+  p.start_stagger = c->start_stagger;
 }
 
 typedef void (*KernelFn) (KParams);
+
+constexpr int kStartSleepChunk = 24;    /* x s_sleep(1) = 64 clocks each */
 
 /* everything a launch needs: arguments, kernel (16-byte fast path or generic),
  * grid size */
@@ -265,6 +275,15 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
     grid = (unsigned) n;
   }
   p.map = make_tile_map (g.tiles_x, g.tiles_y, g.tile_rows, g.band, c->xcd_rot);
+  /* Start delay (DESIGN.md "start delay"): with a band map every workgroup
+   * sleeps ~1.5k cycles before its first load.  Measured +3..5 points of HBM
+   * peak on every box for the chunk-per-XCD order (it thins the number of
+   * requests in flight; halving the occupancy instead costs 10 points), nothing
+   * for the identity order, and pure latency for launches that do not even fill
+   * the machine once -- so only grids of more than 4 workgroups per CU slot get it. */
+  if (c->start_sleep < 0)
+    p.start_sleep = (g.band > 0 && !c->var->persistent
+        && (long long) grid > 16LL * c->num_cus) ? kStartSleepChunk : 0;
   if (geom)
     *geom = g;
   return MIBAYER_OK;
@@ -306,7 +325,8 @@ static int launch (const mibayer_ctx *c, const void *d_src,
       nframes, p, kern, grid);
   if (rc != MIBAYER_OK)
     return rc;
-  hipLaunchKernelGGL (kern, dim3 (grid), dim3 (c->var->threads), 0, stream, p);
+  hipLaunchKernelGGL (kern, dim3 (grid), dim3 (c->var->threads),
+      (size_t) c->dyn_lds, stream, p);
   HIP_TRY (hipGetLastError ());
   return MIBAYER_OK;
 }
@@ -468,6 +488,12 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
     c->band_override = atoi (e);
   if (const char *e = getenv ("MIBAYER_XCD_ROT"))
     c->xcd_rot = atoi (e) & 7;
+  if (const char *e = getenv ("MIBAYER_DYN_LDS"))
+    c->dyn_lds = atoi (e) > 0 ? atoi (e) : 0;
+  if (const char *e = getenv ("MIBAYER_START_SLEEP"))
+    c->start_sleep = atoi (e) >= 0 ? atoi (e) : -1;
+  if (const char *e = getenv ("MIBAYER_START_STAGGER"))
+    c->start_stagger = atoi (e) > 0 ? atoi (e) : 0;
   if (const char *e = getenv ("MIBAYER_PERSIST_WGS"))
     c->persist_wgs_per_cu = atoi (e) > 0 ? atoi (e) : 4;
   {
@@ -569,6 +595,11 @@ extern "C" int mibayer_plan_selectors (const mibayer_cfg *cfg, uint32_t sel[4],
     return MIBAYER_ERR_ARG;
   plan_selectors (f, sel, *swap_rows);
   return MIBAYER_OK;
+}
+
+extern "C" int mibayer_auto_variant (int width)
+{
+  return resolve_variant (0, width);
 }
 
 extern "C" const char *mibayer_ctx_variant_name (const mibayer_ctx *c)
@@ -975,12 +1006,12 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
 
-  /* candidate tile shapes: the configured one, plus the 256-wide production
-   * shape when "auto" picked a wider one */
+  /* candidate tile shapes: the configured one and, under "auto", one other
+   * production shape (256x32, or 1024x8 when 256x32 is the configured one) */
   const Variant *shapes[2] = { c->var, nullptr };
   int nshapes = 1;
-  if (c->cfg.variant == 0 && c->var != &variant (3))
-    shapes[nshapes++] = &variant (3);
+  if (c->cfg.variant == 0)
+    shapes[nshapes++] = (c->var != &variant (3)) ? &variant (3) : &variant (1);
   const bool band_forced = getenv ("MIBAYER_XCD_BAND") != NULL;
   const int bands[2] = { -1, 0 };       /* one chunk per XCD | identity map */
   const int nbands = band_forced ? 1 : 2;

@@ -131,6 +131,8 @@ struct KParams {
   int wlimit4;                  /* ROUND_UP_4(width): last readable column + 1 */
   int dn_last;                  /* source row standing in for row `height`     */
   TileMap map;
+  int start_sleep;              /* tuning: s_sleep(1) iterations before the first load */
+  int start_stagger;            /* tuning: + this many per ((block/8) & 3)             */
   uint32_t sel[4];              /* v_perm_b32 selectors of output pixel 0..3   */
   int swap_rows;                /* 1 for grbg / gbrg                           */
 };

@@ -250,6 +250,12 @@ bayer2rgb_lds_kernel (KParams p)
   const TileId tile = block_to_tile (blockIdx.x, p.map);
   if (!tile.valid)
     return;
+  {                             /* tuning knobs, see DESIGN.md "start delay" */
+    const int nsleep = p.start_sleep
+        + p.start_stagger * (int) ((blockIdx.x / kNumXcd) & 3u);
+    for (int z = 0; z < nsleep; z++)
+      __builtin_amdgcn_s_sleep (1);
+  }
   const uint32_t frame = fastdiv (tile.row, p.map.tiles_y);
   const int ty = (int) (tile.row - frame * p.map.tiles_y.d);
   const uint8_t *src = p.src + frame * p.src_frame_bytes;
@@ -672,18 +678,26 @@ const Variant &variant (int id)
   return kVariants[id];
 }
 
-/* variant 0: the widest tile that the frame width still fills.  All three
- * shapes run within 1 % of each other on 4K / 8K; on widths that are not a
- * multiple of the tile the wider tile wastes fewer partial waves per row. */
+/* variant 0: the production shape (1024x8, 512x16 or 256x32 px) that wastes the
+ * fewest lanes on the frame width -- a 640-px row fills 83 % of three 256-px
+ * tiles but only 62 % of one 1024-px tile (measured 78 % vs 59 % of HBM peak) --
+ * and, among equals, the widest (fewest halo columns). */
 int resolve_variant (int id, int width)
 {
   if (id != 0)
     return id;
-  if (width > 512)
-    return 1;                   /* 1024 x 8  */
-  if (width > 256)
-    return 2;                   /* 512 x 16  */
-  return 3;                     /* 256 x 32  */
+  static const int tile_w[3] = { 1024, 512, 256 };      /* variants 1, 2, 3 */
+  int best = 1;
+  long long best_padded = 0;
+  for (int i = 0; i < 3; i++) {
+    const long long padded = (long long) ((width + tile_w[i] - 1) / tile_w[i])
+        * tile_w[i];
+    if (i == 0 || padded < best_padded) {
+      best = i + 1;
+      best_padded = padded;
+    }
+  }
+  return best;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -194,7 +194,8 @@ int mibayer_time_device (mibayer_ctx *ctx, const void *d_src,
 
 /* Measured launch-plan selection for the device-resident path.  MI355X boxes
  * differ in which block->tile order streams best (DESIGN.md "XCD map"): this
- * call times the candidate plans (tile shape x XCD band map) on the caller's
+ * call times the candidate plans (two tile shapes x {one chunk per XCD with a
+ * start delay, identity order}) on the caller's
  * own buffers with HIP events on the context's compute stream, a few launches
  * each, and keeps the fastest for every later launch of this context.  The
  * kernel is idempotent, so d_dst holds the correct output afterwards.
@@ -243,6 +244,8 @@ int mibayer_fill_synthetic (mibayer_ctx *ctx, void *d_src,
  * production tile shape chosen from the stream width at mibayer_create(). */
 int mibayer_variant_count (void);
 const char *mibayer_variant_name (int variant);
+/* the variant id "auto" (0) resolves to for a frame width (pure host arithmetic) */
+int mibayer_auto_variant (int width);
 /* name of the concrete variant the context resolved to */
 const char *mibayer_ctx_variant_name (const mibayer_ctx *ctx);
 /* Pure host arithmetic, no device needed: the four v_perm_b32 selectors (output

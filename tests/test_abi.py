@@ -165,3 +165,13 @@ def test_rgb2bayer_cfg_validation(pkg):
     for (r, g, b) in [(1, 1, 3), (4, 2, 3), (-1, 2, 3)]:
         assert create(pkg, make_cfg(pkg, r_off=r, g_off=g, b_off=b, flags=F)) == pkg.ERR_LAYOUT
     assert create(pkg, make_cfg(pkg, r_off=1, g_off=2, b_off=3, flags=F, variant=1)) == pkg.ERR_ARG
+
+
+def test_auto_variant_minimises_wasted_lanes(pkg):
+    """variant 0 picks, per frame width, the production tile width with the least padding (widest on ties)."""
+    names = pkg.variant_names()
+    f = pkg.lib().mibayer_auto_variant
+    want = {3840: "lds_1x8", 7680: "lds_2x4", 1920: "lds_4x2", 640: "lds_1x8", 1280: "lds_1x8", 300: "lds_2x4",
+            200: "lds_1x8", 4: "lds_1x8", 1024: "lds_4x2", 1026: "lds_1x8", 2048: "lds_4x2", 512: "lds_2x4"}
+    for w, prefix in want.items():
+        assert names[f(w)].startswith(prefix), (w, names[f(w)])

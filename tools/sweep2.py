@@ -18,8 +18,9 @@ names = pkg.variant_names()
 arms = []
 for spec in sys.argv[5:]:
     name, _, rest = spec.partition(":")
-    band, _, rot = rest.partition(":")
-    for key, val in (("MIBAYER_XCD_BAND", band), ("MIBAYER_XCD_ROT", rot)):
+    parts = (rest.split(":") + ["", "", "", "", ""])[:5]       # band : rot : dyn_lds : start_sleep : stagger
+    for key, val in zip(("MIBAYER_XCD_BAND", "MIBAYER_XCD_ROT", "MIBAYER_DYN_LDS", "MIBAYER_START_SLEEP",
+                         "MIBAYER_START_STAGGER"), parts):
         if val:
             os.environ[key] = val
         else:
@@ -27,7 +28,8 @@ for spec in sys.argv[5:]:
     ctx = pkg.Context(W, H, "rggb", "BGRx", variant=names.index(name))
     arms.append((spec, ctx, []))
 os.environ.pop("MIBAYER_XCD_BAND", None)
-os.environ.pop("MIBAYER_XCD_ROT", None)
+for key in ("MIBAYER_XCD_ROT", "MIBAYER_DYN_LDS", "MIBAYER_START_SLEEP", "MIBAYER_START_STAGGER"):
+    os.environ.pop(key, None)
 c0 = arms[0][1]
 d_src = c0.device_alloc(N * c0.src_bytes)
 d_dst = c0.device_alloc(N * c0.dst_bytes)
