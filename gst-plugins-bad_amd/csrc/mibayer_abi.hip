@@ -116,6 +116,7 @@ struct mibayer_ctx {
                                            -1 = automatic (kStartSleepChunk with a band map on
                                            large grids, else 0); MIBAYER_START_SLEEP overrides */
   int start_stagger = 0;                /* MIBAYER_START_STAGGER (tuning) */
+  int sleep_pos = 0;                    /* MIBAYER_SLEEP_POS (tuning) */
   /* streams: uploads, kernels and downloads each get their own queue so that
    * frame n+1's H2D overlaps frame n's kernel and frame n-1's D2H */
   hipStream_t s_h2d = nullptr;
@@ -234,6 +235,7 @@ static void fill_params (const mibayer_ctx *c, KParams &p, Geometry &g,
   p.swap_rows = c->swap_rows;
   p.start_sleep = c->start_sleep > 0 ? c->start_sleep : 0;      /* auto: plan_launch */
   p.start_stagger = c->start_stagger;
+  p.sleep_pos = c->sleep_pos;
 }
 
 typedef void (*KernelFn) (KParams);
@@ -492,6 +494,8 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
     c->dyn_lds = atoi (e) > 0 ? atoi (e) : 0;
   if (const char *e = getenv ("MIBAYER_START_SLEEP"))
     c->start_sleep = atoi (e) >= 0 ? atoi (e) : -1;
+  if (const char *e = getenv ("MIBAYER_SLEEP_POS"))
+    c->sleep_pos = atoi (e);
   if (const char *e = getenv ("MIBAYER_START_STAGGER"))
     c->start_stagger = atoi (e) > 0 ? atoi (e) : 0;
   if (const char *e = getenv ("MIBAYER_PERSIST_WGS"))

@@ -133,6 +133,8 @@ struct KParams {
   TileMap map;
   int start_sleep;              /* tuning: s_sleep(1) iterations before the first load */
   int start_stagger;            /* tuning: + this many per ((block/8) & 3)             */
+  int sleep_pos;                /* tuning: 0 before the loads (default), 1 after the barrier,
+                                   2 after the stores */
   uint32_t sel[4];              /* v_perm_b32 selectors of output pixel 0..3   */
   int swap_rows;                /* 1 for grbg / gbrg                           */
 };

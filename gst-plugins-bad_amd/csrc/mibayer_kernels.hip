@@ -250,12 +250,15 @@ bayer2rgb_lds_kernel (KParams p)
   const TileId tile = block_to_tile (blockIdx.x, p.map);
   if (!tile.valid)
     return;
-  {                             /* tuning knobs, see DESIGN.md "start delay" */
-    const int nsleep = p.start_sleep
-        + p.start_stagger * (int) ((blockIdx.x / kNumXcd) & 3u);
-    for (int z = 0; z < nsleep; z++)
-      __builtin_amdgcn_s_sleep (1);
-  }
+  /* start delay; stagger / position are tuning knobs */
+  const int nsleep = p.start_sleep
+      + p.start_stagger * (int) ((blockIdx.x / kNumXcd) & 3u);
+  auto nap = [&](int pos) {
+    if (p.sleep_pos == pos)
+      for (int z = 0; z < nsleep; z++)
+        __builtin_amdgcn_s_sleep (1);
+  };
+  nap (0);
   const uint32_t frame = fastdiv (tile.row, p.map.tiles_y);
   const int ty = (int) (tile.row - frame * p.map.tiles_y.d);
   const uint8_t *src = p.src + frame * p.src_frame_bytes;
@@ -329,6 +332,7 @@ bayer2rgb_lds_kernel (KParams p)
     *(uint32_t *) &lds[r * PITCH + (side ? MAIN + TW : MAIN - 4)] = v;
   }
   __syncthreads ();
+  nap (1);
 
   /* ---- per-wave march -------------------------------------------------------- */
   const int wave = tid >> 6;
@@ -383,6 +387,7 @@ bayer2rgb_lds_kernel (KParams p)
     up = cur;
     cur = dn;
   }
+  nap (2);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -18,9 +18,9 @@ names = pkg.variant_names()
 arms = []
 for spec in sys.argv[5:]:
     name, _, rest = spec.partition(":")
-    parts = (rest.split(":") + ["", "", "", "", ""])[:5]       # band : rot : dyn_lds : start_sleep : stagger
+    parts = (rest.split(":") + [""] * 6)[:6]        # band : rot : dyn_lds : start_sleep : stagger : sleep_pos
     for key, val in zip(("MIBAYER_XCD_BAND", "MIBAYER_XCD_ROT", "MIBAYER_DYN_LDS", "MIBAYER_START_SLEEP",
-                         "MIBAYER_START_STAGGER"), parts):
+                         "MIBAYER_START_STAGGER", "MIBAYER_SLEEP_POS"), parts):
         if val:
             os.environ[key] = val
         else:
@@ -28,7 +28,7 @@ for spec in sys.argv[5:]:
     ctx = pkg.Context(W, H, "rggb", "BGRx", variant=names.index(name))
     arms.append((spec, ctx, []))
 os.environ.pop("MIBAYER_XCD_BAND", None)
-for key in ("MIBAYER_XCD_ROT", "MIBAYER_DYN_LDS", "MIBAYER_START_SLEEP", "MIBAYER_START_STAGGER"):
+for key in ("MIBAYER_XCD_ROT", "MIBAYER_DYN_LDS", "MIBAYER_START_SLEEP", "MIBAYER_START_STAGGER", "MIBAYER_SLEEP_POS"):
     os.environ.pop(key, None)
 c0 = arms[0][1]
 d_src = c0.device_alloc(N * c0.src_bytes)
