@@ -326,8 +326,10 @@ def run(args):
         try:
             with open(traffic_file) as f:
                 t = json.load(f)
-            result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
-            result["roofline"]["traffic_source"] = t.get("source")
+            band = ctx0.launch_geometry(BATCH)["band"]
+            plan = "band1" if band == 1 else ("chunk" if band > 1 else "identity")
+            result["roofline"]["traffic"] = t["plans"][plan]["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = "%s; block order of this run: %s" % (t.get("source"), plan)
         except Exception:
             pass
     if rank == 0 and world == 1:

@@ -117,6 +117,7 @@ struct mibayer_ctx {
                                            large grids, else 0); MIBAYER_START_SLEEP overrides */
   int start_stagger = 0;                /* MIBAYER_START_STAGGER (tuning) */
   int sleep_pos = 0;                    /* MIBAYER_SLEEP_POS (tuning) */
+  int xcd_run = 1;                      /* MIBAYER_XCD_RUN (tuning): identity order in runs of k tiles */
   /* streams: uploads, kernels and downloads each get their own queue so that
    * frame n+1's H2D overlaps frame n's kernel and frame n-1's D2H */
   hipStream_t s_h2d = nullptr;
@@ -271,12 +272,14 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
       n = (ntiles + kNumXcd - 1) / kNumXcd * kNumXcd;
     grid = (unsigned) (n > 0 ? n : kNumXcd);
   } else {
-    const long long n = grid_blocks_for (g.tiles_x, g.tile_rows, g.band);
+    const long long n = grid_blocks_for (g.tiles_x, g.tile_rows, g.band,
+        c->xcd_run);
     if (n > 0x7fffffffLL)
       return MIBAYER_ERR_GEOMETRY;
     grid = (unsigned) n;
   }
-  p.map = make_tile_map (g.tiles_x, g.tiles_y, g.tile_rows, g.band, c->xcd_rot);
+  p.map = make_tile_map (g.tiles_x, g.tiles_y, g.tile_rows, g.band, c->xcd_rot,
+      c->var->persistent ? 1 : c->xcd_run);
   /* Start delay (DESIGN.md "start delay"): with a band map every workgroup
    * sleeps ~1.5k cycles before its first load.  Measured +3..5 points of HBM
    * peak on every box for the chunk-per-XCD order (it thins the number of
@@ -494,6 +497,8 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
     c->dyn_lds = atoi (e) > 0 ? atoi (e) : 0;
   if (const char *e = getenv ("MIBAYER_START_SLEEP"))
     c->start_sleep = atoi (e) >= 0 ? atoi (e) : -1;
+  if (const char *e = getenv ("MIBAYER_XCD_RUN"))
+    c->xcd_run = atoi (e) > 1 ? atoi (e) : 1;
   if (const char *e = getenv ("MIBAYER_SLEEP_POS"))
     c->sleep_pos = atoi (e);
   if (const char *e = getenv ("MIBAYER_START_STAGGER"))
@@ -1010,15 +1015,16 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
 
-  /* candidate tile shapes: the configured one and, under "auto", one other
-   * production shape (256x32, or 1024x8 when 256x32 is the configured one) */
+  /* candidate plans: {configured shape, one other production shape under
+   * "auto"} x {band 1, one chunk per XCD, identity}; the band orders carry the
+   * automatic start delay */
   const Variant *shapes[2] = { c->var, nullptr };
   int nshapes = 1;
   if (c->cfg.variant == 0)
     shapes[nshapes++] = (c->var != &variant (3)) ? &variant (3) : &variant (1);
   const bool band_forced = getenv ("MIBAYER_XCD_BAND") != NULL;
-  const int bands[2] = { -1, 0 };       /* one chunk per XCD | identity map */
-  const int nbands = band_forced ? 1 : 2;
+  const int bands[3] = { 1, -1, 0 };
+  const int nbands = band_forced ? 1 : 3;
 
   const Variant *keep_var = c->var, *best_var = c->var;
   const int keep_band = c->band_override;

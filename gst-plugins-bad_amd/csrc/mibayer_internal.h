@@ -58,6 +58,9 @@ struct TileMap {
   uint32_t tile_rows;           /* nframes * tiles_y                            */
   int band;                     /* tile rows per XCD band; 0 = identity map     */
   int rot;                      /* tuning: XCD k takes the bands of XCD (k+rot)%8 */
+  FastDiv run;                  /* band == 0: consecutive tiles per XCD (1 = plain identity);
+                                   runs of k neighbours share an L2, which cuts the halo
+                                   re-fetch of the identity order from 2x to (1 + 1/k)x */
 };
 
 struct TileId {
@@ -70,8 +73,15 @@ __host__ __device__ inline TileId block_to_tile (uint32_t block, const TileMap &
 {
   TileId t;
   if (m.band <= 0) {
-    t.row = fastdiv (block, m.tiles_x);
-    t.tx = block - t.row * m.tiles_x.d;
+    uint32_t lin = block;
+    if (m.run.d > 1) {          /* XCD x takes tiles [ (r*8+x)*k, +k ) for r = 0, 1, ... */
+      const uint32_t xcd = block & (kNumXcd - 1);
+      const uint32_t i = block / kNumXcd;
+      const uint32_t r = fastdiv (i, m.run);
+      lin = (r * kNumXcd + xcd) * m.run.d + (i - r * m.run.d);
+    }
+    t.row = fastdiv (lin, m.tiles_x);
+    t.tx = lin - t.row * m.tiles_x.d;
   } else {
     const uint32_t xcd = (block + (uint32_t) m.rot) & (kNumXcd - 1);
     const uint32_t i = block / kNumXcd;         /* i-th block of this XCD */
@@ -95,19 +105,26 @@ __host__ __device__ inline TileId linear_to_tile (uint32_t tile, const TileMap &
   return t;
 }
 
-inline long long grid_blocks_for (int tiles_x, long long tile_rows, int band)
+inline long long grid_blocks_for (int tiles_x, long long tile_rows, int band,
+    int run = 1)
 {
-  if (band <= 0)
-    return tile_rows * tiles_x;
+  if (band <= 0) {
+    const long long n = tile_rows * tiles_x;
+    if (run <= 1)
+      return n;
+    const long long per = (long long) kNumXcd * run;
+    return (n + per - 1) / per * per;
+  }
   const long long group_rows = (long long) kNumXcd * band;
   const long long groups = (tile_rows + group_rows - 1) / group_rows;
   return groups * group_rows * tiles_x;
 }
 
 inline TileMap make_tile_map (int tiles_x, int tiles_y, long long tile_rows,
-    int band, int rot)
+    int band, int rot, int run = 1)
 {
   TileMap m;
+  m.run = make_fastdiv ((uint32_t) (run > 1 ? run : 1));
   m.tiles_x = make_fastdiv ((uint32_t) tiles_x);
   m.tiles_y = make_fastdiv ((uint32_t) tiles_y);
   m.per_group = make_fastdiv ((uint32_t) (band > 0 ? band : 1)

@@ -633,8 +633,11 @@ bayer2rgb_persist_kernel (KParams p)
   { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1, 1,                   \
     bayer2rgb_persist_kernel<WX, WY, RPW, ST>,                                 \
     bayer2rgb_lds_kernel<WX, WY, RPW, 0, ST, true, true> }
+/* default block order per shape (measured on a dozen boxes, DESIGN.md "XCD map"):
+ * 1024-px tiles -> band 1 (an XCD takes one full-width tile row at a time), the
+ * only plan at 80-81.5 % of peak on EVERY box; narrower tiles -> identity */
 #define LDS_VARIANT(name, WX, WY, RPW, NEIGH, ST, INTRIN)                      \
-  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1, 0,                   \
+  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), (WX) == 4 ? 1 : 0, 0,    \
     bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, false>,               \
     bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, true> }
 #define DIRECT_VARIANT(name, WX, WY, RPW, ST, INTRIN)                          \
@@ -683,26 +686,26 @@ const Variant &variant (int id)
   return kVariants[id];
 }
 
-/* variant 0: the production shape (1024x8, 512x16 or 256x32 px) that wastes the
- * fewest lanes on the frame width -- a 640-px row fills 83 % of three 256-px
- * tiles but only 62 % of one 1024-px tile (measured 78 % vs 59 % of HBM peak) --
- * and, among equals, the widest (fewest halo columns). */
+/* variant 0: 1024x8 tiles whenever they pad the frame width by no more than 7 %
+ * beyond the best shape (3840 -> 4096 is fine, 640 -> 1024 is not): with the band-1
+ * order they are the robust plan.  Otherwise the production shape that wastes the
+ * fewest lanes -- a 640-px row fills 83 % of three 256-px tiles but 62 % of one
+ * 1024-px tile (78 % vs 59 % of HBM peak measured) -- the widest among equals. */
 int resolve_variant (int id, int width)
 {
   if (id != 0)
     return id;
   static const int tile_w[3] = { 1024, 512, 256 };      /* variants 1, 2, 3 */
-  int best = 1;
-  long long best_padded = 0;
+  long long padded[3];
+  int best = 0;
   for (int i = 0; i < 3; i++) {
-    const long long padded = (long long) ((width + tile_w[i] - 1) / tile_w[i])
-        * tile_w[i];
-    if (i == 0 || padded < best_padded) {
-      best = i + 1;
-      best_padded = padded;
-    }
+    padded[i] = (long long) ((width + tile_w[i] - 1) / tile_w[i]) * tile_w[i];
+    if (padded[i] < padded[best])
+      best = i;
   }
-  return best;
+  if (padded[0] * 100 <= padded[best] * 107)
+    return 1;
+  return best + 1;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -15,8 +15,13 @@ echo "== bench"; timeout 600 python bench.py 2>&1 | tail -1 | tee $O/bench.json
 cd /tmp
 echo "== rocprof stats (same command as the bench line, fewer steps)"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --steps 100 --warmup 10 --no-cpu --no-host-path 2>&1 | grep -v "^W20" | tail -1 | cut -c1-300
+# HBM-side traffic, separate --pmc passes, for the THREE block orders the autotuner chooses between
+# (forced with MIBAYER_XCD_BAND, autotune off), plus the calibration probe
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_bench_$c -o $TAG -- python $R/bench.py --steps 8 --warmup 2 --no-cpu --no-host-path 2>&1 | grep -v "^W20" | tail -1 | cut -c1-120
+  for plan in band1:1 chunk:-1 identity:0; do
+    name=${plan%%:*}; band=${plan##*:}
+    MIBAYER_XCD_BAND=$band timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_bench_${name}_$c -o $TAG -- python $R/bench.py --steps 8 --warmup 2 --no-cpu --no-host-path --no-autotune 2>&1 | grep -v "^W20" | tail -1 | cut -c1-120
+  done
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_probe_$c -o $TAG -- $R/tools/hbm_probe 2 32768 2>&1 | grep -v "^W20" | tail -1
 done
 cd $R; find gpurun_out/$TAG -name "*.csv" | wc -l

@@ -81,52 +81,61 @@ if stats:
                  "profiled runs clock ~2 % lower than unprofiled ones, MI355X_MICROARCH.md \"DVFS\")")
     lines.append("")
 
-fetch_b, write_b = counter_means("pmc_bench_FETCH_SIZE", 8), counter_means("pmc_bench_WRITE_SIZE", 8)
 fetch_p, write_p = counter_means("pmc_probe_FETCH_SIZE"), counter_means("pmc_probe_WRITE_SIZE")
-if fetch_b and write_b:
+plans = {}
+for plan in ("band1", "chunk", "identity"):
+    fb, wb = counter_means("pmc_bench_%s_FETCH_SIZE" % plan, 8), counter_means("pmc_bench_%s_WRITE_SIZE" % plan, 8)
+    if fb and wb:
+        plans[plan] = (fb, wb)
+if plans:
     lines += ["## HBM-side traffic (separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, counters in KiB)", "",
               "Calibration on kernels with known byte counts (tools/hbm_probe.hip, 2 123 366 400 B streams, same passes):", "",
               "| probe kernel | true bytes | counter x 1024 | ratio |", "|---|---:|---:|---:|"]
-    cal_f = cal_w = None
     for needle, true, means, name in (("k_read", 4 * ALG_R, fetch_p, "FETCH_SIZE"),
                                       ("k_mix14<true>", ALG_R, fetch_p, "FETCH_SIZE"),
                                       ("k_fill<true>", 4 * ALG_R, write_p, "WRITE_SIZE"),
                                       ("k_mix14<true>", 4 * ALG_R, write_p, "WRITE_SIZE")):
         k, (m, n) = pick(means, needle)
         if k:
-            ratio = m * 1024 / true
-            lines.append("| `%s` %s | %d | %.0f | %.4f |" % (needle, name, true, m * 1024, ratio))
-            if name == "FETCH_SIZE":
-                cal_f = ratio
-            else:
-                cal_w = ratio
+            lines.append("| `%s` %s | %d | %.0f | %.4f |" % (needle, name, true, m * 1024, m * 1024 / true))
     lines += ["", "=> FETCH_SIZE reports exactly 1/2 of the bytes fetched (16 B/lane and 4 B/lane loads alike; the gfx950 "
-                  "correction of MI355X_MICROARCH.md \"HBM\": double it); WRITE_SIZE is exact.", ""]
-    kf, (mf, nf) = pick(fetch_b, "bayer2rgb")
-    kw, (mw, nw) = pick(write_b, "bayer2rgb")
-    rd, wr = mf * 1024 * 2, mw * 1024
-    lines += ["| bench kernel `%s` | per launch | algorithmic | ratio |" % kf[:70], "|---|---:|---:|---:|",
-              "| read  (FETCH_SIZE x 1024 x 2, n=%d) | %.0f | %d | %.4f |" % (nf, rd, ALG_R, rd / ALG_R),
-              "| write (WRITE_SIZE x 1024, n=%d) | %.0f | %d | %.4f |" % (nw, wr, ALG_W, wr / ALG_W),
-              "| total | %.0f | %d | %.5f |" % (rd + wr, ALG_R + ALG_W, (rd + wr) / (ALG_R + ALG_W)), ""]
+                  "correction of MI355X_MICROARCH.md \"HBM\": double it); WRITE_SIZE is exact.", "",
+              "Bench kernel, timed steps only, for the three block orders `mibayer_autotune` chooses between "
+              "(forced with `MIBAYER_XCD_BAND`, `--no-autotune`):", "",
+              "| block order | read = FETCH_SIZE x 1024 x 2 | write = WRITE_SIZE x 1024 | total per launch | / algorithmic 2 654 208 000 |",
+              "|---|---:|---:|---:|---:|"]
+    out = {}
+    for plan, (fb, wb) in plans.items():
+        kf, (mf, nf) = pick(fb, "bayer2rgb")
+        kw, (mw, nw) = pick(wb, "bayer2rgb")
+        rd, wr = mf * 1024 * 2, mw * 1024
+        lines.append("| %s | %.0f (%.4fx) | %.0f (%.4fx) | %.0f | %.5f |" % (
+            {"band1": "band 1: one full-width tile row per XCD at a time (+ start delay) -- the default",
+             "chunk": "one chunk of the batch per XCD (+ start delay)", "identity": "identity"}[plan],
+            rd, rd / ALG_R, wr, wr / ALG_W,
+            rd + wr, (rd + wr) / (ALG_R + ALG_W)))
+        out[plan] = {"hbm_bytes_per_launch": round(rd + wr), "read_bytes": round(rd), "write_bytes": round(wr)}
+        for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+            f = glob.glob(os.path.join(src, "pmc_bench_%s_%s" % (plan, cname), "*counter_collection.csv"))
+            if f:
+                rows = [r for r in csv.DictReader(open(f[0])) if "bayer2rgb" in r["Kernel_Name"]]
+                rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+                rows = rows[-8:]
+                with open(os.path.join(dst, "%s_pmc_bench_%s_%s.csv" % (tag, plan, cname)), "w", newline="") as o:
+                    w = csv.DictWriter(o, fieldnames=["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size",
+                                                      "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Counter_Name",
+                                                      "Counter_Value", "Start_Timestamp", "End_Timestamp"],
+                                       extrasaction="ignore")
+                    w.writeheader()
+                    w.writerows(rows)
+    lines += ["", "Halo lines that live in another XCD's L2 are fetched through the fabric again (the 256 MB Infinity Cache "
+                  "absorbs them before HBM): all of them for the identity order, the rows above/below a tile row for "
+                  "band 1, none for the chunk order.", ""]
     with open(os.path.join(dst, "traffic_latest.json"), "w") as f:
-        json.dump({"hbm_bytes_per_launch": round(rd + wr), "read_bytes": round(rd), "write_bytes": round(wr),
-                   "algorithmic_bytes_per_launch": ALG_R + ALG_W,
+        json.dump({"plans": out, "algorithmic_bytes_per_launch": ALG_R + ALG_W,
                    "source": "profiles/%s_summary.md (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + --pmc "
-                             "WRITE_SIZE, separate passes, mean over the bench launches)" % tag}, f, indent=1)
-    for d in ("pmc_bench_FETCH_SIZE", "pmc_bench_WRITE_SIZE"):
-        f = glob.glob(os.path.join(src, d, "*counter_collection.csv"))
-        if f:
-            rows = [r for r in csv.DictReader(open(f[0])) if "bayer2rgb" in r["Kernel_Name"]]
-            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-            rows = rows[-8:]
-            with open(os.path.join(dst, "%s_%s.csv" % (tag, d)), "w", newline="") as out:
-                w = csv.DictWriter(out, fieldnames=["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size",
-                                                    "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Counter_Name",
-                                                    "Counter_Value", "Start_Timestamp", "End_Timestamp"],
-                                   extrasaction="ignore")
-                w.writeheader()
-                w.writerows(rows)
+                             "WRITE_SIZE, separate passes, mean over the timed bench launches, per block order)" % tag},
+                  f, indent=1)
 with open(os.path.join(dst, "%s_summary.md" % tag), "w") as f:
     f.write("\n".join(lines) + "\n")
 print("\n".join(lines))

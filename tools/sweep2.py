@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Development tool: interleaved A/B timing of (kernel variant, XCD band) arms.
 
-All arms are created up front and timed round-robin for several rounds in ONE process, so slow drifts
-of the box (clock / thermal state) hit every arm alike; reports min and median per arm.
+All arms are created up front and timed for several rounds in ONE process, in a freshly shuffled order each
+round, so slow drifts of the box (clock / thermal state) and "who ran before me" effects hit every arm alike;
+reports min and median per arm.
 Usage: python tools/sweep2.py W H N rounds arm [arm ...]   with arm = variant_name[:band]"""
 import os
 import statistics
@@ -18,9 +19,9 @@ names = pkg.variant_names()
 arms = []
 for spec in sys.argv[5:]:
     name, _, rest = spec.partition(":")
-    parts = (rest.split(":") + [""] * 6)[:6]        # band : rot : dyn_lds : start_sleep : stagger : sleep_pos
+    parts = (rest.split(":") + [""] * 7)[:7]    # band : rot : dyn_lds : start_sleep : stagger : sleep_pos : run
     for key, val in zip(("MIBAYER_XCD_BAND", "MIBAYER_XCD_ROT", "MIBAYER_DYN_LDS", "MIBAYER_START_SLEEP",
-                         "MIBAYER_START_STAGGER", "MIBAYER_SLEEP_POS"), parts):
+                         "MIBAYER_START_STAGGER", "MIBAYER_SLEEP_POS", "MIBAYER_XCD_RUN"), parts):
         if val:
             os.environ[key] = val
         else:
@@ -28,7 +29,8 @@ for spec in sys.argv[5:]:
     ctx = pkg.Context(W, H, "rggb", "BGRx", variant=names.index(name))
     arms.append((spec, ctx, []))
 os.environ.pop("MIBAYER_XCD_BAND", None)
-for key in ("MIBAYER_XCD_ROT", "MIBAYER_DYN_LDS", "MIBAYER_START_SLEEP", "MIBAYER_START_STAGGER", "MIBAYER_SLEEP_POS"):
+for key in ("MIBAYER_XCD_ROT", "MIBAYER_DYN_LDS", "MIBAYER_START_SLEEP", "MIBAYER_START_STAGGER", "MIBAYER_SLEEP_POS",
+            "MIBAYER_XCD_RUN"):
     os.environ.pop(key, None)
 c0 = arms[0][1]
 d_src = c0.device_alloc(N * c0.src_bytes)
@@ -36,8 +38,12 @@ d_dst = c0.device_alloc(N * c0.dst_bytes)
 print("d_src %#x d_dst %#x" % (d_src, d_dst))
 c0.fill_synthetic(d_src, N, 2)
 c0.sync()
+import random
+rng = random.Random(1234)
 for r in range(ROUNDS + 1):
-    for spec, ctx, ts in arms:
+    order = list(arms)
+    rng.shuffle(order)          # a new arm order every round: no systematic "who ran before me" bias
+    for spec, ctx, ts in order:
         t = ctx.time_device(d_src, d_dst, N, warmup=2, reps=10)
         if r > 0:
             ts.append(t)
