@@ -313,7 +313,8 @@ static int launch (const mibayer_ctx *c, const void *d_src,
     q.dst_stride = f.dst_stride;
     q.out_dwords = ((f.width + 3) & ~3) / 4;
     q.total_rows = (long long) nframes * f.height;
-    q.band = c->band_override != INT32_MIN ? c->band_override : 0;
+    q.band = c->band_override != INT32_MIN ? c->band_override : -1;    /* chunk per XCD */
+    q.start_sleep = c->start_sleep > 0 ? c->start_sleep : 0;
     for (int k = 0; k < 2; k++) {
       q.sel_lo[k] = c->r2b_lo[k];
       q.sel_hi[k] = c->r2b_hi[k];

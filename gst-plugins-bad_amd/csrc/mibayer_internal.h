@@ -186,6 +186,7 @@ struct R2BParams {
   int out_dwords;               /* ROUND_UP_4(width) / 4 */
   long long total_rows;         /* nframes * height */
   int band;                     /* XCD band map (see block_to_tile); -1 = one chunk per XCD */
+  int start_sleep;              /* s_sleep(1) iterations before the first load (tuning) */
   TileMap map;                  /* filled by launch_rgb2bayer: tiles = R rows x 1024 px */
   FastDiv div_height;
   uint32_t sel_lo[2];           /* v_perm selectors per row parity: pixels 0,1 */

@@ -729,6 +729,8 @@ rgb2bayer_kernel (R2BParams p)
   const int xd = (int) tile.tx * 256 + threadIdx.x;     /* output dword in the row */
   if (xd >= p.out_dwords)
     return;
+  for (int z = 0; z < p.start_sleep; z++)
+    __builtin_amdgcn_s_sleep (1);
   const long long row0 = (long long) tile.row * R2B_ROWS;
   const int x0 = xd * 4;
   /* (frame, y) of row0; later rows only increment */
@@ -787,9 +789,11 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream)
   if (p.total_rows <= 0 || p.out_dwords <= 0)
     return hipSuccess;
   R2BParams q = p;
-  /* rows per block: 2 with the identity block order measured best on MI355X
-   * (74 % of peak vs 67-71 % for the other arms, profiles/r01_rgb2bayer.log);
-   * MIBAYER_R2B_ROWS / MIBAYER_XCD_BAND are tuning overrides */
+  /* rows per block: 2, with one chunk of the batch per XCD and no start delay,
+   * measured best on MI355X in a shuffled A/B (76 % of peak; identity order 73 %,
+   * 4 or 8 rows 70-75 %, any start delay worse: this direction is read-dominated;
+   * profiles/r01_rgb2bayer.log).  MIBAYER_R2B_ROWS / MIBAYER_XCD_BAND /
+   * MIBAYER_START_SLEEP are tuning overrides */
   static const int rows_per_block = [] {
     const char *e = getenv ("MIBAYER_R2B_ROWS");
     const int v = e ? atoi (e) : 2;
