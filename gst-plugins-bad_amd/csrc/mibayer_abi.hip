@@ -107,17 +107,11 @@ struct mibayer_ctx {
   const Variant *var = nullptr;         /* launch plan: tile shape ...                */
   int band_override = INT32_MIN;        /* ... and XCD band (INT32_MIN = the variant's);
                                            set by MIBAYER_XCD_BAND or mibayer_autotune() */
-  int xcd_rot = 0;                      /* MIBAYER_XCD_ROT (tuning) */
   int num_cus = 256;                    /* hipDeviceProp_t.multiProcessorCount */
   int persist_wgs_per_cu = 4;           /* MIBAYER_PERSIST_WGS (tuning), persistent arms */
-  int dyn_lds = 0;                      /* MIBAYER_DYN_LDS (tuning): extra LDS bytes per
-                                           workgroup, only to lower the occupancy */
   int start_sleep = -1;                 /* s_sleep(1) iterations before a workgroup's first load;
                                            -1 = automatic (kStartSleepChunk with a band map on
                                            large grids, else 0); MIBAYER_START_SLEEP overrides */
-  int start_stagger = 0;                /* MIBAYER_START_STAGGER (tuning) */
-  int sleep_pos = 0;                    /* MIBAYER_SLEEP_POS (tuning) */
-  int xcd_run = 1;                      /* MIBAYER_XCD_RUN (tuning): identity order in runs of k tiles */
   /* streams: uploads, kernels and downloads each get their own queue so that
    * frame n+1's H2D overlaps frame n's kernel and frame n-1's D2H */
   hipStream_t s_h2d = nullptr;
@@ -235,8 +229,6 @@ static void fill_params (const mibayer_ctx *c, KParams &p, Geometry &g,
     p.sel[k] = c->sel[k];
   p.swap_rows = c->swap_rows;
   p.start_sleep = c->start_sleep > 0 ? c->start_sleep : 0;      /* auto: plan_launch */
-  p.start_stagger = c->start_stagger;
-  p.sleep_pos = c->sleep_pos;
 }
 
 typedef void (*KernelFn) (KParams);
@@ -272,14 +264,12 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
       n = (ntiles + kNumXcd - 1) / kNumXcd * kNumXcd;
     grid = (unsigned) (n > 0 ? n : kNumXcd);
   } else {
-    const long long n = grid_blocks_for (g.tiles_x, g.tile_rows, g.band,
-        c->xcd_run);
+    const long long n = grid_blocks_for (g.tiles_x, g.tile_rows, g.band);
     if (n > 0x7fffffffLL)
       return MIBAYER_ERR_GEOMETRY;
     grid = (unsigned) n;
   }
-  p.map = make_tile_map (g.tiles_x, g.tiles_y, g.tile_rows, g.band, c->xcd_rot,
-      c->var->persistent ? 1 : c->xcd_run);
+  p.map = make_tile_map (g.tiles_x, g.tiles_y, g.tile_rows, g.band);
   /* Start delay (DESIGN.md "start delay"): with a band map every workgroup
    * sleeps ~1.5k cycles before its first load.  Measured +3..5 points of HBM
    * peak on every box for the chunk-per-XCD order (it thins the number of
@@ -331,8 +321,7 @@ static int launch (const mibayer_ctx *c, const void *d_src,
       nframes, p, kern, grid);
   if (rc != MIBAYER_OK)
     return rc;
-  hipLaunchKernelGGL (kern, dim3 (grid), dim3 (c->var->threads),
-      (size_t) c->dyn_lds, stream, p);
+  hipLaunchKernelGGL (kern, dim3 (grid), dim3 (c->var->threads), 0, stream, p);
   HIP_TRY (hipGetLastError ());
   return MIBAYER_OK;
 }
@@ -392,7 +381,7 @@ extern "C" int64_t mibayer_block_to_tile (int64_t block, int tiles_x,
       || tile_rows * tiles_x > 0x7fffffffLL)
     return -1;
   /* the very function the kernels run */
-  const TileMap m = make_tile_map (tiles_x, 1, tile_rows, band, 0);
+  const TileMap m = make_tile_map (tiles_x, 1, tile_rows, band);
   const TileId t = block_to_tile ((uint32_t) block, m);
   if (band <= 0 && block >= tile_rows * tiles_x)
     return -1;
@@ -492,18 +481,8 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   c->var = &variant (resolve_variant (f.variant, f.width));
   if (const char *e = getenv ("MIBAYER_XCD_BAND"))
     c->band_override = atoi (e);
-  if (const char *e = getenv ("MIBAYER_XCD_ROT"))
-    c->xcd_rot = atoi (e) & 7;
-  if (const char *e = getenv ("MIBAYER_DYN_LDS"))
-    c->dyn_lds = atoi (e) > 0 ? atoi (e) : 0;
   if (const char *e = getenv ("MIBAYER_START_SLEEP"))
     c->start_sleep = atoi (e) >= 0 ? atoi (e) : -1;
-  if (const char *e = getenv ("MIBAYER_XCD_RUN"))
-    c->xcd_run = atoi (e) > 1 ? atoi (e) : 1;
-  if (const char *e = getenv ("MIBAYER_SLEEP_POS"))
-    c->sleep_pos = atoi (e);
-  if (const char *e = getenv ("MIBAYER_START_STAGGER"))
-    c->start_stagger = atoi (e) > 0 ? atoi (e) : 0;
   if (const char *e = getenv ("MIBAYER_PERSIST_WGS"))
     c->persist_wgs_per_cu = atoi (e) > 0 ? atoi (e) : 4;
   {

@@ -57,10 +57,6 @@ struct TileMap {
   FastDiv per_group;            /* band * tiles_x                               */
   uint32_t tile_rows;           /* nframes * tiles_y                            */
   int band;                     /* tile rows per XCD band; 0 = identity map     */
-  int rot;                      /* tuning: XCD k takes the bands of XCD (k+rot)%8 */
-  FastDiv run;                  /* band == 0: consecutive tiles per XCD (1 = plain identity);
-                                   runs of k neighbours share an L2, which cuts the halo
-                                   re-fetch of the identity order from 2x to (1 + 1/k)x */
 };
 
 struct TileId {
@@ -73,17 +69,10 @@ __host__ __device__ inline TileId block_to_tile (uint32_t block, const TileMap &
 {
   TileId t;
   if (m.band <= 0) {
-    uint32_t lin = block;
-    if (m.run.d > 1) {          /* XCD x takes tiles [ (r*8+x)*k, +k ) for r = 0, 1, ... */
-      const uint32_t xcd = block & (kNumXcd - 1);
-      const uint32_t i = block / kNumXcd;
-      const uint32_t r = fastdiv (i, m.run);
-      lin = (r * kNumXcd + xcd) * m.run.d + (i - r * m.run.d);
-    }
-    t.row = fastdiv (lin, m.tiles_x);
-    t.tx = lin - t.row * m.tiles_x.d;
+    t.row = fastdiv (block, m.tiles_x);
+    t.tx = block - t.row * m.tiles_x.d;
   } else {
-    const uint32_t xcd = (block + (uint32_t) m.rot) & (kNumXcd - 1);
+    const uint32_t xcd = block & (kNumXcd - 1);
     const uint32_t i = block / kNumXcd;         /* i-th block of this XCD */
     const uint32_t group = fastdiv (i, m.per_group);
     const uint32_t in_group = i - group * m.per_group.d;
@@ -105,33 +94,25 @@ __host__ __device__ inline TileId linear_to_tile (uint32_t tile, const TileMap &
   return t;
 }
 
-inline long long grid_blocks_for (int tiles_x, long long tile_rows, int band,
-    int run = 1)
+inline long long grid_blocks_for (int tiles_x, long long tile_rows, int band)
 {
-  if (band <= 0) {
-    const long long n = tile_rows * tiles_x;
-    if (run <= 1)
-      return n;
-    const long long per = (long long) kNumXcd * run;
-    return (n + per - 1) / per * per;
-  }
+  if (band <= 0)
+    return tile_rows * tiles_x;
   const long long group_rows = (long long) kNumXcd * band;
   const long long groups = (tile_rows + group_rows - 1) / group_rows;
   return groups * group_rows * tiles_x;
 }
 
 inline TileMap make_tile_map (int tiles_x, int tiles_y, long long tile_rows,
-    int band, int rot, int run = 1)
+    int band)
 {
   TileMap m;
-  m.run = make_fastdiv ((uint32_t) (run > 1 ? run : 1));
   m.tiles_x = make_fastdiv ((uint32_t) tiles_x);
   m.tiles_y = make_fastdiv ((uint32_t) tiles_y);
   m.per_group = make_fastdiv ((uint32_t) (band > 0 ? band : 1)
       * (uint32_t) tiles_x);
   m.tile_rows = (uint32_t) tile_rows;
   m.band = band;
-  m.rot = rot;
   return m;
 }
 
@@ -148,10 +129,7 @@ struct KParams {
   int wlimit4;                  /* ROUND_UP_4(width): last readable column + 1 */
   int dn_last;                  /* source row standing in for row `height`     */
   TileMap map;
-  int start_sleep;              /* tuning: s_sleep(1) iterations before the first load */
-  int start_stagger;            /* tuning: + this many per ((block/8) & 3)             */
-  int sleep_pos;                /* tuning: 0 before the loads (default), 1 after the barrier,
-                                   2 after the stores */
+  int start_sleep;              /* s_sleep(1) iterations before a workgroup's first load */
   uint32_t sel[4];              /* v_perm_b32 selectors of output pixel 0..3   */
   int swap_rows;                /* 1 for grbg / gbrg                           */
 };

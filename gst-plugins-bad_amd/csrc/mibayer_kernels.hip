@@ -250,15 +250,12 @@ bayer2rgb_lds_kernel (KParams p)
   const TileId tile = block_to_tile (blockIdx.x, p.map);
   if (!tile.valid)
     return;
-  /* start delay; stagger / position are tuning knobs */
-  const int nsleep = p.start_sleep
-      + p.start_stagger * (int) ((blockIdx.x / kNumXcd) & 3u);
-  auto nap = [&](int pos) {
-    if (p.sleep_pos == pos)
-      for (int z = 0; z < nsleep; z++)
-        __builtin_amdgcn_s_sleep (1);
-  };
-  nap (0);
+  /* start delay: thins the requests in flight; +3..5 points of HBM
+   * peak for the band / chunk block orders.  Measured alternatives that lost:
+   * the same delay after the barrier or after the stores, a per-workgroup
+   * stagger, lower occupancy (profiles/r01_sweep_start_delay.log). */
+  for (int z = 0; z < p.start_sleep; z++)
+    __builtin_amdgcn_s_sleep (1);
   const uint32_t frame = fastdiv (tile.row, p.map.tiles_y);
   const int ty = (int) (tile.row - frame * p.map.tiles_y.d);
   const uint8_t *src = p.src + frame * p.src_frame_bytes;
@@ -332,7 +329,6 @@ bayer2rgb_lds_kernel (KParams p)
     *(uint32_t *) &lds[r * PITCH + (side ? MAIN + TW : MAIN - 4)] = v;
   }
   __syncthreads ();
-  nap (1);
 
   /* ---- per-wave march -------------------------------------------------------- */
   const int wave = tid >> 6;
@@ -387,7 +383,6 @@ bayer2rgb_lds_kernel (KParams p)
     up = cur;
     cur = dn;
   }
-  nap (2);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -807,7 +802,7 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream)
   const long long grid = grid_blocks_for (tiles_x, tile_rows, q.band);
   if (grid > 0x7fffffffLL || p.total_rows > 0x7fffffffLL)
     return hipErrorInvalidValue;
-  q.map = make_tile_map (tiles_x, 1, tile_rows, q.band, 0);
+  q.map = make_tile_map (tiles_x, 1, tile_rows, q.band);
   q.div_height = make_fastdiv ((uint32_t) p.height);
 #define R2B_LAUNCH(V, R) hipLaunchKernelGGL ((rgb2bayer_kernel<V, R>), \
       dim3 ((unsigned) grid), dim3 (256), 0, stream, q)

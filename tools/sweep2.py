@@ -4,7 +4,9 @@
 All arms are created up front and timed for several rounds in ONE process, in a freshly shuffled order each
 round, so slow drifts of the box (clock / thermal state) and "who ran before me" effects hit every arm alike;
 reports min and median per arm.
-Usage: python tools/sweep2.py W H N rounds arm [arm ...]   with arm = variant_name[:band]"""
+Usage: python tools/sweep2.py W H N rounds arm [arm ...]   with arm = variant_name[:band[:start_sleep]]
+(the logs under profiles/ were taken with earlier builds of this tool that also carried knobs for the block->XCD
+rotation, an occupancy throttle, a staggered / repositioned delay; those lost and were removed from the product)"""
 import os
 import statistics
 import sys
@@ -19,9 +21,8 @@ names = pkg.variant_names()
 arms = []
 for spec in sys.argv[5:]:
     name, _, rest = spec.partition(":")
-    parts = (rest.split(":") + [""] * 7)[:7]    # band : rot : dyn_lds : start_sleep : stagger : sleep_pos : run
-    for key, val in zip(("MIBAYER_XCD_BAND", "MIBAYER_XCD_ROT", "MIBAYER_DYN_LDS", "MIBAYER_START_SLEEP",
-                         "MIBAYER_START_STAGGER", "MIBAYER_SLEEP_POS", "MIBAYER_XCD_RUN"), parts):
+    parts = (rest.split(":") + ["", ""])[:2]          # band : start_sleep
+    for key, val in zip(("MIBAYER_XCD_BAND", "MIBAYER_START_SLEEP"), parts):
         if val:
             os.environ[key] = val
         else:
@@ -29,9 +30,7 @@ for spec in sys.argv[5:]:
     ctx = pkg.Context(W, H, "rggb", "BGRx", variant=names.index(name))
     arms.append((spec, ctx, []))
 os.environ.pop("MIBAYER_XCD_BAND", None)
-for key in ("MIBAYER_XCD_ROT", "MIBAYER_DYN_LDS", "MIBAYER_START_SLEEP", "MIBAYER_START_STAGGER", "MIBAYER_SLEEP_POS",
-            "MIBAYER_XCD_RUN"):
-    os.environ.pop(key, None)
+os.environ.pop("MIBAYER_START_SLEEP", None)
 c0 = arms[0][1]
 d_src = c0.device_alloc(N * c0.src_bytes)
 d_dst = c0.device_alloc(N * c0.dst_bytes)
