@@ -696,9 +696,6 @@ static int graph_submit (mibayer_ctx *c, Slot &s, const uint8_t *src,
         p, kern, grid);
     if (rc != MIBAYER_OK)
       return rc;
-    HIP_TRY (hipGraphCreate (&s.graph, 0));
-    HIP_TRY (hipGraphAddMemcpyNode1D (&s.n_h2d, s.graph, NULL, 0, s.d_src, src,
-            c->src_bytes, hipMemcpyHostToDevice));
     void *args[1] = { &p };
     hipKernelNodeParams kp;
     memset (&kp, 0, sizeof kp);
@@ -708,10 +705,24 @@ static int graph_submit (mibayer_ctx *c, Slot &s, const uint8_t *src,
     kp.sharedMemBytes = 0;
     kp.kernelParams = args;
     kp.extra = NULL;
-    HIP_TRY (hipGraphAddKernelNode (&s.n_kernel, s.graph, &s.n_h2d, 1, &kp));
-    HIP_TRY (hipGraphAddMemcpyNode1D (&s.n_d2h, s.graph, &s.n_kernel, 1, dst,
-            s.d_dst, c->dst_bytes, hipMemcpyDeviceToHost));
-    HIP_TRY (hipGraphInstantiate (&s.exec, s.graph, NULL, NULL, 0));
+    bool bad = hip_failed (hipGraphCreate (&s.graph, 0), "hipGraphCreate");
+    bad = bad || hip_failed (hipGraphAddMemcpyNode1D (&s.n_h2d, s.graph, NULL,
+            0, s.d_src, src, c->src_bytes, hipMemcpyHostToDevice),
+        "hipGraphAddMemcpyNode1D");
+    bad = bad || hip_failed (hipGraphAddKernelNode (&s.n_kernel, s.graph,
+            &s.n_h2d, 1, &kp), "hipGraphAddKernelNode");
+    bad = bad || hip_failed (hipGraphAddMemcpyNode1D (&s.n_d2h, s.graph,
+            &s.n_kernel, 1, dst, s.d_dst, c->dst_bytes, hipMemcpyDeviceToHost),
+        "hipGraphAddMemcpyNode1D");
+    bad = bad || hip_failed (hipGraphInstantiate (&s.exec, s.graph, NULL, NULL,
+            0), "hipGraphInstantiate");
+    if (bad) {                  /* no half-built graph survives a failure */
+      if (s.graph)
+        (void) hipGraphDestroy (s.graph);
+      s.graph = nullptr;
+      s.exec = nullptr;
+      return MIBAYER_ERR_HIP;
+    }
   }
   s.g_src = src;
   s.g_dst = dst;
@@ -720,7 +731,7 @@ static int graph_submit (mibayer_ctx *c, Slot &s, const uint8_t *src,
   return MIBAYER_OK;
 }
 
-static int submit_locked (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
+static int enqueue_frame (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
     void *tag)
 {
   int rc = ensure_ring (c);
@@ -767,6 +778,27 @@ static int submit_locked (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
   c->head = (c->head + 1) % (int) c->ring.size ();
   c->pending++;
   return MIBAYER_OK;
+}
+
+/* A submit that fails half-way (say the upload was queued and the launch was
+ * refused) must not leave work behind that still touches the caller's buffers
+ * after the error has been returned: drain whatever was queued. */
+static int submit_locked (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
+    void *tag)
+{
+  const int rc = enqueue_frame (c, src, dst, tag);
+  if (rc != MIBAYER_OK && rc != MIBAYER_ERR_BUSY) {
+    char keep[sizeof t_hip_error];
+    memcpy (keep, t_hip_error, sizeof keep);    /* report the first error */
+    (void) hipStreamSynchronize (c->s_h2d);
+    (void) hipStreamSynchronize (c->s_compute);
+    (void) hipStreamSynchronize (c->s_d2h);
+    for (Slot &sl : c->ring)
+      if (sl.s_graph)
+        (void) hipStreamSynchronize (sl.s_graph);
+    memcpy (t_hip_error, keep, sizeof keep);
+  }
+  return rc;
 }
 
 static int wait_locked (mibayer_ctx *c, void **tag)

@@ -1,0 +1,816 @@
+/* Shared implementation of `bayer2rgb` and `rgb2bayer` -- MI355X-native.
+ *
+ * Everything a neighbouring element can observe is kept identical to the
+ * reference elements (gst-plugins-bad 1.19.2):
+ *   transform_caps / get_unit_size / set_caps
+ *        gst/bayer/gstbayer2rgb.c:289-322 / :324-352 / :237-276
+ *        gst/bayer/gstrgb2bayer.c:128-159 / :161-188 / :190-228
+ *   1-in/1-out synchronous transform (the default mode)
+ *        gstbayer2rgb.c:456-487, gstrgb2bayer.c:230-278
+ * What changes is below the transform vfunc: the reference calls its CPU frame
+ * loops (gst_bayer2rgb_process, gstbayer2rgb.c:475-477; the double loop of
+ * gstrgb2bayer.c:254-268); here the mapped pointers and strides go to the HIP
+ * path through the C ABI of mibayer.h.  There is no CPU fallback: without a
+ * usable MI355X the elements post a RESOURCE error instead of converting on
+ * the host.
+ *
+ * Additive, optional behaviour:
+ *   - hipHostMalloc-pinned buffer pools are proposed upstream and used
+ *     downstream when nobody offers a pool (propose/decide_allocation), so the
+ *     H2D/D2H copies are asynchronous DMA;
+ *   - `inflight` > 1 and/or `devices` switch to a queued mode: input buffers
+ *     are submitted to a round-robin pool of GPUs (frame g -> devices[g % N])
+ *     and outputs are pushed in order as they complete; pending frames are
+ *     drained before EOS / caps / segment events and dropped on flush.
+ *     In-tree precedent for queueing in submit_input_buffer/generate_output:
+ *     sys/va/gstvadeinterlace.c:186-232, :467-531.
+ */
+#ifdef HAVE_CONFIG_H
+#include "config.h"
+#endif
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "gstmibayerelement.h"
+#include "gstmihostpool.h"
+
+/* each element logs into its own category, named like the reference's
+ * ("bayer2rgb", "rgb2bayer"); the category lives in the class */
+#define EL_DEBUG(obj, ...) \
+  GST_CAT_DEBUG_OBJECT (ELEMENT_CLASS_OF (obj)->cat, obj, __VA_ARGS__)
+#define EL_WARNING(obj, ...) \
+  GST_CAT_WARNING_OBJECT (ELEMENT_CLASS_OF (obj)->cat, obj, __VA_ARGS__)
+
+#define ELEMENT(obj) ((GstMiBayerElement *) (obj))
+#define ELEMENT_CLASS_OF(obj) \
+  ((GstMiBayerElementClass *) G_OBJECT_GET_CLASS (obj))
+#define LABEL(obj) (ELEMENT_CLASS_OF (obj)->label)
+#define IS_INVERSE(obj) (ELEMENT_CLASS_OF (obj)->inverse)
+#define BASE_CLASS(obj) (ELEMENT_CLASS_OF (obj)->base_class)
+
+enum
+{
+  PROP_0,
+  PROP_DEVICE_ID,
+  PROP_DEVICES,
+  PROP_INFLIGHT,
+  PROP_HIPGRAPH,
+  PROP_PINNED_POOL
+};
+
+#define DEFAULT_DEVICE_ID 0
+#define DEFAULT_INFLIGHT 1
+#define DEFAULT_HIPGRAPH FALSE
+#define DEFAULT_PINNED_POOL TRUE
+
+/* one frame between submit and wait: both buffers stay mapped until the GPU
+ * has written the output */
+typedef struct
+{
+  GstBuffer *inbuf;
+  GstBuffer *outbuf;
+  GstBuffer *mosaic_buf;        /* == inbuf (bayer2rgb) or outbuf (rgb2bayer) */
+  GstMapInfo mosaic;            /* the 8-bit mosaic side */
+  GstVideoFrame video;          /* the 4-byte-per-pixel side */
+  gboolean owns_outbuf;         /* queued mode: we hold the only reference to outbuf;
+                                   synchronous mode: the base class owns it */
+} PendingFrame;
+
+/* ---- GPU pool --------------------------------------------------------------- */
+
+/* unmap and free the bookkeeping; the output buffer is unreffed only if this
+ * entry owns it and the caller does not take it over */
+static void
+pending_release (PendingFrame * p, gboolean caller_takes_outbuf)
+{
+  gst_video_frame_unmap (&p->video);
+  gst_buffer_unmap (p->mosaic_buf, &p->mosaic);
+  gst_buffer_unref (p->inbuf);
+  if (p->owns_outbuf && !caller_takes_outbuf)
+    gst_buffer_unref (p->outbuf);
+  g_free (p);
+}
+
+static void
+post_gpu_failure (GstMiBayerElement * self, int rc)
+{
+  GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
+      ("%s: GPU conversion failed", LABEL (self)),
+      ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
+}
+
+/* wait for everything in flight; push it downstream (push == TRUE) or drop it */
+static GstFlowReturn
+element_drain (GstMiBayerElement * self, gboolean push)
+{
+  GstFlowReturn ret = GST_FLOW_OK;
+  PendingFrame *p;
+
+  while ((p = g_queue_pop_head (&self->pending)) != NULL) {
+    GstBuffer *out = p->outbuf;
+    gboolean owned = p->owns_outbuf;
+    int rc = self->pool ? mibayer_pool_wait (self->pool, NULL) : MIBAYER_OK;
+    gboolean do_push = push && owned && rc == MIBAYER_OK && ret == GST_FLOW_OK;
+
+    pending_release (p, do_push);
+    if (rc != MIBAYER_OK) {
+      post_gpu_failure (self, rc);
+      ret = GST_FLOW_ERROR;
+    } else if (do_push) {
+      ret = gst_pad_push (GST_BASE_TRANSFORM_SRC_PAD (self), out);
+    }
+  }
+  return ret;
+}
+
+static void
+element_drop_pool (GstMiBayerElement * self)
+{
+  element_drain (self, FALSE);
+  if (self->pool) {
+    mibayer_pool_destroy (self->pool);
+    self->pool = NULL;
+  }
+  self->pool_stride = 0;
+  self->capacity = 0;
+}
+
+/* reference gst_bayer2rgb_reset, gstbayer2rgb.c:278-287 */
+static void
+element_clear_negotiation (GstMiBayerElement * self)
+{
+  self->width = 0;
+  self->height = 0;
+  self->r_off = 0;
+  self->g_off = 0;
+  self->b_off = 0;
+  self->format = MIBAYER_BGGR;
+  gst_video_info_init (&self->info);
+}
+
+static gboolean
+element_parse_devices (GstMiBayerElement * self, mibayer_pool_cfg * pc)
+{
+  gchar **tok, **t;
+
+  pc->ndevices = 0;
+  if (self->devices == NULL || self->devices[0] == '\0') {
+    pc->devices[pc->ndevices++] = self->device_id;
+    return TRUE;
+  }
+  tok = g_strsplit_set (self->devices, ",;: ", -1);
+  for (t = tok; *t != NULL; t++) {
+    gchar *end = NULL;
+    glong v;
+
+    if (**t == '\0')
+      continue;
+    v = strtol (*t, &end, 10);
+    if (end == *t || *end != '\0' || v < 0
+        || pc->ndevices >= MIBAYER_MAX_SHARDS) {
+      g_strfreev (tok);
+      return FALSE;
+    }
+    pc->devices[pc->ndevices++] = (int32_t) v;
+  }
+  g_strfreev (tok);
+  return pc->ndevices > 0;
+}
+
+static gint
+element_ndevices (GstMiBayerElement * self)
+{
+  mibayer_pool_cfg pc;
+
+  return element_parse_devices (self, &pc) ? pc.ndevices : 1;
+}
+
+/* `video_stride` is the mapped stride of the 4-byte-per-pixel frame: the
+ * destination stride of bayer2rgb (reference gstbayer2rgb.c:476), the source
+ * stride of rgb2bayer (gstrgb2bayer.c:256).  The mosaic rows are always
+ * GST_ROUND_UP_4 (width) apart (gstbayer2rgb.c:477, gstrgb2bayer.c:255). */
+static gboolean
+element_ensure_pool (GstMiBayerElement * self, gint video_stride)
+{
+  const gboolean inverse = IS_INVERSE (self);
+  mibayer_pool_cfg pc;
+  int rc;
+
+  if (self->pool && self->pool_stride == video_stride)
+    return TRUE;
+  element_drop_pool (self);
+
+  memset (&pc, 0, sizeof pc);
+  pc.struct_size = sizeof pc;
+  pc.stream.struct_size = sizeof pc.stream;
+  pc.stream.width = self->width;
+  pc.stream.height = self->height;
+  if (inverse) {
+    pc.stream.src_stride = video_stride;
+    pc.stream.dst_stride = GST_ROUND_UP_4 (self->width);
+  } else {
+    pc.stream.src_stride = GST_ROUND_UP_4 (self->width);
+    pc.stream.dst_stride = video_stride;
+  }
+  pc.stream.pattern = self->format;
+  pc.stream.r_off = self->r_off;
+  pc.stream.g_off = self->g_off;
+  pc.stream.b_off = self->b_off;
+  pc.stream.inflight = self->inflight;
+  pc.stream.flags = (self->use_hipgraph ? MIBAYER_FLAG_HIPGRAPH : 0)
+      | (inverse ? MIBAYER_FLAG_RGB2BAYER : 0);
+  if (!element_parse_devices (self, &pc)) {
+    GST_ELEMENT_ERROR (self, LIBRARY, SETTINGS,
+        ("%s: cannot parse devices=\"%s\"", LABEL (self), self->devices),
+        (NULL));
+    return FALSE;
+  }
+
+  rc = mibayer_pool_create (&pc, &self->pool);
+  if (rc != MIBAYER_OK) {
+    self->pool = NULL;
+    if (rc == MIBAYER_ERR_NO_DEVICE) {
+      GST_ELEMENT_ERROR (self, RESOURCE, NOT_FOUND,
+          ("%s: no usable MI355X / HIP device (device-id=%d devices=%s)",
+              LABEL (self), self->device_id,
+              self->devices ? self->devices : ""),
+          ("%s; this element has no CPU path", mibayer_strerror (rc)));
+    } else if (rc == MIBAYER_ERR_GEOMETRY) {
+      GST_ELEMENT_ERROR (self, STREAM, FORMAT,
+          ("%s: unsupported frame geometry %dx%d", LABEL (self), self->width,
+              self->height), ("%s", mibayer_strerror (rc)));
+    } else {
+      GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
+          ("%s: cannot create GPU context", LABEL (self)),
+          ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
+    }
+    return FALSE;
+  }
+  self->pool_stride = video_stride;
+  self->capacity = mibayer_pool_capacity (self->pool);
+  EL_DEBUG (self, "GPU pool: %d device(s), %d frame(s) in flight, "
+      "%dx%d pattern %d stride %d%s", pc.ndevices, self->capacity, self->width,
+      self->height, self->format, video_stride,
+      self->use_hipgraph ? ", hipGraph per frame" : "");
+  return TRUE;
+}
+
+static inline gboolean
+element_is_queued_mode (GstMiBayerElement * self)
+{
+  return self->inflight > 1
+      || (self->devices != NULL && strchr (self->devices, ',') != NULL);
+}
+
+/* ---- GObject ----------------------------------------------------------------- */
+
+static void
+element_set_property (GObject * object, guint prop_id, const GValue * value,
+    GParamSpec * pspec)
+{
+  GstMiBayerElement *self = ELEMENT (object);
+
+  GST_OBJECT_LOCK (self);
+  switch (prop_id) {
+    case PROP_DEVICE_ID:
+      self->device_id = g_value_get_int (value);
+      break;
+    case PROP_DEVICES:
+      g_free (self->devices);
+      self->devices = g_value_dup_string (value);
+      break;
+    case PROP_INFLIGHT:
+      self->inflight = g_value_get_int (value);
+      break;
+    case PROP_HIPGRAPH:
+      self->use_hipgraph = g_value_get_boolean (value);
+      break;
+    case PROP_PINNED_POOL:
+      self->pinned_pool = g_value_get_boolean (value);
+      break;
+    default:
+      G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
+      break;
+  }
+  GST_OBJECT_UNLOCK (self);
+}
+
+static void
+element_get_property (GObject * object, guint prop_id, GValue * value,
+    GParamSpec * pspec)
+{
+  GstMiBayerElement *self = ELEMENT (object);
+
+  switch (prop_id) {
+    case PROP_DEVICE_ID:
+      g_value_set_int (value, self->device_id);
+      break;
+    case PROP_DEVICES:
+      g_value_set_string (value, self->devices);
+      break;
+    case PROP_INFLIGHT:
+      g_value_set_int (value, self->inflight);
+      break;
+    case PROP_HIPGRAPH:
+      g_value_set_boolean (value, self->use_hipgraph);
+      break;
+    case PROP_PINNED_POOL:
+      g_value_set_boolean (value, self->pinned_pool);
+      break;
+    default:
+      G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
+      break;
+  }
+}
+
+static void
+element_finalize (GObject * object)
+{
+  GstMiBayerElement *self = ELEMENT (object);
+
+  element_drop_pool (self);
+  g_free (self->devices);
+  self->devices = NULL;
+  G_OBJECT_CLASS (BASE_CLASS (self))->finalize (object);
+}
+
+/* ---- caps (identical semantics to the reference) ------------------------------ */
+
+/* reference gstbayer2rgb.c:289-322 and its mirror image gstrgb2bayer.c:128-159:
+ * the bayer side and the raw side differ only in the media type name and in the
+ * fields that describe the pixel encoding */
+static GstCaps *
+element_transform_caps (GstBaseTransform * base, GstPadDirection direction,
+    GstCaps * caps, GstCaps * filter)
+{
+  /* caps given for the pad that carries the mosaic -> produce raw caps */
+  const gboolean to_raw = (direction == GST_PAD_SINK) != IS_INVERSE (base);
+  GstCaps *result = gst_caps_copy (caps);
+  guint i, n = gst_caps_get_size (result);
+
+  for (i = 0; i < n; i++) {
+    GstStructure *s = gst_caps_get_structure (result, i);
+
+    if (to_raw) {
+      gst_structure_set_name (s, "video/x-raw");
+      gst_structure_remove_field (s, "format");
+    } else {
+      gst_structure_set_name (s, "video/x-bayer");
+      gst_structure_remove_fields (s, "format", "colorimetry", "chroma-site",
+          NULL);
+    }
+  }
+  if (filter) {
+    GstCaps *unfiltered = result;
+
+    result = gst_caps_intersect_full (filter, unfiltered,
+        GST_CAPS_INTERSECT_FIRST);
+    gst_caps_unref (unfiltered);
+  }
+  EL_DEBUG (base, "transformed %" GST_PTR_FORMAT " into %"
+      GST_PTR_FORMAT, caps, result);
+  return result;
+}
+
+/* reference gstbayer2rgb.c:324-352, gstrgb2bayer.c:161-188 */
+static gboolean
+element_get_unit_size (GstBaseTransform * base, GstCaps * caps, gsize * size)
+{
+  GstStructure *s = gst_caps_get_structure (caps, 0);
+  gint w, h;
+
+  if (!gst_structure_get_int (s, "width", &w)
+      || !gst_structure_get_int (s, "height", &h)) {
+    GST_ELEMENT_ERROR (base, CORE, NEGOTIATION, (NULL),
+        ("Incomplete caps, some required field missing"));
+    return FALSE;
+  }
+  if (gst_structure_has_name (s, "video/x-raw"))
+    *size = (gsize) w * h * 4;            /* always 32 bits per pixel */
+  else
+    *size = (gsize) GST_ROUND_UP_4 (w) * h;     /* 8-bit mosaic, rows padded to 4 */
+  return TRUE;
+}
+
+/* reference gstbayer2rgb.c:237-276, gstrgb2bayer.c:190-228 */
+static gboolean
+element_set_caps (GstBaseTransform * base, GstCaps * incaps, GstCaps * outcaps)
+{
+  static const struct
+  {
+    const gchar *name;
+    gint pattern;
+  } orders[] = {
+    {"bggr", MIBAYER_BGGR}, {"gbrg", MIBAYER_GBRG},
+    {"grbg", MIBAYER_GRBG}, {"rggb", MIBAYER_RGGB}
+  };
+  GstMiBayerElement *self = ELEMENT (base);
+  const gboolean inverse = IS_INVERSE (self);
+  GstCaps *bayer_caps = inverse ? outcaps : incaps;
+  GstCaps *raw_caps = inverse ? incaps : outcaps;
+  GstStructure *s = gst_caps_get_structure (bayer_caps, 0);
+  const gchar *order;
+  GstVideoInfo info;
+  guint i;
+
+  EL_DEBUG (self, "in caps %" GST_PTR_FORMAT " out caps %"
+      GST_PTR_FORMAT, incaps, outcaps);
+
+  gst_structure_get_int (s, "width", &self->width);
+  gst_structure_get_int (s, "height", &self->height);
+
+  order = gst_structure_get_string (s, "format");
+  if (order == NULL)
+    return FALSE;
+  for (i = 0; i < G_N_ELEMENTS (orders); i++) {
+    if (g_str_equal (order, orders[i].name))
+      break;
+  }
+  if (i == G_N_ELEMENTS (orders))
+    return FALSE;
+  self->format = orders[i].pattern;
+
+  /* where R, G and B live inside the 4-byte pixel (rgb2bayer's ARGB: 1, 2, 3 =
+   * the hard-coded offsets of gstrgb2bayer.c:259-266) */
+  if (!gst_video_info_from_caps (&info, raw_caps))
+    return FALSE;
+  self->r_off = GST_VIDEO_INFO_COMP_OFFSET (&info, 0);
+  self->g_off = GST_VIDEO_INFO_COMP_OFFSET (&info, 1);
+  self->b_off = GST_VIDEO_INFO_COMP_OFFSET (&info, 2);
+  self->info = info;
+
+  /* geometry changed: the GPU pool is rebuilt on the next buffer, once the
+   * mapped video stride is known */
+  element_drop_pool (self);
+  return TRUE;
+}
+
+/* ---- allocation: pinned pools -------------------------------------------------- */
+
+static GstBufferPool *
+element_make_pinned_pool (GstMiBayerElement * self, GstCaps * caps, guint size,
+    guint min)
+{
+  GstBufferPool *pool;
+  GstStructure *config;
+
+  if (mibayer_device_count () <= 0)
+    return NULL;
+  pool = gst_mi_host_pool_new ();
+  config = gst_buffer_pool_get_config (pool);
+  gst_buffer_pool_config_set_params (config, caps, size, min, 0);
+  if (!gst_buffer_pool_set_config (pool, config)) {
+    gst_object_unref (pool);
+    return NULL;
+  }
+  EL_DEBUG (self, "pinned pool: %u bytes per buffer, min %u", size,
+      min);
+  return pool;
+}
+
+/* upstream asks how to allocate the buffers it will send us */
+static gboolean
+element_propose_allocation (GstBaseTransform * base, GstQuery * decide_query,
+    GstQuery * query)
+{
+  GstMiBayerElement *self = ELEMENT (base);
+  GstCaps *caps = NULL;
+  gboolean need_pool = FALSE;
+  gsize size = 0;
+  guint min;
+  GstBufferPool *pool;
+
+  if (!BASE_CLASS (self)->propose_allocation (base, decide_query, query))
+    return FALSE;
+  if (!self->pinned_pool)
+    return TRUE;
+  gst_query_parse_allocation (query, &caps, &need_pool);
+  if (caps == NULL || !element_get_unit_size (base, caps, &size))
+    return TRUE;
+  /* every frame in flight keeps its input buffer mapped */
+  min = (guint) (MAX (self->inflight, 1) * element_ndevices (self) + 2);
+  pool = element_make_pinned_pool (self, caps, (guint) size, min);
+  if (pool) {
+    gst_query_add_allocation_pool (query, pool, (guint) size, min, 0);
+    gst_object_unref (pool);
+    EL_DEBUG (self, "proposed a pinned input pool upstream");
+  }
+  return TRUE;
+}
+
+/* downstream answered our allocation query: if it brought no pool of its own,
+ * allocate the output buffers from pinned memory */
+static gboolean
+element_decide_allocation (GstBaseTransform * base, GstQuery * query)
+{
+  GstMiBayerElement *self = ELEMENT (base);
+
+  if (self->pinned_pool && gst_query_get_n_allocation_pools (query) == 0) {
+    GstCaps *caps = NULL;
+    gsize size = 0;
+
+    gst_query_parse_allocation (query, &caps, NULL);
+    if (caps != NULL && element_get_unit_size (base, caps, &size)) {
+      guint min = (guint) (self->capacity > 0 ? self->capacity + 1 : 2);
+      GstBufferPool *pool =
+          element_make_pinned_pool (self, caps, (guint) size, min);
+
+      if (pool) {
+        gst_query_add_allocation_pool (query, pool, (guint) size, min, 0);
+        gst_object_unref (pool);
+        EL_DEBUG (self, "using a pinned output pool");
+      }
+    }
+  }
+  return BASE_CLASS (self)->decide_allocation (base, query);
+}
+
+/* ---- data flow -------------------------------------------------------------------- */
+
+/* map both buffers and hand the frame to the GPU pool; on success the mapped
+ * frame is appended to self->pending */
+static GstFlowReturn
+element_submit (GstMiBayerElement * self, GstBuffer * inbuf, GstBuffer * outbuf,
+    gboolean owns_outbuf)
+{
+  const gboolean inverse = IS_INVERSE (self);
+  GstBuffer *mosaic_buf = inverse ? outbuf : inbuf;
+  GstBuffer *video_buf = inverse ? inbuf : outbuf;
+  PendingFrame *p = g_new0 (PendingFrame, 1);
+  const guint8 *src;
+  guint8 *dst;
+  int rc;
+
+  if (!gst_buffer_map (mosaic_buf, &p->mosaic,
+          inverse ? GST_MAP_WRITE : GST_MAP_READ)) {
+    g_free (p);
+    return GST_FLOW_CUSTOM_ERROR;       /* map failure: see callers */
+  }
+  if (!gst_video_frame_map (&p->video, &self->info, video_buf,
+          inverse ? GST_MAP_READ : GST_MAP_WRITE)) {
+    gst_buffer_unmap (mosaic_buf, &p->mosaic);
+    g_free (p);
+    return GST_FLOW_CUSTOM_ERROR;
+  }
+  if (p->mosaic.size < (gsize) GST_ROUND_UP_4 (self->width) * self->height) {
+    GST_ELEMENT_ERROR (self, STREAM, FORMAT,
+        ("%s: short %s buffer", LABEL (self), inverse ? "output" : "input"),
+        ("%" G_GSIZE_FORMAT " bytes for %dx%d", p->mosaic.size, self->width,
+            self->height));
+    goto fail;
+  }
+  if (!element_ensure_pool (self, GST_VIDEO_FRAME_PLANE_STRIDE (&p->video, 0)))
+    goto fail;
+
+  if (inverse) {
+    src = GST_VIDEO_FRAME_PLANE_DATA (&p->video, 0);
+    dst = p->mosaic.data;
+  } else {
+    src = p->mosaic.data;
+    dst = GST_VIDEO_FRAME_PLANE_DATA (&p->video, 0);
+  }
+  /* the call that replaces gst_bayer2rgb_process (gstbayer2rgb.c:475-477) /
+   * the pixel loop of gst_rgb2bayer_transform (gstrgb2bayer.c:254-268) */
+  rc = mibayer_pool_submit (self->pool, src, dst, p);
+  if (rc != MIBAYER_OK) {
+    post_gpu_failure (self, rc);
+    goto fail;
+  }
+  p->inbuf = gst_buffer_ref (inbuf);
+  p->outbuf = outbuf;
+  p->mosaic_buf = mosaic_buf;
+  p->owns_outbuf = owns_outbuf;
+  g_queue_push_tail (&self->pending, p);
+  return GST_FLOW_OK;
+
+fail:
+  gst_video_frame_unmap (&p->video);
+  gst_buffer_unmap (mosaic_buf, &p->mosaic);
+  g_free (p);
+  return GST_FLOW_ERROR;
+}
+
+/* oldest frame: wait for the GPU, unmap, hand the output buffer back */
+static GstFlowReturn
+element_collect (GstMiBayerElement * self, GstBuffer ** outbuf)
+{
+  PendingFrame *p = g_queue_pop_head (&self->pending);
+  int rc;
+
+  *outbuf = NULL;
+  if (p == NULL)
+    return GST_FLOW_OK;
+  rc = mibayer_pool_wait (self->pool, NULL);
+  if (rc != MIBAYER_OK) {
+    pending_release (p, FALSE);
+    post_gpu_failure (self, rc);
+    return GST_FLOW_ERROR;
+  }
+  *outbuf = p->outbuf;
+  pending_release (p, TRUE);
+  return GST_FLOW_OK;
+}
+
+/* reference gstbayer2rgb.c:456-487, gstrgb2bayer.c:230-278 -- synchronous mode,
+ * the default */
+static GstFlowReturn
+element_transform (GstBaseTransform * base, GstBuffer * inbuf,
+    GstBuffer * outbuf)
+{
+  GstMiBayerElement *self = ELEMENT (base);
+  GstFlowReturn ret;
+  GstBuffer *done = NULL;
+
+  EL_DEBUG (self, "transforming buffer");
+
+  ret = element_submit (self, inbuf, outbuf, FALSE);
+  if (ret == GST_FLOW_CUSTOM_ERROR) {
+    /* same as the reference: warn and skip (gstbayer2rgb.c:484-486,
+     * gstrgb2bayer.c:274-276) */
+    EL_WARNING (self, "Could not map buffer, skipping");
+    return GST_FLOW_OK;
+  }
+  if (ret != GST_FLOW_OK)
+    return ret;
+  return element_collect (self, &done);   /* done == outbuf, still owned by the base class */
+}
+
+/* queued mode: take the input the base class parked in queued_buf, submit it,
+ * and release the oldest frame once the pool is full */
+static GstFlowReturn
+element_generate_output (GstBaseTransform * base, GstBuffer ** outbuf)
+{
+  GstMiBayerElement *self = ELEMENT (base);
+  GstBaseTransformClass *klass = GST_BASE_TRANSFORM_GET_CLASS (base);
+  GstBuffer *inbuf;
+
+  if (!element_is_queued_mode (self))
+    return BASE_CLASS (self)->generate_output (base, outbuf);
+
+  *outbuf = NULL;
+  inbuf = base->queued_buf;
+  base->queued_buf = NULL;
+  if (inbuf != NULL) {
+    GstBuffer *out = NULL;
+    GstFlowReturn ret = klass->prepare_output_buffer (base, inbuf, &out);
+
+    if (ret != GST_FLOW_OK || out == NULL) {
+      gst_buffer_unref (inbuf);
+      return ret == GST_FLOW_OK ? GST_FLOW_ERROR : ret;
+    }
+    ret = element_submit (self, inbuf, out, TRUE);
+    gst_buffer_unref (inbuf);           /* the pending entry holds its own ref */
+    if (ret == GST_FLOW_CUSTOM_ERROR) {
+      EL_WARNING (self, "Could not map buffer, skipping");
+      gst_buffer_unref (out);
+      return GST_FLOW_OK;
+    }
+    if (ret != GST_FLOW_OK) {
+      gst_buffer_unref (out);
+      return ret;
+    }
+  }
+  if (self->capacity > 0
+      && (gint) g_queue_get_length (&self->pending) >= self->capacity)
+    return element_collect (self, outbuf);
+  return GST_FLOW_OK;
+}
+
+static gboolean
+element_sink_event (GstBaseTransform * base, GstEvent * event)
+{
+  GstMiBayerElement *self = ELEMENT (base);
+
+  switch (GST_EVENT_TYPE (event)) {
+    case GST_EVENT_CAPS:
+    case GST_EVENT_EOS:
+    case GST_EVENT_SEGMENT:
+    case GST_EVENT_GAP:
+      /* frames in flight precede the event */
+      element_drain (self, TRUE);
+      break;
+    case GST_EVENT_FLUSH_STOP:
+      element_drain (self, FALSE);
+      break;
+    default:
+      break;
+  }
+  return BASE_CLASS (self)->sink_event (base, event);
+}
+
+/* queued mode holds up to `capacity` frames back: report that to live pipelines */
+static gboolean
+element_query (GstBaseTransform * base, GstPadDirection direction,
+    GstQuery * query)
+{
+  GstMiBayerElement *self = ELEMENT (base);
+
+  if (direction == GST_PAD_SRC && GST_QUERY_TYPE (query) == GST_QUERY_LATENCY
+      && element_is_queued_mode (self)) {
+    gboolean live = FALSE;
+    GstClockTime min = 0, max = GST_CLOCK_TIME_NONE;
+    gint fps_n = GST_VIDEO_INFO_FPS_N (&self->info);
+    gint fps_d = GST_VIDEO_INFO_FPS_D (&self->info);
+
+    if (!gst_pad_peer_query (GST_BASE_TRANSFORM_SINK_PAD (base), query))
+      return FALSE;
+    gst_query_parse_latency (query, &live, &min, &max);
+    if (fps_n > 0 && fps_d > 0) {
+      GstClockTime held =
+          gst_util_uint64_scale_int (GST_SECOND * (guint64) (self->inflight
+              * element_ndevices (self)), fps_d, fps_n);
+
+      min += held;
+      if (GST_CLOCK_TIME_IS_VALID (max))
+        max += held;
+      EL_DEBUG (self, "queued mode adds %" GST_TIME_FORMAT " latency",
+          GST_TIME_ARGS (held));
+    }
+    gst_query_set_latency (query, live, min, max);
+    return TRUE;
+  }
+  return BASE_CLASS (self)->query (base, direction, query);
+}
+
+static gboolean
+element_stop (GstBaseTransform * base)
+{
+  element_drop_pool (ELEMENT (base));
+  return TRUE;
+}
+
+/* ---- set-up called by the two concrete types -------------------------------------- */
+
+void
+gst_mi_bayer_element_class_setup (GstMiBayerElementClass * klass,
+    gboolean inverse, const gchar * label)
+{
+  GObjectClass *object_class = G_OBJECT_CLASS (klass);
+  GstBaseTransformClass *transform_class = GST_BASE_TRANSFORM_CLASS (klass);
+
+  klass->cat = NULL;
+  GST_DEBUG_CATEGORY_INIT (klass->cat, label, 0,
+      inverse ? "rgb2bayer element" : "bayer2rgb element");
+  klass->base_class = g_type_class_peek_parent (klass);
+  klass->inverse = inverse;
+  klass->label = label;
+
+  object_class->set_property = element_set_property;
+  object_class->get_property = element_get_property;
+  object_class->finalize = element_finalize;
+
+  g_object_class_install_property (object_class, PROP_DEVICE_ID,
+      g_param_spec_int ("device-id", "Device ID",
+          "HIP ordinal of the MI355X that converts this stream", 0, G_MAXINT,
+          DEFAULT_DEVICE_ID, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (object_class, PROP_DEVICES,
+      g_param_spec_string ("devices", "Devices",
+          "Comma-separated HIP ordinals; frames are sharded round-robin over "
+          "them (frame g -> devices[g % N]); empty = device-id only", NULL,
+          G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (object_class, PROP_INFLIGHT,
+      g_param_spec_int ("inflight", "Frames in flight",
+          "Frames in flight per device; 1 = strictly synchronous 1-in/1-out "
+          "like the stock element, more = queued mode (adds latency)", 1, 16,
+          DEFAULT_INFLIGHT, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (object_class, PROP_HIPGRAPH,
+      g_param_spec_boolean ("hipgraph", "hipGraph per frame",
+          "Run each frame's upload/kernel/download chain as one instantiated "
+          "hipGraph (bayer2rgb direction)", DEFAULT_HIPGRAPH,
+          G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (object_class, PROP_PINNED_POOL,
+      g_param_spec_boolean ("pinned-pool", "Pinned buffer pools",
+          "Propose hipHostMalloc-pinned buffer pools upstream and use them "
+          "downstream when no other pool is offered", DEFAULT_PINNED_POOL,
+          G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+
+  transform_class->transform_caps = GST_DEBUG_FUNCPTR (element_transform_caps);
+  transform_class->get_unit_size = GST_DEBUG_FUNCPTR (element_get_unit_size);
+  transform_class->set_caps = GST_DEBUG_FUNCPTR (element_set_caps);
+  transform_class->transform = GST_DEBUG_FUNCPTR (element_transform);
+  transform_class->generate_output =
+      GST_DEBUG_FUNCPTR (element_generate_output);
+  transform_class->sink_event = GST_DEBUG_FUNCPTR (element_sink_event);
+  transform_class->query = GST_DEBUG_FUNCPTR (element_query);
+  transform_class->propose_allocation =
+      GST_DEBUG_FUNCPTR (element_propose_allocation);
+  transform_class->decide_allocation =
+      GST_DEBUG_FUNCPTR (element_decide_allocation);
+  transform_class->stop = GST_DEBUG_FUNCPTR (element_stop);
+}
+
+void
+gst_mi_bayer_element_instance_setup (GstMiBayerElement * self)
+{
+  element_clear_negotiation (self);
+  self->device_id = DEFAULT_DEVICE_ID;
+  self->devices = NULL;
+  self->inflight = DEFAULT_INFLIGHT;
+  self->use_hipgraph = DEFAULT_HIPGRAPH;
+  self->pinned_pool = DEFAULT_PINNED_POOL;
+  self->pool = NULL;
+  self->pool_stride = 0;
+  self->capacity = 0;
+  g_queue_init (&self->pending);
+}

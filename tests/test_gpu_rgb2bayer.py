@@ -62,18 +62,20 @@ def test_round_trip_4k_batch_is_identity(gpu_pkg):
 
 
 @needs_gst
-def test_rgb2bayer_element_and_plugin_round_trip(plugin, gpu_pkg, oracle, tmp_path):
+@pytest.mark.parametrize("props", ["", "inflight=3", "inflight=2 devices=0,0 pinned-pool=false"])
+def test_rgb2bayer_element_and_plugin_round_trip(plugin, gpu_pkg, oracle, tmp_path, props):
     """videotestsrc ARGB -> rgb2bayer -> bayer2rgb through one pipeline; the mosaic equals the oracle's
     rgb2bayer of the ARGB frames and the final RGBx equals the oracle's bayer2rgb of that mosaic
     (the reference's own pipeline test for this element only asserts EOS:
-    tests/check/elements/autovideoconvert.c:98-110)."""
-    w, h, n = 320, 240, 3
+    tests/check/elements/autovideoconvert.c:98-110).  With `inflight` > 1 / `devices` the element runs the same
+    queued mode as bayer2rgb: every frame arrives, in order, and the tail is drained at EOS."""
+    w, h, n = 320, 240, 7 if props else 3
     argb, mosaic, rgb = (str(tmp_path / f) for f in ("argb.raw", "mosaic.raw", "rgb.raw"))
     pipeline = ("videotestsrc num-buffers=%d ! video/x-raw,format=ARGB,width=%d,height=%d,framerate=30/1 "
-                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! rgb2bayer "
+                "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! rgb2bayer %s "
                 "! video/x-bayer,format=grbg ! tee name=u u. ! queue ! filesink location=%s "
                 "u. ! queue ! bayer2rgb ! video/x-raw,format=RGBx ! filesink location=%s"
-                % (n, w, h, argb, mosaic, rgb))
+                % (n, w, h, argb, props, mosaic, rgb))
     res = subprocess.run([GST_LAUNCH, "-q"] + pipeline.split(), capture_output=True, text=True,
                          env=gst_env(tmp_path), timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]

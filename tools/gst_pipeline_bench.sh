@@ -10,11 +10,32 @@ W=3840; H=2160
 run () {
   local t0=$(date +%s.%N)
   /opt/conda/bin/gst-launch-1.0 -q fakesrc num-buffers=$1 sizetype=fixed sizemax=$((W*H)) filltype=nothing \
-     ! video/x-bayer,format=rggb,width=$W,height=$H,framerate=0/1 ! $2 ! video/x-raw,format=BGRx ! fakesink sync=false >/dev/null 2>&1
+     ! video/x-bayer,format=rggb,width=$W,height=$H,framerate=0/1 ! $2 ! "${3:-video/x-raw,format=BGRx}" ! fakesink sync=false >/dev/null 2>&1
   local t1=$(date +%s.%N)
   echo "$t0 $t1" | awk '{print $2-$1}'
 }
-for mode in "bayer2rgb" "bayer2rgb inflight=2" "bayer2rgb inflight=4" "bayer2rgb inflight=3 devices=0,0" "bayer2rgb inflight=4 hipgraph=true" "bayer2rgb pinned-pool=false" "identity"; do
+line () {   # label, elapsed(20 frames), elapsed(N+20 frames)
+  echo "$1 | $2 $3 $N" | awk -F'|' '{split($2,v," "); dt=v[2]-v[1]; printf "%-44s %7.1f fps  %8.1f Mpix/s  (%.3f s for %d frames)\n", $1, v[3]/dt, v[3]*3840*2160/dt/1e6, dt, v[3]}'
+}
+# device-resident output (rank 4 of SURVEY 8(f)): only the 1 B/px mosaic crosses PCIe
+DEV='video/x-raw(memory:HIPMemory),format=BGRx'
+a=$(run 20 "hipupload ! hipbayer2rgb" "$DEV"); b=$(run $((N+20)) "hipupload ! hipbayer2rgb" "$DEV")
+line "hipupload ! hipbayer2rgb (stays on GPU)" $a $b
+a=$(run 20 "hipupload ! hipbayer2rgb ! hipdownload"); b=$(run $((N+20)) "hipupload ! hipbayer2rgb ! hipdownload")
+line "hipupload ! hipbayer2rgb ! hipdownload" $a $b
+# the inverse element: 4 B/px in, 1 B/px out
+run_inv () {
+  local t0=$(date +%s.%N)
+  /opt/conda/bin/gst-launch-1.0 -q fakesrc num-buffers=$1 sizetype=fixed sizemax=$((W*H*4)) filltype=nothing \
+     ! video/x-raw,format=ARGB,width=$W,height=$H,framerate=0/1 ! $2 ! video/x-bayer,format=rggb ! fakesink sync=false >/dev/null 2>&1
+  local t1=$(date +%s.%N)
+  echo "$t0 $t1" | awk '{print $2-$1}'
+}
+for mode in "rgb2bayer" "rgb2bayer inflight=4"; do
+  a=$(run_inv 20 "$mode"); b=$(run_inv $((N+20)) "$mode")
+  line "$mode" $a $b
+done
+for mode in "bayer2rgb" "bayer2rgb inflight=2" "bayer2rgb inflight=4" "bayer2rgb inflight=3 devices=0,0" "bayer2rgb inflight=4 hipgraph=true" "bayer2rgb pinned-pool=false"; do
   a=$(run 20 "$mode"); b=$(run $((N+20)) "$mode")
   echo "$mode | $a $b $N" | awk -F'|' '{split($2,v," "); dt=v[2]-v[1]; printf "%-44s %7.1f fps  %8.1f Mpix/s  (%.3f s for %d frames)\n", $1, v[3]/dt, v[3]*3840*2160/dt/1e6, dt, v[3]}'
 done
