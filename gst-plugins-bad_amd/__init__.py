@@ -6,7 +6,7 @@ The product is native code:
                   (csrc/mibayer_kernels.hip, csrc/mibayer_abi.hip)
   libgstbayer.so  GStreamer plugin `bayer`, element `bayer2rgb`: registration, pad templates and
                   caps negotiation identical to reference gst/bayer/gstbayer2rgb.c, `transform`
-                  calling the C ABI (gst/gstbayer2rgb.c)
+                  calling the C ABI (gst/gstmibayerelement.c)
 
 This Python module is only the ctypes harness that tests/ and bench.py use to drive the C ABI
 (the directory name is not an importable identifier; load it through

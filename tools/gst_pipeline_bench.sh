@@ -14,13 +14,14 @@ run () {
   local t1=$(date +%s.%N)
   echo "$t0 $t1" | awk '{print $2-$1}'
 }
-line () {   # label, elapsed(20 frames), elapsed(N+20 frames)
-  echo "$1 | $2 $3 $N" | awk -F'|' '{split($2,v," "); dt=v[2]-v[1]; printf "%-44s %7.1f fps  %8.1f Mpix/s  (%.3f s for %d frames)\n", $1, v[3]/dt, v[3]*3840*2160/dt/1e6, dt, v[3]}'
+line () {   # label, elapsed(20 frames), elapsed(n+20 frames), n (default N)
+  echo "$1 | $2 $3 ${4:-$N}" | awk -F'|' '{split($2,v," "); dt=v[2]-v[1]; printf "%-44s %7.1f fps  %8.1f Mpix/s  (%.3f s for %d frames)\n", $1, v[3]/dt, v[3]*3840*2160/dt/1e6, dt, v[3]}'
 }
 # device-resident output (rank 4 of SURVEY 8(f)): only the 1 B/px mosaic crosses PCIe
 DEV='video/x-raw(memory:HIPMemory),format=BGRx'
-a=$(run 20 "hipupload ! hipbayer2rgb" "$DEV"); b=$(run $((N+20)) "hipupload ! hipbayer2rgb" "$DEV")
-line "hipupload ! hipbayer2rgb (stays on GPU)" $a $b
+# (ten times the frames: this pipeline is fast enough for process start-up noise to matter)
+a=$(run 20 "hipupload ! hipbayer2rgb" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb" "$DEV")
+line "hipupload ! hipbayer2rgb (stays on GPU)" $a $b $((10*N))
 a=$(run 20 "hipupload ! hipbayer2rgb ! hipdownload"); b=$(run $((N+20)) "hipupload ! hipbayer2rgb ! hipdownload")
 line "hipupload ! hipbayer2rgb ! hipdownload" $a $b
 # the inverse element: 4 B/px in, 1 B/px out
