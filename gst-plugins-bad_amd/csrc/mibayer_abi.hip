@@ -1043,7 +1043,7 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
   int best_band = keep_band;
   float best_ms = 0.f;
   size_t used = 0;
-  const int reps = 4;
+  const int warmup = 2, reps = 8;       /* ~25 ms for six candidates at 4K x 64 */
   for (int si = 0; si < nshapes; si++) {
     for (int bi = 0; bi < nbands; bi++) {
       c->var = shapes[si];
@@ -1051,7 +1051,7 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
         c->band_override = bands[bi];
       float ms = 0.f;
       int rc = mibayer_time_device (c, d_src, src_frame_bytes, d_dst,
-          dst_frame_bytes, nframes, 1, reps, &ms);
+          dst_frame_bytes, nframes, warmup, reps, &ms);
       if (rc != MIBAYER_OK) {
         c->var = keep_var;
         c->band_override = keep_band;
