@@ -272,8 +272,9 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
   p.map = make_tile_map (g.tiles_x, g.tiles_y, g.tile_rows, g.band);
   /* Start delay (DESIGN.md "start delay"): with a band map every workgroup
    * sleeps ~1.5k cycles before its first load.  Measured +3..5 points of HBM
-   * peak on every box for the chunk-per-XCD order (it thins the number of
-   * requests in flight; halving the occupancy instead costs 10 points), nothing
+   * peak on every box for the chunk-per-XCD order (the previous workgroup's
+   * stores drain before the new loads reach the L2, profiles/r01_delay_counters.md;
+   * halving the occupancy instead costs 10 points), nothing
    * for the identity order, and pure latency for launches that do not even fill
    * the machine once -- so only grids of more than 4 workgroups per CU slot get it. */
   if (c->start_sleep < 0)

@@ -250,7 +250,9 @@ bayer2rgb_lds_kernel (KParams p)
   const TileId tile = block_to_tile (blockIdx.x, p.map);
   if (!tile.valid)
     return;
-  /* start delay: thins the requests in flight; +3..5 points of HBM
+  /* start delay: lets the store burst of the workgroup that just
+   * retired on this CU drain before this one's loads reach the L2 (input-FIFO-full
+   * cycles drop 5-9x, profiles/r01_delay_counters.md); +3..5 points of HBM
    * peak for the band / chunk block orders.  Measured alternatives that lost:
    * the same delay after the barrier or after the stores, a per-workgroup
    * stagger, lower occupancy (profiles/r01_sweep_start_delay.log). */
