@@ -1039,36 +1039,57 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
   const int bands[3] = { 1, -1, 0 };
   const int nbands = band_forced ? 1 : 3;
 
-  const Variant *keep_var = c->var, *best_var = c->var;
+  const Variant *keep_var = c->var;
   const int keep_band = c->band_override;
+  /* The candidates are timed in interleaved rounds after a common warm-up and
+   * each keeps its best round: an idle GPU needs some milliseconds to clock up
+   * (the first candidate used to lose for that reason alone), and a slow round
+   * (another process, a DVFS step) must not decide the plan. */
+  const int kRounds = 3, kWarm = 24, kReps = 6;
+  float cand_ms[6];
+  for (float &m : cand_ms)
+    m = 0.f;
+  int rc = MIBAYER_OK;
+  float ms = 0.f;
+  rc = mibayer_time_device (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes,
+      nframes, 0, kWarm, &ms);
+  for (int round = 0; round < kRounds && rc == MIBAYER_OK; round++) {
+    for (int si = 0; si < nshapes && rc == MIBAYER_OK; si++) {
+      for (int bi = 0; bi < nbands && rc == MIBAYER_OK; bi++) {
+        c->var = shapes[si];
+        if (!band_forced)
+          c->band_override = bands[bi];
+        rc = mibayer_time_device (c, d_src, src_frame_bytes, d_dst,
+            dst_frame_bytes, nframes, 1, kReps, &ms);
+        float &best = cand_ms[si * 3 + bi];
+        if (rc == MIBAYER_OK && (best == 0.f || ms < best))
+          best = ms;
+      }
+    }
+  }
+  if (rc != MIBAYER_OK) {
+    c->var = keep_var;
+    c->band_override = keep_band;
+    return rc;
+  }
+  const Variant *best_var = keep_var;
   int best_band = keep_band;
   float best_ms = 0.f;
   size_t used = 0;
-  const int warmup = 2, reps = 8;       /* ~25 ms for six candidates at 4K x 64 */
   for (int si = 0; si < nshapes; si++) {
     for (int bi = 0; bi < nbands; bi++) {
-      c->var = shapes[si];
-      if (!band_forced)
-        c->band_override = bands[bi];
-      float ms = 0.f;
-      int rc = mibayer_time_device (c, d_src, src_frame_bytes, d_dst,
-          dst_frame_bytes, nframes, warmup, reps, &ms);
-      if (rc != MIBAYER_OK) {
-        c->var = keep_var;
-        c->band_override = keep_band;
-        return rc;
-      }
+      const float m = cand_ms[si * 3 + bi];
       if (report && used < report_len) {
         int n = snprintf (report + used, report_len - used, "%s%s/band%d=%.4fms",
-            used ? " " : "", c->var->name, band_forced ? keep_band : bands[bi],
-            ms);
+            used ? " " : "", shapes[si]->name,
+            band_forced ? keep_band : bands[bi], m);
         if (n > 0)
           used += (size_t) n;
       }
-      if (best_ms == 0.f || ms < best_ms) {
-        best_ms = ms;
-        best_var = c->var;
-        best_band = c->band_override;
+      if (best_ms == 0.f || m < best_ms) {
+        best_ms = m;
+        best_var = shapes[si];
+        best_band = band_forced ? keep_band : bands[bi];
       }
     }
   }
