@@ -3,6 +3,7 @@
  * the demosaic -- with plain and non-temporal stores.  Build: hipcc --offload-arch=gfx950 -O3
  * tools/hbm_probe.hip -o tools/hbm_probe */
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
@@ -70,6 +71,8 @@ int main (int argc, char **argv)
   const size_t in_bytes = out_bytes / 4;
   const int reps = argc > 1 ? atoi (argv[1]) : 20;
   const int only_grid = argc > 2 ? atoi (argv[2]) : 0;
+  const char *only = argc > 3 ? argv[3] : NULL;       /* one kernel only: read, fill, fill_nt, copy, ... */
+  auto want = [&] (const char *name) { return only == NULL || strcmp (only, name) == 0; };
   uint8_t *a, *b; uint32_t *sink;
   CK (hipMalloc (&a, out_bytes)); CK (hipMalloc (&b, out_bytes)); CK (hipMalloc (&sink, 4));
   CK (hipMemset (a, 1, out_bytes)); CK (hipMemset (b, 2, out_bytes));
@@ -79,20 +82,34 @@ int main (int argc, char **argv)
       continue;
     dim3 grid (g), blk (256);
     double t;
-    t = time_ms ([&] { hipLaunchKernelGGL (k_read, grid, blk, 0, 0, (const u32x4 *) a, out_bytes / 16, sink); }, reps);
-    printf ("grid %6d  read        %8.1f GB/s\n", g, out_bytes / t / 1e6);
-    t = time_ms ([&] { hipLaunchKernelGGL (k_fill<false>, grid, blk, 0, 0, (u32x4 *) a, out_bytes / 16); }, reps);
-    printf ("grid %6d  fill        %8.1f GB/s\n", g, out_bytes / t / 1e6);
-    t = time_ms ([&] { hipLaunchKernelGGL (k_fill<true>, grid, blk, 0, 0, (u32x4 *) a, out_bytes / 16); }, reps);
-    printf ("grid %6d  fill_nt     %8.1f GB/s\n", g, out_bytes / t / 1e6);
-    t = time_ms ([&] { hipLaunchKernelGGL (k_copy<false>, grid, blk, 0, 0, (u32x4 *) b, (const u32x4 *) a, out_bytes / 16); }, reps);
-    printf ("grid %6d  copy        %8.1f GB/s (r+w)\n", g, 2.0 * out_bytes / t / 1e6);
-    t = time_ms ([&] { hipLaunchKernelGGL (k_copy<true>, grid, blk, 0, 0, (u32x4 *) b, (const u32x4 *) a, out_bytes / 16); }, reps);
-    printf ("grid %6d  copy_nt     %8.1f GB/s (r+w)\n", g, 2.0 * out_bytes / t / 1e6);
-    t = time_ms ([&] { hipLaunchKernelGGL (k_mix14<false>, grid, blk, 0, 0, (u32x4 *) b, (const uint32_t *) a, in_bytes / 4); }, reps);
-    printf ("grid %6d  mix1r4w     %8.1f GB/s (r+w)   <- bayer2rgb traffic shape\n", g, (in_bytes + out_bytes) / t / 1e6);
-    t = time_ms ([&] { hipLaunchKernelGGL (k_mix14<true>, grid, blk, 0, 0, (u32x4 *) b, (const uint32_t *) a, in_bytes / 4); }, reps);
-    printf ("grid %6d  mix1r4w_nt  %8.1f GB/s (r+w)\n", g, (in_bytes + out_bytes) / t / 1e6);
+    if (want ("read")) {
+      t = time_ms ([&] { hipLaunchKernelGGL (k_read, grid, blk, 0, 0, (const u32x4 *) a, out_bytes / 16, sink); }, reps);
+      printf ("grid %6d  read        %8.1f GB/s\n", g, out_bytes / t / 1e6);
+    }
+    if (want ("fill")) {
+      t = time_ms ([&] { hipLaunchKernelGGL (k_fill<false>, grid, blk, 0, 0, (u32x4 *) a, out_bytes / 16); }, reps);
+      printf ("grid %6d  fill        %8.1f GB/s\n", g, out_bytes / t / 1e6);
+    }
+    if (want ("fill_nt")) {
+      t = time_ms ([&] { hipLaunchKernelGGL (k_fill<true>, grid, blk, 0, 0, (u32x4 *) a, out_bytes / 16); }, reps);
+      printf ("grid %6d  fill_nt     %8.1f GB/s\n", g, out_bytes / t / 1e6);
+    }
+    if (want ("copy")) {
+      t = time_ms ([&] { hipLaunchKernelGGL (k_copy<false>, grid, blk, 0, 0, (u32x4 *) b, (const u32x4 *) a, out_bytes / 16); }, reps);
+      printf ("grid %6d  copy        %8.1f GB/s (r+w)\n", g, 2.0 * out_bytes / t / 1e6);
+    }
+    if (want ("copy_nt")) {
+      t = time_ms ([&] { hipLaunchKernelGGL (k_copy<true>, grid, blk, 0, 0, (u32x4 *) b, (const u32x4 *) a, out_bytes / 16); }, reps);
+      printf ("grid %6d  copy_nt     %8.1f GB/s (r+w)\n", g, 2.0 * out_bytes / t / 1e6);
+    }
+    if (want ("mix1r4w")) {
+      t = time_ms ([&] { hipLaunchKernelGGL (k_mix14<false>, grid, blk, 0, 0, (u32x4 *) b, (const uint32_t *) a, in_bytes / 4); }, reps);
+      printf ("grid %6d  mix1r4w     %8.1f GB/s (r+w)   <- bayer2rgb traffic shape\n", g, (in_bytes + out_bytes) / t / 1e6);
+    }
+    if (want ("mix1r4w_nt")) {
+      t = time_ms ([&] { hipLaunchKernelGGL (k_mix14<true>, grid, blk, 0, 0, (u32x4 *) b, (const uint32_t *) a, in_bytes / 4); }, reps);
+      printf ("grid %6d  mix1r4w_nt  %8.1f GB/s (r+w)\n", g, (in_bytes + out_bytes) / t / 1e6);
+    }
   }
   hipDeviceProp_t p; CK (hipGetDeviceProperties (&p, 0));
   printf ("device %s  CUs %d  memClk %d kHz  busWidth %d  -> %.0f GB/s nominal\n", p.name, p.multiProcessorCount,
