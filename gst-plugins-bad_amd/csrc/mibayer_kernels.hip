@@ -191,11 +191,12 @@ __device__ __forceinline__ u32x4 merge_rows (const Lines &u, const Lines &c,
 
 /* ST = cache policy of the 16-byte output stores (the output is never re-read):
  * 0 plain, 1 nt (streaming hint), 2 sc1, 3 sc0 sc1 (write-through, line dropped
- * from the XCD L2), 4 nt sc1 */
-template <int ST, bool GENERIC>
+ * from the XCD L2), 4 nt sc1; + 8 = nt hint on the LDS kernel's row loads too */
+template <int STLD, bool GENERIC>
 __device__ __forceinline__ void store_pixels (uint8_t *p, u32x4 px,
     int lastmode)
 {
+  constexpr int ST = STLD & 7;  /* bit 3 = nt hint on the tile's row loads */
   if constexpr (!GENERIC) {
     if constexpr (ST == 1)
       __builtin_nontemporal_store (px, (u32x4 *) p);
@@ -283,7 +284,10 @@ bayer2rgb_lds_kernel (KParams p)
         const uint8_t *g = src
             + (size_t) map_row (y, p.height, p.dn_last) * p.src_stride
             + tile_x + c;
-        v[i] = *(const u32x4 *) g;
+        if constexpr ((ST & 8) != 0)
+          v[i] = __builtin_nontemporal_load ((const u32x4 *) g);
+        else
+          v[i] = *(const u32x4 *) g;
       }
     }
 #pragma unroll
@@ -671,6 +675,8 @@ static const Variant kVariants[] = {
    * per-tile kernels in the same interleaved run (profiles/r01_sweep_persistent.log) */
   PERSIST_VARIANT ("persist_4x2_r4_nt", 4, 2, 4, 1),
   PERSIST_VARIANT ("persist_1x8_r4_nt", 1, 8, 4, 1),
+  /* nt hint on the row loads as well (the mosaic is read once per XCD) */
+  LDS_VARIANT ("lds_4x2_r4_dpp_nt_ldnt", 4, 2, 4, 0, 9, true),
 };
 
 int variant_count ()
