@@ -191,12 +191,13 @@ __device__ __forceinline__ u32x4 merge_rows (const Lines &u, const Lines &c,
 
 /* ST = cache policy of the 16-byte output stores (the output is never re-read):
  * 0 plain, 1 nt (streaming hint), 2 sc1, 3 sc0 sc1 (write-through, line dropped
- * from the XCD L2), 4 nt sc1; + 8 = nt hint on the LDS kernel's row loads too */
+ * from the XCD L2), 4 nt sc1; + 8 = nt hint on the LDS kernel's row loads too,
+ * + 16 = direct-to-LDS row loads */
 template <int STLD, bool GENERIC>
 __device__ __forceinline__ void store_pixels (uint8_t *p, u32x4 px,
     int lastmode)
 {
-  constexpr int ST = STLD & 7;  /* bit 3 = nt hint on the tile's row loads */
+  constexpr int ST = STLD & 7;  /* bit 3 = nt hint on the tile's row loads, bit 4 = direct-to-LDS loads */
   if constexpr (!GENERIC) {
     if constexpr (ST == 1)
       __builtin_nontemporal_store (px, (u32x4 *) p);
@@ -268,7 +269,32 @@ bayer2rgb_lds_kernel (KParams p)
   const int tid = threadIdx.x;
 
   /* ---- stage rows tile_y-1 .. tile_y+TR (through map_row) into LDS ---------- */
-  if constexpr (!GENERIC) {
+  if constexpr (!GENERIC && (ST & 16) != 0) {
+    /* experiment arm: direct global -> LDS loads (global_load_lds_dwordx4), no
+     * staging registers and no ds_write pass.  The LDS destination of such a load
+     * is wave-uniform base + lane * 16, so it needs one wave per 1 KiB tile row:
+     * WX == 4.  Lanes right of the frame skip their load; what their LDS bytes
+     * hold is never used (the last valid lane replaces its right neighbour). */
+    static_assert (WX == 4, "one wave stages one 1024-px row");
+    constexpr int RPP = NTHREADS / 64;    /* rows per pass = waves */
+    constexpr int NPASS = (NROWS + RPP - 1) / RPP;
+    const int c = (tid & 63) * 16;
+    const int rr = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int r = i * RPP + rr;
+      const int y = tile_y - 1 + r;
+      if (r < NROWS && y <= p.height && tile_x + c < p.width) {
+        const uint8_t *g = src
+            + (size_t) map_row (y, p.height, p.dn_last) * p.src_stride
+            + tile_x + c;
+        __builtin_amdgcn_global_load_lds (
+            (const __attribute__ ((address_space (1))) void *) g,
+            (__attribute__ ((address_space (3))) void *) &lds[r * PITCH + MAIN],
+            16, 0, 0);
+      }
+    }
+  } else if constexpr (!GENERIC) {
     constexpr int TPR = TW / 16;          /* threads per row, 16 B each */
     constexpr int RPP = NTHREADS / TPR;   /* rows per pass */
     constexpr int NPASS = (NROWS + RPP - 1) / RPP;
@@ -677,6 +703,8 @@ static const Variant kVariants[] = {
   PERSIST_VARIANT ("persist_1x8_r4_nt", 1, 8, 4, 1),
   /* nt hint on the row loads as well (the mosaic is read once per XCD) */
   LDS_VARIANT ("lds_4x2_r4_dpp_nt_ldnt", 4, 2, 4, 0, 9, true),
+  /* direct global -> LDS row loads (no staging registers, no ds_write pass) */
+  LDS_VARIANT ("lds_4x2_r4_dpp_nt_glds", 4, 2, 4, 0, 17, true),
 };
 
 int variant_count ()

@@ -3,7 +3,7 @@
 set +e
 R=${GRAFT_REPO_ROOT:-$PWD}
 rocm-smi --showserial 2>/dev/null | grep Serial
-for v in 1 3 13 8 4 14 10 16; do
+for v in ${VARIANTS:-1 3 13 8 4 14 10 16}; do
   python $R/bench.py --steps 14000 --warmup 20 --no-cpu --no-host-path --no-autotune --variant $v > /tmp/bench_load.json 2>/dev/null &
   P=$!
   sleep 5
