@@ -122,6 +122,11 @@ ABI = {
     "mibayer_dev_free": (None, [ctypes.c_int, _vp]),
     "mibayer_dev_upload": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_size_t]),
     "mibayer_dev_download": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_size_t]),
+    "mibayer_dev_event_create": (_vp, [ctypes.c_int]),
+    "mibayer_dev_event_destroy": (None, [ctypes.c_int, _vp]),
+    "mibayer_dev_event_record": (ctypes.c_int, [ctypes.c_int, _vp, _vp]),
+    "mibayer_dev_event_wait": (ctypes.c_int, [ctypes.c_int, _vp]),
+    "mibayer_dev_stream_wait_event": (ctypes.c_int, [ctypes.c_int, _vp, _vp]),
     "mibayer_fill_synthetic": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_uint32,
                                               ctypes.c_int, ctypes.c_uint32, _vp]),
     "mibayer_variant_count": (ctypes.c_int, []),

@@ -1222,6 +1222,70 @@ extern "C" int mibayer_dev_download (int device, void *dst, const void *d_src,
   return MIBAYER_OK;
 }
 
+extern "C" void *mibayer_dev_event_create (int device)
+{
+  if (device < 0 || device >= device_count_cached ())
+    return NULL;
+  DeviceGuard guard (device);
+  if (!guard.ok)
+    return NULL;
+  hipEvent_t ev = nullptr;
+  if (hip_failed (hipEventCreateWithFlags (&ev, hipEventDisableTiming),
+          "hipEventCreate"))
+    return NULL;
+  return (void *) ev;
+}
+
+extern "C" void mibayer_dev_event_destroy (int device, void *event)
+{
+  if (!event || device < 0 || device >= device_count_cached ())
+    return;
+  DeviceGuard guard (device);
+  (void) hipEventDestroy ((hipEvent_t) event);
+}
+
+extern "C" int mibayer_dev_event_record (int device, void *event,
+    void *hip_stream)
+{
+  if (!event)
+    return MIBAYER_ERR_ARG;
+  if (device < 0 || device >= device_count_cached ())
+    return MIBAYER_ERR_NO_DEVICE;
+  DeviceGuard guard (device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  HIP_TRY (hipEventRecord ((hipEvent_t) event, (hipStream_t) hip_stream));
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_dev_event_wait (int device, void *event)
+{
+  if (!event)
+    return MIBAYER_ERR_ARG;
+  if (device < 0 || device >= device_count_cached ())
+    return MIBAYER_ERR_NO_DEVICE;
+  DeviceGuard guard (device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  HIP_TRY (hipEventSynchronize ((hipEvent_t) event));
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_dev_stream_wait_event (int device, void *hip_stream,
+    void *event)
+{
+  if (!event)
+    return MIBAYER_ERR_ARG;
+  if (device < 0 || device >= device_count_cached ())
+    return MIBAYER_ERR_NO_DEVICE;
+  DeviceGuard guard (device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  HIP_TRY (hipStreamWaitEvent ((hipStream_t) hip_stream, (hipEvent_t) event,
+          0));
+  return MIBAYER_OK;
+}
+
 extern "C" int mibayer_fill_synthetic (mibayer_ctx *c, void *d_src,
     size_t src_frame_bytes, uint32_t first_frame, int nframes, uint32_t seed,
     void *hip_stream)

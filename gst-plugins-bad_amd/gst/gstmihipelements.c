@@ -544,6 +544,7 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
   GstMemory *out_mem = buffer_hip_memory (outbuf);
   GstMapInfo in_map, out_map;
   GstFlowReturn ret = GST_FLOW_OK;
+  gpointer stream;
   int rc;
 
   if (!in_mem || !out_mem || !self->ctx) {
@@ -551,17 +552,33 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
         ("hipbayer2rgb needs HIP device memory on both pads"), (NULL));
     return GST_FLOW_ERROR;
   }
-  if (!gst_memory_map (in_mem, &in_map, GST_MAP_READ | GST_MAP_HIP))
+  /* Stream-ordered, no host round trip: the launch is ordered after whatever
+   * was last queued on the two memories, and both are marked with an event
+   * after it.  The next user either orders its own stream after that event or
+   * -- any plain map, hipdownload, a CPU map -- waits for it on the host. */
+  stream = mibayer_ctx_stream (self->ctx);
+  if (!gst_memory_map (in_mem, &in_map,
+          GST_MAP_READ | GST_MAP_HIP | GST_MAP_HIP_ASYNC))
     return GST_FLOW_ERROR;
-  if (!gst_memory_map (out_mem, &out_map, GST_MAP_WRITE | GST_MAP_HIP)) {
+  if (!gst_memory_map (out_mem, &out_map,
+          GST_MAP_WRITE | GST_MAP_HIP | GST_MAP_HIP_ASYNC)) {
     gst_memory_unmap (in_mem, &in_map);
     return GST_FLOW_ERROR;
   }
+  if (!gst_mi_hip_memory_order_after ((GstMiHipMemory *) in_mem, stream)
+      || !gst_mi_hip_memory_order_after ((GstMiHipMemory *) out_mem, stream)) {
+    /* could not order on the device: fall back to waiting on the host */
+    gst_mi_hip_memory_wait ((GstMiHipMemory *) in_mem);
+    gst_mi_hip_memory_wait ((GstMiHipMemory *) out_mem);
+  }
   /* device-resident call: no PCIe traffic at all */
   rc = mibayer_process_device (self->ctx, in_map.data, 0, out_map.data, 0, 1,
-      mibayer_ctx_stream (self->ctx));
-  if (rc == MIBAYER_OK)
-    rc = mibayer_sync (self->ctx);
+      stream);
+  if (rc == MIBAYER_OK
+      && !(gst_mi_hip_memory_mark_access ((GstMiHipMemory *) in_mem, stream)
+          && gst_mi_hip_memory_mark_access ((GstMiHipMemory *) out_mem,
+              stream)))
+    rc = mibayer_sync (self->ctx);      /* no event: finish before anyone looks */
   if (rc != MIBAYER_OK) {
     GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
         ("hipbayer2rgb: GPU conversion failed"),

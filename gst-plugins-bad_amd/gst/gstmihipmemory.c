@@ -47,6 +47,9 @@ gst_mi_hip_allocator_free (GstAllocator * allocator, GstMemory * memory)
 {
   GstMiHipMemory *m = (GstMiHipMemory *) memory;
 
+  gst_mi_hip_memory_wait (m);   /* no GPU work may outlive the allocation */
+  if (m->access_event)
+    mibayer_dev_event_destroy (m->device, m->access_event);
   if (m->staging)
     mibayer_host_free (m->staging);
   mibayer_dev_free (m->device, m->d_ptr);
@@ -60,6 +63,10 @@ gst_mi_hip_mem_map_full (GstMemory * memory, GstMapInfo * info, gsize maxsize)
   GstMiHipMemory *m = (GstMiHipMemory *) memory;
   gpointer ret = NULL;
 
+  /* GPU work queued by an earlier user must have finished, unless the caller
+   * orders its own stream after it (gst_mi_hip_memory_order_after) */
+  if (!(info->flags & GST_MAP_HIP_ASYNC) && !gst_mi_hip_memory_wait (m))
+    return NULL;
   if (info->flags & GST_MAP_HIP)
     return m->d_ptr;            /* device access: the caller orders its own GPU work */
 
@@ -103,6 +110,54 @@ gst_mi_hip_mem_unmap_full (GstMemory * memory, GstMapInfo * info)
     m->cpu_dirty = FALSE;
   }
   g_mutex_unlock (&m->lock);
+}
+
+gboolean
+gst_mi_hip_memory_wait (GstMiHipMemory * m)
+{
+  gboolean ok = TRUE;
+
+  g_mutex_lock (&m->lock);
+  if (m->access_pending) {
+    ok = mibayer_dev_event_wait (m->device, m->access_event) == MIBAYER_OK;
+    if (ok)
+      m->access_pending = FALSE;
+    else
+      GST_ERROR ("waiting for queued GPU work failed: %s",
+          mibayer_last_hip_error ());
+  }
+  g_mutex_unlock (&m->lock);
+  return ok;
+}
+
+gboolean
+gst_mi_hip_memory_order_after (GstMiHipMemory * m, gpointer hip_stream)
+{
+  gboolean ok = TRUE;
+
+  g_mutex_lock (&m->lock);
+  if (m->access_pending)
+    ok = mibayer_dev_stream_wait_event (m->device, hip_stream,
+        m->access_event) == MIBAYER_OK;
+  g_mutex_unlock (&m->lock);
+  return ok;
+}
+
+gboolean
+gst_mi_hip_memory_mark_access (GstMiHipMemory * m, gpointer hip_stream)
+{
+  gboolean ok;
+
+  g_mutex_lock (&m->lock);
+  if (m->access_event == NULL)
+    m->access_event = mibayer_dev_event_create (m->device);
+  ok = m->access_event != NULL
+      && mibayer_dev_event_record (m->device, m->access_event,
+      hip_stream) == MIBAYER_OK;
+  if (ok)
+    m->access_pending = TRUE;
+  g_mutex_unlock (&m->lock);
+  return ok;
 }
 
 static GstMemory *

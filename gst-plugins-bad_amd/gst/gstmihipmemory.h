@@ -19,6 +19,10 @@ G_BEGIN_DECLS
  * DEVICE pointer in info.data; without it the memory is staged through pinned
  * host memory (download on map for READ, upload on unmap after WRITE) */
 #define GST_MAP_HIP (GST_MAP_FLAG_LAST << 1)
+/* A memory carries a "last access" event (see gst_mi_hip_memory_mark_access).  Any map waits for it on the host, so a
+ * consumer that knows nothing about it is always safe; a consumer that orders its own stream after the event with
+ * gst_mi_hip_memory_order_after () adds this flag to GST_MAP_HIP to skip the host wait. */
+#define GST_MAP_HIP_ASYNC (GST_MAP_FLAG_LAST << 2)
 
 typedef struct _GstMiHipMemory GstMiHipMemory;
 
@@ -31,6 +35,8 @@ struct _GstMiHipMemory
   GMutex lock;
   gint cpu_maps;                /* outstanding CPU maps */
   gboolean cpu_dirty;           /* a CPU WRITE map is outstanding */
+  gpointer access_event;        /* HIP event of the last GPU access queued on this memory, created on first use */
+  gboolean access_pending;      /* that event has not been waited for on the host yet */
 };
 
 GType gst_mi_hip_allocator_get_type (void);
@@ -41,6 +47,16 @@ gboolean gst_is_mi_hip_memory (GstMemory * mem);
 GstMemory *gst_mi_hip_memory_new (gint device, gsize size);
 /* buffers of one GstMiHipMemory each; size comes from the pool config */
 GstBufferPool *gst_mi_hip_pool_new (gint device);
+
+/* Stream-ordered hand-over.  A user that queues GPU work touching `mem` on `hip_stream` and does not wait for it:
+ *   gst_mi_hip_memory_order_after (mem, stream);     before queueing: the work starts after the last queued access
+ *   ... queue the work on stream ...
+ *   gst_mi_hip_memory_mark_access (mem, stream);     after queueing: later users will be ordered after this work
+ * mark_access returns FALSE if the event could not be recorded; the caller must then synchronise the stream itself. */
+gboolean gst_mi_hip_memory_order_after (GstMiHipMemory * mem, gpointer hip_stream);
+gboolean gst_mi_hip_memory_mark_access (GstMiHipMemory * mem, gpointer hip_stream);
+/* host waits until the last queued access has completed */
+gboolean gst_mi_hip_memory_wait (GstMiHipMemory * mem);
 
 G_END_DECLS
 #endif

@@ -232,6 +232,17 @@ int mibayer_dev_upload (int device, void *d_dst, const void *src, size_t bytes);
 int mibayer_dev_download (int device, void *dst, const void *d_src,
     size_t bytes);
 
+/* Context-free events, for stream-ordered hand-over of a device buffer from one
+ * user to the next without a host round trip (GstMiHipMemory carries one as
+ * its "last access" marker): record after the work that touches the buffer,
+ * make the next user's stream wait for it -- or block the host on it. */
+void *mibayer_dev_event_create (int device);
+void mibayer_dev_event_destroy (int device, void *event);
+int mibayer_dev_event_record (int device, void *event,
+    void *hip_stream /* used as given */);
+int mibayer_dev_event_wait (int device, void *event);          /* host blocks */
+int mibayer_dev_stream_wait_event (int device, void *hip_stream, void *event);
+
 /* Counter-based synthetic mosaic generated on the device (stateless per byte;
  * definition in DESIGN.md "Synthetic input"): frames first_frame ..
  * first_frame+nframes-1 with the context's width/height/src_stride. */

@@ -49,6 +49,25 @@ def test_upload_convert_download_pipeline(plugin, gpu_pkg, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_stream_ordered_handover_survives_buffer_recycling(plugin, gpu_pkg, oracle, tmp_path):
+    """hipbayer2rgb does not wait for its kernel: it marks both memories with a "last access" event.  With 24 frames
+    through pools of a few buffers, a `queue` between the elements (the converter runs ahead of the downloader) and
+    every memory recycled several times, each frame must still be the right one: hipupload's WRITE map waits for the
+    kernel that still reads a recycled input, hipdownload's READ map for the kernel that writes its input."""
+    w, h, n = 1280, 720, 24
+    inp, outp = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
+    res = launch(tmp_path,
+                 "videotestsrc num-buffers=%d pattern=snow ! video/x-bayer,format=gbrg,width=%d,height=%d,framerate=30/1 "
+                 "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! hipupload ! hipbayer2rgb ! queue "
+                 "! hipdownload ! video/x-raw,format=RGBx ! filesink location=%s" % (n, w, h, inp, outp))
+    assert res.returncode == 0, res.stderr[-2000:]
+    src = np.fromfile(inp, np.uint8).reshape(n, h, w)
+    got = np.fromfile(outp, np.uint8).reshape(n, h, 4 * w)
+    want = oracle.bayer2rgb_batch(src, w, "gbrg", 0, 1, 2, nthreads=4)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
 def test_device_memory_is_cpu_mappable_through_staging(plugin, gpu_pkg, oracle, tmp_path):
     """No hipdownload: filesink maps the HIPMemory buffers for READ, which stages them through pinned memory."""
     w, h = 640, 480
