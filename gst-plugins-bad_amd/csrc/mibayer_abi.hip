@@ -62,12 +62,17 @@ struct DeviceGuard {
   }
 };
 
+constexpr int kMaxHostBands = 8;
+
 struct Slot {
   uint8_t *d_src = nullptr;
   uint8_t *d_dst = nullptr;
   hipEvent_t ev_in = nullptr;     /* H2D done   */
   hipEvent_t ev_kernel = nullptr; /* kernel done */
   hipEvent_t ev_out = nullptr;    /* D2H done   */
+  /* banded frames (mibayer_ctx::host_bands > 1): upload / kernel done, per band */
+  hipEvent_t ev_band_in[kMaxHostBands] = {};
+  hipEvent_t ev_band_kernel[kMaxHostBands] = {};
   void *tag = nullptr;
   /* MIBAYER_FLAG_HIPGRAPH: the frame's upload -> kernel -> download chain as one
    * instantiated graph, launched on the slot's own stream */
@@ -109,6 +114,9 @@ struct mibayer_ctx {
                                            set by MIBAYER_XCD_BAND or mibayer_autotune() */
   int num_cus = 256;                    /* hipDeviceProp_t.multiProcessorCount */
   int persist_wgs_per_cu = 4;           /* MIBAYER_PERSIST_WGS (tuning), persistent arms */
+  int host_bands = 1;                   /* host path: horizontal bands a frame is cut into so that
+                                           the upload of band b+1, the kernel of band b and the
+                                           download of band b-1 overlap inside ONE frame */
   int start_sleep = -1;                 /* s_sleep(1) iterations before a workgroup's first load;
                                            -1 = automatic (kStartSleepChunk with a band map on
                                            large grids, else 0); MIBAYER_START_SLEEP overrides */
@@ -239,11 +247,21 @@ constexpr int kStartSleepChunk = 24;    /* x s_sleep(1) = 64 clocks each */
  * grid size */
 static int plan_launch (const mibayer_ctx *c, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
-    KParams &p, KernelFn &kern, unsigned &grid, Geometry *geom = nullptr)
+    KParams &p, KernelFn &kern, unsigned &grid, Geometry *geom = nullptr,
+    long long tile_row0 = 0, long long ntile_rows = -1)
 {
   Geometry g;
   fill_params (c, p, g, d_src, src_frame_bytes, d_dst, dst_frame_bytes,
       nframes);
+  if (ntile_rows >= 0) {        /* one horizontal band of the batch */
+    if (tile_row0 < 0 || tile_row0 + ntile_rows > g.tile_rows)
+      return MIBAYER_ERR_ARG;
+    g.tile_rows = ntile_rows;
+    if (c->band_override == INT32_MIN ? c->var->band < 0 : c->band_override < 0)
+      g.band = (int) ((g.tile_rows + kNumXcd - 1) / kNumXcd);
+  } else {
+    tile_row0 = 0;
+  }
   if (g.tile_rows * g.tiles_x > 0x7fffffffLL)
     return MIBAYER_ERR_GEOMETRY;
   const mibayer_cfg &f = c->cfg;
@@ -269,7 +287,7 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
       return MIBAYER_ERR_GEOMETRY;
     grid = (unsigned) n;
   }
-  p.map = make_tile_map (g.tiles_x, g.tiles_y, g.tile_rows, g.band);
+  p.map = make_tile_map (g.tiles_x, g.tiles_y, g.tile_rows, g.band, tile_row0);
   /* Start delay (DESIGN.md "start delay"): with a band map every workgroup
    * sleeps ~1.5k cycles before its first load.  Measured +3..5 points of HBM
    * peak on every box for the chunk-per-XCD order (the previous workgroup's
@@ -287,9 +305,9 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
 
 static int launch (const mibayer_ctx *c, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
-    hipStream_t stream)
+    hipStream_t stream, long long tile_row0 = 0, long long ntile_rows = -1)
 {
-  if (nframes == 0)
+  if (nframes == 0 || ntile_rows == 0)
     return MIBAYER_OK;
   if (c->inverse) {
     const mibayer_cfg &f = c->cfg;
@@ -319,7 +337,7 @@ static int launch (const mibayer_ctx *c, const void *d_src,
   KernelFn kern;
   unsigned grid;
   int rc = plan_launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes,
-      nframes, p, kern, grid);
+      nframes, p, kern, grid, nullptr, tile_row0, ntile_rows);
   if (rc != MIBAYER_OK)
     return rc;
   hipLaunchKernelGGL (kern, dim3 (grid), dim3 (c->var->threads), 0, stream, p);
@@ -450,6 +468,8 @@ static int validate (const mibayer_cfg *in, mibayer_cfg *out)
   return MIBAYER_OK;
 }
 
+static int choose_host_bands (const mibayer_ctx *c);
+
 extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
 {
   if (!out)
@@ -496,6 +516,7 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
     make_inverse_plan (c);
   else
     make_plan (c);
+  c->host_bands = choose_host_bands (c);
 
   DeviceGuard guard (dev);
   if (!guard.ok) {
@@ -534,6 +555,12 @@ static void free_ring (mibayer_ctx *c)
       (void) hipEventDestroy (s.ev_kernel);
     if (s.ev_out)
       (void) hipEventDestroy (s.ev_out);
+    for (int b = 0; b < kMaxHostBands; b++) {
+      if (s.ev_band_in[b])
+        (void) hipEventDestroy (s.ev_band_in[b]);
+      if (s.ev_band_kernel[b])
+        (void) hipEventDestroy (s.ev_band_kernel[b]);
+    }
     if (s.exec)
       (void) hipGraphExecDestroy (s.exec);
     if (s.graph)
@@ -657,6 +684,12 @@ static int ensure_ring (mibayer_ctx *c)
             hipEventDisableTiming), "hipEventCreate");
     bad |= hip_failed (hipEventCreateWithFlags (&s.ev_out,
             hipEventDisableTiming), "hipEventCreate");
+    for (int b = 0; b < c->host_bands && c->host_bands > 1; b++) {
+      bad |= hip_failed (hipEventCreateWithFlags (&s.ev_band_in[b],
+              hipEventDisableTiming), "hipEventCreate");
+      bad |= hip_failed (hipEventCreateWithFlags (&s.ev_band_kernel[b],
+              hipEventDisableTiming), "hipEventCreate");
+    }
     if (bad) {
       free_ring (c);
       return MIBAYER_ERR_HIP;
@@ -732,8 +765,87 @@ static int graph_submit (mibayer_ctx *c, Slot &s, const uint8_t *src,
   return MIBAYER_OK;
 }
 
+/* Host path, one frame cut into horizontal bands: band b's kernel needs source
+ * rows y0-1 .. y1 (one halo row above and below), so upload chunk b carries the
+ * band's rows plus the row below it, and the chunks run down the frame in one
+ * queue.  With the three queues of the ring, the download of band b-1 (4 B/px,
+ * the long pole: PCIe is full duplex) overlaps the upload of band b+1 and the
+ * kernel of band b inside ONE frame -- the synchronous 1-in/1-out element mode
+ * gets most of what the queued mode gets from overlapping whole frames.
+ * Bands are whole tile rows; the bottom-edge rule dn(H-1) = H-4
+ * (gstbayer2rgb.c:430-447) needs the last band to hold at least 4 rows. */
+static int choose_host_bands (const mibayer_ctx *c)
+{
+  int want = 4;
+  if (const char *e = getenv ("MIBAYER_HOST_BANDS"))
+    want = atoi (e);
+  if (want > kMaxHostBands)
+    want = kMaxHostBands;
+  if (want < 2 || c->inverse || c->var->persistent
+      || c->dst_bytes < ((size_t) 16 << 20))    /* below ~4K the extra enqueues cost more
+                                                   than the overlap gains (1080p: -10 %) */
+    return 1;
+  const int th = c->var->tile_h;
+  const int tiles_y = (c->cfg.height + th - 1) / th;
+  while (want > 1) {
+    const int per = (tiles_y + want - 1) / want;        /* tile rows per band */
+    const int nb = (tiles_y + per - 1) / per;           /* bands actually needed */
+    const int last_y0 = (nb - 1) * per * th;
+    if (nb == want && per * th >= 8 && c->cfg.height - last_y0 >= 4)
+      return want;
+    want--;
+  }
+  return 1;
+}
+
+static int enqueue_frame_banded (mibayer_ctx *c, Slot &s, const uint8_t *src,
+    uint8_t *dst, size_t row_bytes)
+{
+  const mibayer_cfg &f = c->cfg;
+  const int th = c->var->tile_h;
+  const int tiles_y = (f.height + th - 1) / th;
+  const int nb = c->host_bands;
+  const int per = (tiles_y + nb - 1) / nb;
+  int uploaded = 0;             /* source rows already queued for upload */
+  for (int b = 0; b < nb; b++) {
+    const int t0 = b * per;
+    const int t1 = t0 + per < tiles_y ? t0 + per : tiles_y;
+    const int y0 = t0 * th;
+    const int y1 = t1 * th < f.height ? t1 * th : f.height;
+    const int up_to = y1 + 1 < f.height ? y1 + 1 : f.height;   /* + the halo row below */
+    if (up_to > uploaded) {
+      const size_t off = (size_t) uploaded * f.src_stride;
+      HIP_TRY (hipMemcpyAsync (s.d_src + off, src + off,
+              (size_t) (up_to - uploaded) * f.src_stride, hipMemcpyHostToDevice,
+              c->s_h2d));
+      uploaded = up_to;
+    }
+    HIP_TRY (hipEventRecord (s.ev_band_in[b], c->s_h2d));
+    HIP_TRY (hipStreamWaitEvent (c->s_compute, s.ev_band_in[b], 0));
+    int rc = launch (c, s.d_src, c->src_bytes, s.d_dst, c->dst_bytes, 1,
+        c->s_compute, t0, t1 - t0);
+    if (rc != MIBAYER_OK)
+      return rc;
+    HIP_TRY (hipEventRecord (s.ev_band_kernel[b], c->s_compute));
+    HIP_TRY (hipStreamWaitEvent (c->s_d2h, s.ev_band_kernel[b], 0));
+    const size_t doff = (size_t) y0 * f.dst_stride;
+    if ((size_t) f.dst_stride == row_bytes) {
+      HIP_TRY (hipMemcpyAsync (dst + doff, s.d_dst + doff,
+              (size_t) (y1 - y0) * f.dst_stride, hipMemcpyDeviceToHost,
+              c->s_d2h));
+    } else {
+      /* padded destination rows: only the written bytes of each row */
+      HIP_TRY (hipMemcpy2DAsync (dst + doff, (size_t) f.dst_stride,
+              s.d_dst + doff, (size_t) f.dst_stride, row_bytes,
+              (size_t) (y1 - y0), hipMemcpyDeviceToHost, c->s_d2h));
+    }
+  }
+  HIP_TRY (hipEventRecord (s.ev_out, c->s_d2h));
+  return MIBAYER_OK;
+}
+
 static int enqueue_frame (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
-    void *tag)
+    void *tag, bool alone)
 {
   int rc = ensure_ring (c);
   if (rc != MIBAYER_OK)
@@ -746,6 +858,17 @@ static int enqueue_frame (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
   if ((c->cfg.flags & MIBAYER_FLAG_HIPGRAPH) && !c->inverse
       && (size_t) c->cfg.dst_stride == row_bytes) {
     rc = graph_submit (c, s, src, dst);
+    if (rc != MIBAYER_OK)
+      return rc;
+    s.tag = tag;
+    c->head = (c->head + 1) % (int) c->ring.size ();
+    c->pending++;
+    return MIBAYER_OK;
+  }
+  /* bands pay when this frame has the link to itself (measured at 4K: +7 %
+   * synchronous, -6 % with three frames in flight, which overlap anyway) */
+  if (c->host_bands > 1 && alone && c->pending == 0) {
+    rc = enqueue_frame_banded (c, s, src, dst, row_bytes);
     if (rc != MIBAYER_OK)
       return rc;
     s.tag = tag;
@@ -785,9 +908,9 @@ static int enqueue_frame (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
  * refused) must not leave work behind that still touches the caller's buffers
  * after the error has been returned: drain whatever was queued. */
 static int submit_locked (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
-    void *tag)
+    void *tag, bool alone)
 {
-  const int rc = enqueue_frame (c, src, dst, tag);
+  const int rc = enqueue_frame (c, src, dst, tag, alone);
   if (rc != MIBAYER_OK && rc != MIBAYER_ERR_BUSY) {
     char keep[sizeof t_hip_error];
     memcpy (keep, t_hip_error, sizeof keep);    /* report the first error */
@@ -823,7 +946,8 @@ extern "C" int mibayer_submit (mibayer_ctx *c, const uint8_t *src,
   DeviceGuard guard (c->device);
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
-  return submit_locked (c, src, dst, tag);
+  /* a ring of one frame is the synchronous 1-in/1-out use */
+  return submit_locked (c, src, dst, tag, c->cfg.inflight == 1);
 }
 
 extern "C" int mibayer_wait (mibayer_ctx *c, void **tag)
@@ -851,7 +975,7 @@ extern "C" int mibayer_process_host (mibayer_ctx *c, const uint8_t *src,
   DeviceGuard guard (c->device);
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
-  int rc = submit_locked (c, src, dst, NULL);
+  int rc = submit_locked (c, src, dst, NULL, true);
   if (rc != MIBAYER_OK)
     return rc;
   return wait_locked (c, NULL);

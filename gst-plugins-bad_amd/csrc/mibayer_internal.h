@@ -55,12 +55,14 @@ struct TileMap {
   FastDiv tiles_x;              /* tiles per tile row                           */
   FastDiv tiles_y;              /* tile rows per frame                          */
   FastDiv per_group;            /* band * tiles_x                               */
-  uint32_t tile_rows;           /* nframes * tiles_y                            */
+  uint32_t tile_rows;           /* tile rows of this launch (nframes * tiles_y, or
+                                   the rows of one horizontal band of one frame) */
+  uint32_t row0;                /* first tile row of this launch (0 unless a band) */
   int band;                     /* tile rows per XCD band; 0 = identity map     */
 };
 
 struct TileId {
-  uint32_t row;                 /* tile row in the batch */
+  uint32_t row;                 /* tile row in the batch (TileMap.row0 included) */
   uint32_t tx;
   bool valid;
 };
@@ -81,6 +83,7 @@ __host__ __device__ inline TileId block_to_tile (uint32_t block, const TileMap &
     t.row = (group * kNumXcd + xcd) * (uint32_t) m.band + r_local;
   }
   t.valid = t.row < m.tile_rows;
+  t.row += m.row0;
   return t;
 }
 
@@ -91,6 +94,7 @@ __host__ __device__ inline TileId linear_to_tile (uint32_t tile, const TileMap &
   t.row = fastdiv (tile, m.tiles_x);
   t.tx = tile - t.row * m.tiles_x.d;
   t.valid = t.row < m.tile_rows;
+  t.row += m.row0;
   return t;
 }
 
@@ -104,7 +108,7 @@ inline long long grid_blocks_for (int tiles_x, long long tile_rows, int band)
 }
 
 inline TileMap make_tile_map (int tiles_x, int tiles_y, long long tile_rows,
-    int band)
+    int band, long long row0 = 0)
 {
   TileMap m;
   m.tiles_x = make_fastdiv ((uint32_t) tiles_x);
@@ -112,6 +116,7 @@ inline TileMap make_tile_map (int tiles_x, int tiles_y, long long tile_rows,
   m.per_group = make_fastdiv ((uint32_t) (band > 0 ? band : 1)
       * (uint32_t) tiles_x);
   m.tile_rows = (uint32_t) tile_rows;
+  m.row0 = (uint32_t) row0;
   m.band = band;
   return m;
 }

@@ -114,6 +114,39 @@ def test_strides_and_padding(gpu_pkg, oracle):
         assert np.array_equal(ctx.process_host(src), ctx.process_host(src2))
 
 
+@pytest.mark.parametrize("bands", ["", "1", "3", "8"], ids=["default", "1", "3", "8"])
+def test_banded_synchronous_host_path(gpu_pkg, oracle, bands, monkeypatch):
+    """Frames of 16 MB and more go through the synchronous host path in horizontal bands (upload of band b+1, kernel
+    of band b and download of band b-1 overlap inside one frame).  Every band count gives the reference's bytes: the
+    halo rows across band boundaries, the top row (up(0) = 1) and the bottom rows (dn(H-1) = H-4) included; heights
+    that are no multiple of the tile height; padded destination rows (2-D download); the queued use of the same
+    context (which does not band) in between."""
+    if bands:
+        monkeypatch.setenv("MIBAYER_HOST_BANDS", bands)
+    else:
+        monkeypatch.delenv("MIBAYER_HOST_BANDS", raising=False)
+    rng = np.random.default_rng(40)
+    for (w, h, pat, fmt, pad) in ((3840, 2160, "rggb", "BGRx", 0), (2048, 2053, "gbrg", "xRGB", 0),
+                                  (2560, 1666, "grbg", "RGBx", 64)):
+        r, g, b = gpu_pkg.FORMATS[fmt]
+        src = rng.integers(0, 256, (h, (w + 3) & ~3), dtype=np.uint8)
+        want = oracle.bayer2rgb(src, w, pat, r, g, b)
+        with gpu_pkg.Context(w, h, pat, fmt, dst_stride=4 * w + pad, inflight=2) as ctx:
+            for _ in range(2):
+                got = ctx.process_host(src)
+                assert np.array_equal(got[:, :4 * w], want), (w, h, pat, fmt, bands)
+                if pad:
+                    assert (got[:, 4 * w:] == 0xA5).all()     # padding never written
+            # two frames in flight through the same context: unbanded path, same bytes
+            outs = [np.full((h, 4 * w + pad), 0xA5, np.uint8) for _ in range(2)]
+            for i, o in enumerate(outs):
+                ctx.submit(src, o, tag=i + 1)
+            assert [ctx.wait(), ctx.wait()] == [1, 2]
+            for o in outs:
+                assert np.array_equal(o[:, :4 * w], want)
+            assert np.array_equal(ctx.process_host(src)[:, :4 * w], want)
+
+
 def test_known_md5_answers_full_size(gpu_pkg):
     """BASELINE.json configs 2-4 geometries: md5 of the HIP output equals the md5 the compiled
     reference element produced.  Input is generated ON the device."""
