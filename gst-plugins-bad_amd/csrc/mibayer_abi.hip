@@ -674,10 +674,17 @@ static int ensure_ring (mibayer_ctx *c)
   c->ring.resize ((size_t) c->cfg.inflight);
   for (Slot &s : c->ring) {
     bool bad = false;
-    bad |= hip_failed (hipMalloc ((void **) &s.d_src, c->src_bytes),
-        "hipMalloc");
-    bad |= hip_failed (hipMalloc ((void **) &s.d_dst, c->dst_bytes),
-        "hipMalloc");
+    const hipError_t e_src = hipMalloc ((void **) &s.d_src, c->src_bytes);
+    const hipError_t e_dst = e_src == hipSuccess
+        ? hipMalloc ((void **) &s.d_dst, c->dst_bytes) : e_src;
+    if (e_src == hipErrorOutOfMemory || e_dst == hipErrorOutOfMemory) {
+      (void) hip_failed (hipErrorOutOfMemory, "hipMalloc (frame ring)");
+      (void) hipGetLastError ();
+      free_ring (c);
+      return MIBAYER_ERR_NOMEM;
+    }
+    bad |= hip_failed (e_src, "hipMalloc");
+    bad |= hip_failed (e_dst, "hipMalloc");
     bad |= hip_failed (hipEventCreateWithFlags (&s.ev_in,
             hipEventDisableTiming), "hipEventCreate");
     bad |= hip_failed (hipEventCreateWithFlags (&s.ev_kernel,
