@@ -9,6 +9,9 @@
  *        push every frame of in.raw through the element, then EOS; write every buffer that comes out
  *   element_harness flush <launchline> <sinkcaps> <in.raw> <framebytes> <out.raw> <nbefore>
  *        push <nbefore> frames, FLUSH_START/FLUSH_STOP, push the rest, EOS; write what comes out
+ *   element_harness renegotiate <launchline> <caps1> <in1.raw> <framebytes1> <caps2> <in2.raw> <framebytes2> <out.raw>
+ *        push every frame of in1.raw under caps1, then switch to caps2 mid-stream (a new CAPS event) and push every
+ *        frame of in2.raw, then EOS; write every buffer that comes out (frames in flight precede the new caps)
  *   element_harness states <pipeline> <cycles>
  *        NULL -> PLAYING -> (EOS) -> NULL, <cycles> times, on ONE pipeline instance
  */
@@ -94,6 +97,52 @@ run_harness (int argc, char **argv, int flush_after)
 }
 
 static int
+run_renegotiate (char **argv)
+{
+  const char *launch = argv[2], *out_path = argv[9];
+  GstHarness *h = gst_harness_new_parse (launch);
+  FILE *out = fopen (out_path, "wb");
+  int pushed = 0, pulled = 0, seg, n;
+
+  if (!h || !out) {
+    fprintf (stderr, "setup failed\n");
+    return 2;
+  }
+  for (seg = 0; seg < 2; seg++) {
+    const char *caps = argv[3 + 3 * seg], *in_path = argv[4 + 3 * seg];
+    size_t frame_bytes = (size_t) atol (argv[5 + 3 * seg]);
+    FILE *in = fopen (in_path, "rb");
+    guint8 *frame = g_malloc (frame_bytes);
+
+    if (!in)
+      return 2;
+    gst_harness_set_src_caps_str (h, caps);     /* CAPS event; the second one arrives mid-stream */
+    while (fread (frame, 1, frame_bytes, in) == frame_bytes) {
+      GstBuffer *buf = gst_buffer_new_allocate (NULL, frame_bytes, NULL);
+
+      gst_buffer_fill (buf, 0, frame, frame_bytes);
+      GST_BUFFER_PTS (buf) = (GstClockTime) pushed * GST_SECOND / 30;
+      if (gst_harness_push (h, buf) != GST_FLOW_OK) {
+        fprintf (stderr, "push %d failed\n", pushed);
+        return 3;
+      }
+      pushed++;
+      if ((n = drain_to_file (h, out)) < 0)
+        return 4;
+      pulled += n;
+    }
+    fclose (in);
+    g_free (frame);
+  }
+  gst_harness_push_event (h, gst_event_new_eos ());
+  pulled += drain_to_file (h, out);
+  fprintf (stdout, "pushed=%d pulled=%d\n", pushed, pulled);
+  fclose (out);
+  gst_harness_teardown (h);
+  return 0;
+}
+
+static int
 run_states (const char *desc, int cycles)
 {
   GError *err = NULL;
@@ -143,6 +192,8 @@ main (int argc, char **argv)
     return run_harness (argc, argv, 0);
   if (argc >= 8 && strcmp (argv[1], "flush") == 0)
     return run_harness (argc, argv, atoi (argv[7]));
+  if (argc >= 10 && strcmp (argv[1], "renegotiate") == 0)
+    return run_renegotiate (argv);
   if (argc >= 4 && strcmp (argv[1], "states") == 0)
     return run_states (argv[2], atoi (argv[3]));
   fprintf (stderr, "usage: see the header of element_harness.c\n");

@@ -51,6 +51,28 @@ def test_harness_convert_every_frame_in_order(plugin, gpu_pkg, oracle, harness, 
         assert np.array_equal(got[i], oracle.bayer2rgb(src[i], w, "gbrg", 0, 1, 2)), (launch, i)     # default RGBx
 
 
+@pytest.mark.parametrize("launch", ["bayer2rgb", "bayer2rgb inflight=3", "bayer2rgb inflight=2 devices=0,0"])
+def test_harness_caps_change_mid_stream(plugin, gpu_pkg, oracle, harness, tmp_path, launch):
+    """Resolution AND Bayer order change while the stream runs: the frames still in flight under the old caps come
+    out first (queued mode drains on the CAPS event), the GPU pool is rebuilt for the new geometry, every frame
+    of both halves is converted, in order."""
+    (w1, h1, p1, n1), (w2, h2, p2, n2) = (64, 48, "bggr", 7), (130, 22, "grbg", 6)
+    a = oracle.fill_synthetic(w1, h1, n1, seed=81)
+    b = oracle.fill_synthetic(w2, h2, n2, seed=82, stride=132)
+    fa, fb, outp = tmp_path / "a.raw", tmp_path / "b.raw", tmp_path / "out.raw"
+    a.tofile(fa)
+    b.tofile(fb)
+    kv = run(harness, tmp_path, "renegotiate", launch, CAPS % (p1, w1, h1), fa, w1 * h1,
+             CAPS % (p2, w2, h2), fb, 132 * h2, outp)
+    assert kv["pushed"] == str(n1 + n2) and kv["pulled"] == str(n1 + n2)
+    got = np.fromfile(outp, np.uint8)
+    first, second = got[:n1 * h1 * 4 * w1].reshape(n1, h1, 4 * w1), got[n1 * h1 * 4 * w1:].reshape(n2, h2, 4 * w2)
+    for i in range(n1):
+        assert np.array_equal(first[i], oracle.bayer2rgb(a[i], w1, p1, 0, 1, 2)), (launch, "first", i)
+    for i in range(n2):
+        assert np.array_equal(second[i], oracle.bayer2rgb(b[i], w2, p2, 0, 1, 2)), (launch, "second", i)
+
+
 def test_harness_flush_drops_frames_in_flight(plugin, gpu_pkg, oracle, harness, tmp_path):
     """Queued mode, capacity 4: after 3 buffers nothing has come out; FLUSH_START/STOP must drop those 3;
     the 5 buffers pushed afterwards all come out (the last ones at EOS), and nothing else."""
