@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Development tool: do contexts, pools, rings, graphs and events give their device and pinned memory back?
+Creates / uses / destroys them many times and compares hipMemGetInfo before and after.  Run on the GPU box."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import __graft_entry__ as entry  # noqa: E402
+
+pkg = entry.load_package()
+L = pkg.lib()
+hip = ctypes.CDLL("libamdhip64.so.7")       # already loaded by libmibayer.so: same runtime
+
+
+def free_bytes():
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+    return f.value
+
+
+def rss_kb():
+    for line in open("/proc/self/status"):
+        if line.startswith("VmRSS"):
+            return int(line.split()[1])
+
+
+rng = np.random.default_rng(1)
+w, h = 1920, 1080
+src = rng.integers(0, 256, (h, w), dtype=np.uint8)
+
+
+def one_round(i):
+    flags = (0, pkg.FLAG_HIPGRAPH, pkg.FLAG_RGB2BAYER)[i % 3]
+    if flags == pkg.FLAG_RGB2BAYER:
+        with pkg.Context(w, h, "rggb", "ARGB", inflight=3, flags=flags) as ctx:
+            ctx.process_host(np.zeros((h, 4 * w), np.uint8))
+        return
+    with pkg.Context(w, h, "rggb", "BGRx", inflight=3, flags=flags) as ctx:
+        ctx.process_host(src)
+        outs = [np.empty((h, 4 * w), np.uint8) for _ in range(3)]
+        for k, o in enumerate(outs):
+            ctx.submit(src, o, tag=k + 1)
+        while ctx.pending():
+            ctx.wait()
+        d = ctx.device_alloc(ctx.dst_bytes)
+        ctx.device_free(d)
+    with pkg.Pool([0, 0], w, h, "bggr", "RGBx", inflight=2) as pool:
+        o = np.empty((h, 4 * w), np.uint8)
+        pool.submit(src, o, tag=1)
+        pool.wait()
+    ev = L.mibayer_dev_event_create(0)
+    L.mibayer_dev_event_record(0, ev, None)
+    L.mibayer_dev_event_wait(0, ev)
+    L.mibayer_dev_event_destroy(0, ev)
+    p = L.mibayer_host_alloc(1 << 20)
+    L.mibayer_host_free(p)
+
+
+for i in range(6):
+    one_round(i)                # warm-up: runtime pools, code objects
+f0, r0 = free_bytes(), rss_kb()
+N = 150
+for i in range(N):
+    one_round(i)
+f1, r1 = free_bytes(), rss_kb()
+print("device memory free: before %d B, after %d rounds %d B, delta %+d B" % (f0, N, f1, f1 - f0))
+print("host RSS: before %d kB, after %d kB, delta %+d kB" % (r0, r1, r1 - r0))
