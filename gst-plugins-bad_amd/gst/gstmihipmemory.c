@@ -29,6 +29,8 @@ gst_mi_hip_allocator_obtain (void)
   if (g_once_init_enter (&once)) {
     singleton = g_object_new (gst_mi_hip_allocator_get_type (), NULL);
     gst_object_ref_sink (singleton);
+    /* process-lifetime singleton: not a leak for GST_TRACERS=leaks */
+    GST_OBJECT_FLAG_SET (singleton, GST_OBJECT_FLAG_MAY_BE_LEAKED);
     g_once_init_leave (&once, 1);
   }
   return singleton;

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Development tool: GStreamer's own leak tracer over the elements (GstBuffer / GstMemory / GstObject refcounts).
+# Any "object-alive" line at exit is a leaked object.  Run on the GPU box.
+R=${GRAFT_REPO_ROOT:-$PWD}
+export GST_PLUGIN_SYSTEM_PATH_1_0=/opt/conda/lib/gstreamer-1.0 GST_PLUGIN_PATH_1_0=$R/gst-plugins-bad_amd \
+       GST_PLUGIN_SCANNER=/opt/conda/libexec/gstreamer-1.0/gst-plugin-scanner GST_REGISTRY=/tmp/gst_leaks.reg
+/opt/conda/bin/gst-inspect-1.0 bayer2rgb >/dev/null 2>&1
+B='video/x-bayer,format=rggb,width=640,height=480,framerate=30/1'
+for p in \
+  "videotestsrc num-buffers=40 ! $B ! bayer2rgb ! fakesink" \
+  "videotestsrc num-buffers=40 ! $B ! bayer2rgb inflight=3 ! fakesink" \
+  "videotestsrc num-buffers=40 ! $B ! bayer2rgb inflight=2 devices=0,0 hipgraph=true ! fakesink" \
+  "videotestsrc num-buffers=40 ! video/x-raw,format=ARGB,width=640,height=480 ! rgb2bayer inflight=2 ! bayer2rgb ! fakesink" \
+  "videotestsrc num-buffers=40 ! $B ! hipupload ! hipbayer2rgb ! hipdownload ! fakesink" \
+  "videotestsrc num-buffers=40 ! $B ! hipupload ! hipbayer2rgb ! fakesink"; do
+  out=$(GST_TRACERS=leaks GST_DEBUG=GST_TRACER:7 GST_DEBUG_NO_COLOR=1 /opt/conda/bin/gst-launch-1.0 -q $p 2>&1)
+  rc=$?
+  alive=$(echo "$out" | grep -c "object-alive, type-name=(string)[A-Za-z]")
+  echo "rc=$rc alive=$alive :: $p"
+  echo "$out" | grep "object-alive, type-name=(string)[A-Za-z]" | head -5
+done
