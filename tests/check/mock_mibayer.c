@@ -1,7 +1,8 @@
 /* TEST DOUBLE of libmibayer.so -- NOT a conversion path, NOT shipped, NOT a fallback.
  *
  * The elements of plugin `bayer` (gst-plugins-bad_amd/gst/gstmibayerelement.c) talk to the GPU only through ten
- * entry points of include/mibayer.h.  This file implements exactly those ten with NO demosaic in them, so that
+ * entry points of include/mibayer.h, those of plugin `mihip` through nineteen.  This file implements exactly
+ * those with NO demosaic in them, so that
  * the elements' own logic -- buffer ownership in the synchronous and the queued mode, ordering, draining on
  * EOS / caps / segment events, dropping on flush, pool re-creation on renegotiation -- can be exercised on a
  * machine without a GPU, under AddressSanitizer (tests/test_gst_element_logic.py).
@@ -165,4 +166,213 @@ mibayer_pool_wait (mibayer_pool * p, void **tag)
   if (tag)
     *tag = fr.tag;
   return MIBAYER_OK;
+}
+
+/* ---- the entry points plugin `mihip` uses (device memory, events, device-resident launches) ------------------
+ *
+ * "Device memory" is plain heap.  A launch does nothing when it is queued: it completes only when something
+ * that the real runtime would order after it is waited for on the host -- an event recorded after it
+ * (mibayer_dev_event_wait), or mibayer_sync / mibayer_destroy of its context.  Copies (dev_upload / dev_download)
+ * deliberately do NOT complete pending launches: an element that reads a buffer without honouring its "last
+ * access" event gets the bytes from before the launch, and the stamp check of the test fails.  Freeing memory
+ * that a pending launch still uses aborts. */
+
+#include <pthread.h>
+#include <stdio.h>
+
+#define MOCK_MAX_OPS 4096
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;     /* elements may run in different streaming threads */
+
+typedef struct
+{
+  mibayer_ctx *ctx;
+  const uint8_t *src;
+  uint8_t *dst;
+  uint32_t seq;
+  int done;
+} mock_op;
+
+static mock_op g_ops[MOCK_MAX_OPS];
+static uint32_t g_nops;         /* launches queued so far == sequence number of the next one */
+
+struct mibayer_ctx
+{
+  mibayer_cfg cfg;
+  size_t src_bytes, dst_bytes;
+};
+
+typedef struct
+{
+  uint32_t marker;              /* launches queued before the record */
+} mock_event;
+
+static void
+mock_complete_upto (uint32_t marker, const mibayer_ctx * only)
+{
+  uint32_t i;
+
+  for (i = 0; i < g_nops && i < marker; i++) {
+    mock_op *op = &g_ops[i % MOCK_MAX_OPS];
+    unsigned sum = 0;
+    size_t k;
+
+    if (op->done || (only && op->ctx != only))
+      continue;
+    for (k = 0; k < op->ctx->src_bytes; k++)
+      sum += op->src[k];        /* the source must still be alive */
+    memset (op->dst, op->src[0], op->ctx->dst_bytes);
+    memcpy (op->dst, &op->seq, 4);
+    if (sum == 0xffffffffu)
+      op->dst[4] ^= 1;
+    op->done = 1;
+  }
+}
+
+int
+mibayer_create (const mibayer_cfg * cfg, mibayer_ctx ** out)
+{
+  mibayer_ctx *c;
+
+  if (!cfg || !out || cfg->struct_size != sizeof (*cfg))
+    return MIBAYER_ERR_ARG;
+  if (mibayer_device_count () <= 0)
+    return MIBAYER_ERR_NO_DEVICE;
+  if (cfg->width < 4 || (cfg->width & 1) || cfg->height < 3)
+    return MIBAYER_ERR_GEOMETRY;
+  c = calloc (1, sizeof *c);
+  c->cfg = *cfg;
+  if (c->cfg.src_stride == 0)
+    c->cfg.src_stride = (cfg->width + 3) & ~3;
+  if (c->cfg.dst_stride == 0)
+    c->cfg.dst_stride = 4 * cfg->width;
+  c->src_bytes = (size_t) c->cfg.src_stride * cfg->height;
+  c->dst_bytes = (size_t) c->cfg.dst_stride * cfg->height;
+  *out = c;
+  return MIBAYER_OK;
+}
+
+int
+mibayer_sync (mibayer_ctx * c)
+{
+  if (!c)
+    return MIBAYER_ERR_ARG;
+  pthread_mutex_lock (&g_lock);
+  mock_complete_upto (g_nops, c);
+  pthread_mutex_unlock (&g_lock);
+  return MIBAYER_OK;
+}
+
+void
+mibayer_destroy (mibayer_ctx * c)
+{
+  if (!c)
+    return;
+  mibayer_sync (c);
+  free (c);
+}
+
+void *
+mibayer_ctx_stream (mibayer_ctx * c)
+{
+  return c;                     /* any non-NULL token */
+}
+
+int
+mibayer_process_device (mibayer_ctx * c, const void *d_src,
+    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
+    void *hip_stream)
+{
+  mock_op *op;
+
+  if (!c || !d_src || !d_dst || nframes != 1)
+    return MIBAYER_ERR_ARG;
+  pthread_mutex_lock (&g_lock);
+  op = &g_ops[g_nops % MOCK_MAX_OPS];
+  op->ctx = c;
+  op->src = d_src;
+  op->dst = d_dst;
+  op->seq = g_nops;
+  op->done = 0;
+  g_nops++;
+  pthread_mutex_unlock (&g_lock);
+  return MIBAYER_OK;
+}
+
+void *
+mibayer_dev_alloc (int device, size_t bytes)
+{
+  return device == 0 ? malloc (bytes ? bytes : 1) : NULL;
+}
+
+void
+mibayer_dev_free (int device, void *d_ptr)
+{
+  uint32_t i;
+
+  pthread_mutex_lock (&g_lock);
+  for (i = 0; i < g_nops && i < MOCK_MAX_OPS; i++) {
+    const mock_op *op = &g_ops[i];
+
+    if (!op->done && (op->src == d_ptr || op->dst == d_ptr)) {
+      fprintf (stderr, "mock_mibayer: device memory freed while launch %u still uses it\n", op->seq);
+      abort ();
+    }
+  }
+  pthread_mutex_unlock (&g_lock);
+  free (d_ptr);
+}
+
+int
+mibayer_dev_upload (int device, void *d_dst, const void *src, size_t bytes)
+{
+  memcpy (d_dst, src, bytes);
+  return MIBAYER_OK;
+}
+
+int
+mibayer_dev_download (int device, void *dst, const void *d_src, size_t bytes)
+{
+  memcpy (dst, d_src, bytes);
+  return MIBAYER_OK;
+}
+
+void *
+mibayer_dev_event_create (int device)
+{
+  return calloc (1, sizeof (mock_event));
+}
+
+void
+mibayer_dev_event_destroy (int device, void *event)
+{
+  free (event);
+}
+
+int
+mibayer_dev_event_record (int device, void *event, void *hip_stream)
+{
+  if (!event)
+    return MIBAYER_ERR_ARG;
+  pthread_mutex_lock (&g_lock);
+  ((mock_event *) event)->marker = g_nops;
+  pthread_mutex_unlock (&g_lock);
+  return MIBAYER_OK;
+}
+
+int
+mibayer_dev_event_wait (int device, void *event)
+{
+  if (!event)
+    return MIBAYER_ERR_ARG;
+  pthread_mutex_lock (&g_lock);
+  mock_complete_upto (((mock_event *) event)->marker, NULL);
+  pthread_mutex_unlock (&g_lock);
+  return MIBAYER_OK;
+}
+
+int
+mibayer_dev_stream_wait_event (int device, void *hip_stream, void *event)
+{
+  return event ? MIBAYER_OK : MIBAYER_ERR_ARG;  /* one in-order list of launches: nothing to do */
 }

@@ -48,6 +48,9 @@ def rig(tmp_path_factory):
                                                "gstmibayerelement.c", "gstmihostpool.c")]
     cc(SAN + ["-fPIC", "-shared"] + INC + srcs + ["-o", os.path.join(d, "libgstbayer.so"), "-L" + d, "-lmibayer",
                                                   "-Wl,-rpath," + d] + GSTLIBS)
+    hip = [os.path.join(GSTSRC, f) for f in ("gstmihipelements.c", "gstmihipmemory.c", "gstmihostpool.c")]
+    cc(SAN + ["-fPIC", "-shared"] + INC + hip + ["-o", os.path.join(d, "libgstmihip.so"), "-L" + d, "-lmibayer",
+                                                 "-Wl,-rpath," + d] + GSTLIBS)
     exe = os.path.join(d, "element_harness")
     cc(SAN + INC + [os.path.join(ROOT, "tests", "check", "element_harness.c"), "-o", exe,
                     "%s/lib/libgstcheck-1.0.so" % GST_PREFIX] + GSTLIBS)
@@ -154,6 +157,25 @@ def test_out_of_domain_geometry_and_missing_device_are_errors(rig, tmp_path):
                           str(tmp_path / "o.raw")], capture_output=True, text=True,
                          env=dict(env, MOCK_MIBAYER_DEVICES="0"), timeout=60)
     assert res.returncode != 0 and "AddressSanitizer" not in res.stdout + res.stderr
+
+
+def test_device_memory_elements_honour_the_last_access_event(rig, tmp_path):
+    """hipbayer2rgb queues its launch and marks both memories instead of waiting.  The double completes a launch only
+    when an event recorded after it is waited for (or its context is synchronised) and its copies do not wait for
+    anything, so the right stamps can only come out if hipdownload's map -- and the CPU map of a HIPMemory buffer --
+    wait for the memory's event; freeing memory that a queued launch still uses aborts the double."""
+    w, h, n = 258, 37, 12
+    inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
+    frames(n, 260 * h, first=30).tofile(inp)
+    for launch in ("hipupload ! hipbayer2rgb ! hipdownload", "hipupload ! hipbayer2rgb"):
+        kv = run(rig, "convert", launch, B2R % ("gbrg", w, h), inp, 260 * h, outp)
+        assert kv["pushed"] == str(n) and kv["pulled"] == str(n), launch
+        seq, fill = stamps(outp, n, 4 * w * h)
+        assert fill == list(range(30, 30 + n)), launch
+        assert seq == list(range(n)), launch
+    kv = run(rig, "states", "videotestsrc num-buffers=9 ! video/x-bayer,format=rggb,width=64,height=48 ! hipupload ! "
+             "hipbayer2rgb ! queue ! hipdownload ! fakesink", 3)
+    assert kv["cycles_ok"] == "3"
 
 
 def test_state_cycles(rig):
