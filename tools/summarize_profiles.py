@@ -77,7 +77,7 @@ if stats:
         lines.append("Timed region only (the last 100 bayer2rgb dispatches of the trace = the 100 timed steps, kernel `%s`): "
                      "**avg %.0f ns**, min %d, max %d." % (timed[-1]["Kernel_Name"][:60], sum(d) / len(d), min(d), max(d)))
         lines.append("")
-    lines.append("(calls include the autotune launches of `mibayer_autotune`, which try both tile shapes and both XCD maps; "
+    lines.append("(calls include the autotune launches of `mibayer_autotune`, which try two tile shapes x three block orders in three rounds; "
                  "profiled runs clock ~2 % lower than unprofiled ones, MI355X_MICROARCH.md \"DVFS\")")
     lines.append("")
 
