@@ -64,7 +64,11 @@ int oracle_bayer2rgb_batch (uint8_t *dst, size_t dst_frame_bytes, int dst_stride
  * Padding bytes of a destination row are left untouched, as in the reference.
  * PARITY UNPINNED for this function: the reference element cannot be built
  * here (GStreamer >= 1.20 macros) and its tests hold no vectors for it; the
- * restatement is a line-by-line reading of an 11-line loop. */
+ * restatement is a line-by-line reading of an 11-line loop.  Independent
+ * cross-check of the site -> channel mapping (not of the reference element):
+ * gst-plugins-base's videotestsrc, the GStreamer 1.14 binary of this image,
+ * writes video/x-bayer itself from the ARGB it paints; its mosaic equals this
+ * function of its ARGB frame for all four orders (tests/test_oracle.py). */
 int oracle_rgb2bayer (uint8_t *dst, int dst_stride, const uint8_t *src,
     int src_stride, int width, int height, int pattern, int r_off, int g_off,
     int b_off);

@@ -173,3 +173,36 @@ def test_rgb2bayer_oracle_forms_agree_and_invert_bayer2rgb(oracle):
                 rgb = oracle.bayer2rgb(src, w, pat, r, g, b)
                 back = oracle.rgb2bayer(rgb, w, pat, r, g, b)
                 assert np.array_equal(back[:, :w], S), (w, h, pat, lay)
+
+
+def test_rgb2bayer_oracle_matches_videotestsrc_bayer_writer(oracle, tmp_path):
+    """An independent pin for the CFA-site -> channel mapping of the rgb2bayer oracle: gst-plugins-base's videotestsrc
+    (the GStreamer 1.14 binary of this image, not part of the reference tree) paints every pattern as ARGB and, for
+    video/x-bayer caps, writes the mosaic itself.  For the same pattern and size that mosaic must be exactly
+    rgb2bayer(ARGB frame) for all four orders.  (The reference's rgb2bayer element itself cannot be built here and its
+    tests hold no vectors -- parity with *it* stays unpinned, see bayer2rgb_oracle.h.)"""
+    import subprocess
+    from test_gst_element import GST_LAUNCH, GST_PREFIX
+    if not os.path.exists(GST_LAUNCH):
+        pytest.skip("no GStreamer installation")
+    env = dict(os.environ, GST_PLUGIN_SYSTEM_PATH_1_0=os.path.join(GST_PREFIX, "lib", "gstreamer-1.0"),
+               GST_PLUGIN_SCANNER=os.path.join(GST_PREFIX, "libexec", "gstreamer-1.0", "gst-plugin-scanner"),
+               GST_REGISTRY=str(tmp_path / "registry.bin"))
+    env.pop("GST_PLUGIN_PATH_1_0", None)
+
+    def shoot(pattern, caps, path):
+        res = subprocess.run([GST_LAUNCH, "-q", "videotestsrc", "num-buffers=1", "pattern=" + pattern, "!", caps, "!",
+                              "filesink", "location=" + str(path)], capture_output=True, text=True, env=env, timeout=120)
+        assert res.returncode == 0, res.stderr[-1000:]
+        return np.fromfile(path, np.uint8)
+
+    for (w, h) in ((322, 241), (130, 37), (64, 48)):
+        for pattern in ("smpte", "snow", "pinwheel"):
+            argb = shoot(pattern, "video/x-raw,format=ARGB,width=%d,height=%d" % (w, h), tmp_path / "a.raw")
+            argb = argb.reshape(h, 4 * w)
+            assert len(np.unique(argb)) > 8
+            for order in ("bggr", "gbrg", "grbg", "rggb"):
+                mosaic = shoot(pattern, "video/x-bayer,format=%s,width=%d,height=%d" % (order, w, h),
+                               tmp_path / "m.raw").reshape(h, -1)
+                want = oracle.rgb2bayer(argb, w, order, 1, 2, 3)
+                assert np.array_equal(mosaic[:, :w], want[:, :w]), (w, h, pattern, order)
