@@ -63,6 +63,7 @@ struct DeviceGuard {
 };
 
 constexpr int kMaxHostBands = 8;
+constexpr int kInverseBandUnit = 16;    /* rows; a multiple of every rows-per-block of the rgb2bayer kernel */
 
 struct Slot {
   uint8_t *d_src = nullptr;
@@ -330,7 +331,15 @@ static int launch (const mibayer_ctx *c, const void *d_src,
     }
     const bool vec16 = (f.width % 4 == 0) && (f.src_stride % 16 == 0)
         && aligned16 (d_src) && (nframes == 1 || src_frame_bytes % 16 == 0);
-    HIP_TRY (launch_rgb2bayer (q, vec16, stream));
+    if (ntile_rows >= 0) {      /* band of 16-row units (host path) */
+      const long long y0 = tile_row0 * kInverseBandUnit;
+      long long y1 = (tile_row0 + ntile_rows) * kInverseBandUnit;
+      if (y1 > q.total_rows)
+        y1 = q.total_rows;
+      HIP_TRY (launch_rgb2bayer (q, vec16, stream, y0, y1 - y0));
+    } else {
+      HIP_TRY (launch_rgb2bayer (q, vec16, stream));
+    }
     return MIBAYER_OK;
   }
   KParams p;
@@ -788,11 +797,12 @@ static int choose_host_bands (const mibayer_ctx *c)
     want = atoi (e);
   if (want > kMaxHostBands)
     want = kMaxHostBands;
-  if (want < 2 || c->inverse || c->var->persistent
-      || c->dst_bytes < ((size_t) 16 << 20))    /* below ~4K the extra enqueues cost more
+  const size_t big_side = c->inverse ? c->src_bytes : c->dst_bytes;     /* the 4 B/px frame */
+  if (want < 2 || c->var->persistent
+      || big_side < ((size_t) 16 << 20))        /* below ~4K the extra enqueues cost more
                                                    than the overlap gains (1080p: -10 %) */
     return 1;
-  const int th = c->var->tile_h;
+  const int th = c->inverse ? kInverseBandUnit : c->var->tile_h;
   const int tiles_y = (c->cfg.height + th - 1) / th;
   while (want > 1) {
     const int per = (tiles_y + want - 1) / want;        /* tile rows per band */
@@ -809,7 +819,8 @@ static int enqueue_frame_banded (mibayer_ctx *c, Slot &s, const uint8_t *src,
     uint8_t *dst, size_t row_bytes)
 {
   const mibayer_cfg &f = c->cfg;
-  const int th = c->var->tile_h;
+  const int th = c->inverse ? kInverseBandUnit : c->var->tile_h;
+  const int halo = c->inverse ? 0 : 1;  /* rgb2bayer has no neighbourhood */
   const int tiles_y = (f.height + th - 1) / th;
   const int nb = c->host_bands;
   const int per = (tiles_y + nb - 1) / nb;
@@ -819,7 +830,7 @@ static int enqueue_frame_banded (mibayer_ctx *c, Slot &s, const uint8_t *src,
     const int t1 = t0 + per < tiles_y ? t0 + per : tiles_y;
     const int y0 = t0 * th;
     const int y1 = t1 * th < f.height ? t1 * th : f.height;
-    const int up_to = y1 + 1 < f.height ? y1 + 1 : f.height;   /* + the halo row below */
+    const int up_to = y1 + halo < f.height ? y1 + halo : f.height;     /* + the halo row below */
     if (up_to > uploaded) {
       const size_t off = (size_t) uploaded * f.src_stride;
       HIP_TRY (hipMemcpyAsync (s.d_src + off, src + off,

@@ -175,7 +175,9 @@ struct R2BParams {
   uint32_t sel_lo[2];           /* v_perm selectors per row parity: pixels 0,1 */
   uint32_t sel_hi[2];           /*                                  pixels 2,3 */
 };
-hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream);
+/* rows [row0, row0 + nrows) of the batch (nrows < 0: all); row0 must be a multiple of 16 */
+hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
+    long long row0 = 0, long long nrows = -1);
 
 /* synthetic mosaic generator kernel launcher */
 hipError_t launch_fill_synthetic (uint8_t *d_buf, int width, int height,

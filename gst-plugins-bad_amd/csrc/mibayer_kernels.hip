@@ -815,11 +815,19 @@ rgb2bayer_kernel (R2BParams p)
   }
 }
 
-hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream)
+hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
+    long long row0, long long nrows)
 {
-  if (p.total_rows <= 0 || p.out_dwords <= 0)
+  if (p.total_rows <= 0 || p.out_dwords <= 0 || nrows == 0)
     return hipSuccess;
   R2BParams q = p;
+  if (nrows < 0) {
+    row0 = 0;
+    nrows = p.total_rows;
+  }
+  if (row0 < 0 || (row0 & 15) || row0 + nrows > p.total_rows)
+    return hipErrorInvalidValue;
+  q.total_rows = row0 + nrows;  /* the kernel's "row < total_rows" guard ends the band */
   /* rows per block: 2, with one chunk of the batch per XCD and no start delay,
    * measured best on MI355X in a shuffled A/B (76 % of peak; identity order 73 %,
    * 4 or 8 rows 70-75 %, any start delay worse: this direction is read-dominated;
@@ -831,14 +839,14 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream)
     return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 2;
   } ();
   const int R2B_ROWS = rows_per_block;
-  const long long tile_rows = (p.total_rows + R2B_ROWS - 1) / R2B_ROWS;
+  const long long tile_rows = (nrows + R2B_ROWS - 1) / R2B_ROWS;
   const int tiles_x = (p.out_dwords + 255) / 256;
   if (q.band < 0)               /* one contiguous chunk of tile rows per XCD */
     q.band = (int) ((tile_rows + kNumXcd - 1) / kNumXcd);
   const long long grid = grid_blocks_for (tiles_x, tile_rows, q.band);
   if (grid > 0x7fffffffLL || p.total_rows > 0x7fffffffLL)
     return hipErrorInvalidValue;
-  q.map = make_tile_map (tiles_x, 1, tile_rows, q.band);
+  q.map = make_tile_map (tiles_x, 1, tile_rows, q.band, row0 / R2B_ROWS);
   q.div_height = make_fastdiv ((uint32_t) p.height);
 #define R2B_LAUNCH(V, R) hipLaunchKernelGGL ((rgb2bayer_kernel<V, R>), \
       dim3 ((unsigned) grid), dim3 (256), 0, stream, q)

@@ -28,6 +28,30 @@ def test_rgb2bayer_matches_oracle_all_sizes(gpu_pkg, oracle):
                 assert (got_d[:, w:] == 0).all()         # padding columns are written as zero on the device
 
 
+@pytest.mark.parametrize("bands", ["", "1", "3", "8"], ids=["default", "1", "3", "8"])
+def test_rgb2bayer_banded_synchronous_host_path(gpu_pkg, oracle, bands, monkeypatch):
+    """Frames of 16 MB input and more go through the synchronous host path in horizontal bands (16-row units), like
+    bayer2rgb's: same bytes for every band count, odd heights, padded source rows; queued use stays unbanded."""
+    if bands:
+        monkeypatch.setenv("MIBAYER_HOST_BANDS", bands)
+    else:
+        monkeypatch.delenv("MIBAYER_HOST_BANDS", raising=False)
+    rng = np.random.default_rng(41)
+    for (w, h, pat, pad) in ((3840, 2160, "rggb", 0), (2050, 2053, "gbrg", 0), (2560, 1667, "grbg", 64)):
+        src = rng.integers(0, 256, (h, 4 * w + pad), dtype=np.uint8)
+        want = oracle.rgb2bayer(src, w, pat, 1, 2, 3)
+        with gpu_pkg.Context(w, h, pat, (1, 2, 3), src_stride=4 * w + pad, inflight=2,
+                             flags=gpu_pkg.FLAG_RGB2BAYER) as ctx:
+            for _ in range(2):
+                assert np.array_equal(ctx.process_host(src)[:, :w], want[:, :w]), (w, h, pat, bands)
+            outs = [np.zeros((h, ctx.dst_stride), np.uint8) for _ in range(2)]
+            for i, o in enumerate(outs):
+                ctx.submit(src, o, tag=i + 1)
+            assert [ctx.wait(), ctx.wait()] == [1, 2]
+            for o in outs:
+                assert np.array_equal(o[:, :w], want[:, :w])
+
+
 def test_rgb2bayer_padded_source_rows_and_batch(gpu_pkg, oracle):
     rng = np.random.default_rng(10)
     w, h, n = 130, 21, 5
