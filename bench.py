@@ -3,7 +3,8 @@
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py
-  --gpus N ...`, one rank per GPU.  Rank 0 prints ONE JSON line.
+  --gpus N ...`, one rank per GPU; barriers and the max-over-ranks run over RCCL (gloo only if the RCCL
+  communicator cannot be brought up).  Rank 0 prints ONE JSON line.
 
 Workload = BASELINE.json configs[2]: 3840x2160, batch = 64 frames per GPU, all four Bayer orders
 (step i converts the batch as order ORDERS[i % 4] -> BGRx; the kernel is the same for all four, only
@@ -187,9 +188,35 @@ def host_path_note(pkg, device):
                     "frames; bound by PCIe (5 B/pixel over a Gen5 x16 link), not HBM; never `value`"}
 
 
+class ControlPlane:
+    """Barrier and max-over-ranks for the timed region: the only communication of this bench (the data path has no
+    collective).  Same small surface as the torch.distributed module, bound to one process group."""
+
+    def __init__(self, dist_mod, group, backend, device):
+        self._d, self._g, self._backend, self._device = dist_mod, group, backend, device
+        self.ReduceOp = dist_mod.ReduceOp
+
+    def get_backend(self):
+        return self._backend
+
+    def barrier(self):
+        if self._backend == "nccl":
+            self._d.barrier(group=self._g, device_ids=[self._device])
+        else:
+            self._d.barrier(group=self._g)
+
+    def all_reduce(self, t, op):
+        self._d.all_reduce(t, op=op, group=self._g)
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
+
+
 def setup_distributed(args):
-    """(world, rank, device ordinal, dist-or-None).  One rank per GPU over RCCL ("nccl"); --backend gloo with
-    --share-gpu exists only to exercise the N > 1 code path on a 1-GPU box (ranks then share GPU 0)."""
+    """(world, rank, device ordinal, control plane or None).  One rank per GPU; the ranks bootstrap over gloo and
+    then bring up an RCCL ("nccl") group for the barriers and the max-reduction.  If the RCCL communicator cannot be
+    brought up (e.g. --share-gpu puts two ranks on one GPU) the gloo group carries them instead -- the measured
+    region does not depend on it.  --backend gloo skips RCCL."""
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -200,16 +227,25 @@ def setup_distributed(args):
         raise SystemExit("bench.py: no MI355X visible; the bayer2rgb path has no CPU fallback")
     device = local_rank % torch.cuda.device_count() if args.share_gpu else local_rank
     torch.cuda.set_device(device)
-    dist = None
+    plane = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("gloo")
+        plane = ControlPlane(dist_mod, None, "gloo", device)
         if args.backend == "nccl":
-            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", device))
-        else:
-            dist_mod.init_process_group(args.backend)
-        dist = dist_mod
-    return world, rank, device, dist
+            try:
+                group = dist_mod.new_group(backend="nccl")
+                probe = torch.ones(1, device="cuda")
+                dist_mod.all_reduce(probe, group=group)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError("all_reduce over RCCL returned %r for %d ranks" % (probe.item(), world))
+                plane = ControlPlane(dist_mod, group, "nccl", device)
+            except Exception as exc:        # noqa: BLE001 -- any RCCL bring-up failure: keep the gloo plane
+                sys.stderr.write("bench.py rank %d: RCCL control plane unavailable (%s: %s); barriers and the "
+                                 "max-reduction run over gloo\n" % (rank, type(exc).__name__, str(exc)[:200]))
+    return world, rank, device, plane
 
 
 def run_stream(args):
@@ -315,7 +351,8 @@ def run(args):
                                "(BASELINE.json configs[2]), one launch per step, frames sharded round-robin "
                                "over ranks, no collective",
                    "kernel_variant": ctx0.variant_name, "launch_plan": ctx0.launch_geometry(BATCH),
-                   "autotune": tune.get(ORDERS[0], "off"), "parity": parity},
+                   "autotune": tune.get(ORDERS[0], "off"), "parity": parity,
+                   "control_plane": dist.get_backend() if dist is not None else "single process"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel_ms": round(kernel_ms, 4),
