@@ -1,6 +1,5 @@
 """GPU tests of the inverse direction (MIBAYER_FLAG_RGB2BAYER; reference gst/bayer/gstrgb2bayer.c:230-278):
 bit-exact against the oracle, exact left inverse of bayer2rgb at full size, and through the element."""
-import os
 import subprocess
 
 import numpy as np

@@ -8,7 +8,6 @@ the bytes written by the element with the oracle applied to the bytes that enter
 Pattern follows the reference's pipeline tests (tests/check/elements/autovideoconvert.c:56-96)."""
 import hashlib
 import os
-import shutil
 import subprocess
 
 import numpy as np
