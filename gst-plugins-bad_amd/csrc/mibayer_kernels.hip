@@ -717,15 +717,22 @@ const Variant &variant (int id)
   return kVariants[id];
 }
 
-/* variant 0: 1024x8 tiles whenever they pad the frame width by no more than 7 %
- * beyond the best shape (3840 -> 4096 is fine, 640 -> 1024 is not): with the band-1
- * order they are the robust plan.  Otherwise the production shape that wastes the
- * fewest lanes -- a 640-px row fills 83 % of three 256-px tiles but 62 % of one
- * 1024-px tile (78 % vs 59 % of HBM peak measured) -- the widest among equals. */
+/* variant 0.  Rows that fit into ONE tile take the narrowest production tile that covers them (256 / 512 / 1024 px),
+ * run in identity order without the start delay: 81-84 % of HBM peak for 320 ... 1024-px rows, against 50-79 % for
+ * the other shapes (a second, mostly empty tile per row is what hurts: 640 px in 512-px tiles 59 %;
+ * profiles/r01_sweep_narrow_frames.log).  Wider rows: 1024x8 tiles whenever they pad the frame width by no more
+ * than 7 % beyond the best shape (3840 -> 4096 is fine) -- with the band-1 order they are the robust plan --
+ * otherwise the production shape that wastes the fewest lanes, the widest among equals. */
 int resolve_variant (int id, int width)
 {
   if (id != 0)
     return id;
+  if (width <= 256)
+    return 3;
+  if (width <= 512)
+    return 2;
+  if (width <= 1024)
+    return 1;
   static const int tile_w[3] = { 1024, 512, 256 };      /* variants 1, 2, 3 */
   long long padded[3];
   int best = 0;

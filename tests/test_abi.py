@@ -168,11 +168,13 @@ def test_rgb2bayer_cfg_validation(pkg):
 
 
 def test_auto_variant_minimises_wasted_lanes(pkg):
-    """variant 0: 1024-px tiles when they pad the width <= 7 % beyond the best shape, else the least padding."""
+    """variant 0: rows that fit one tile take the narrowest tile that covers them (256 / 512 / 1024 px); wider rows
+    take 1024-px tiles when they pad the width <= 7 % beyond the best shape, else the least padding."""
     names = pkg.variant_names()
     f = pkg.lib().mibayer_auto_variant
-    want = {3840: "lds_4x2", 7680: "lds_4x2", 1920: "lds_4x2", 640: "lds_1x8", 1280: "lds_1x8", 300: "lds_2x4",
-            200: "lds_1x8", 4: "lds_1x8", 1024: "lds_4x2", 1026: "lds_1x8", 2048: "lds_4x2", 512: "lds_2x4",
-            4000: "lds_4x2", 3072: "lds_4x2", 2600: "lds_1x8"}
+    want = {3840: "lds_4x2", 7680: "lds_4x2", 1920: "lds_4x2", 640: "lds_4x2", 800: "lds_4x2", 1280: "lds_1x8",
+            300: "lds_2x4", 256: "lds_1x8", 258: "lds_2x4", 200: "lds_1x8", 4: "lds_1x8", 1024: "lds_4x2",
+            1026: "lds_1x8", 2048: "lds_4x2", 512: "lds_2x4", 514: "lds_4x2", 4000: "lds_4x2", 3072: "lds_4x2",
+            2600: "lds_1x8"}
     for w, prefix in want.items():
         assert names[f(w)].startswith(prefix), (w, names[f(w)])
