@@ -271,9 +271,17 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
       && (nframes == 1 || (src_frame_bytes % 16 == 0
               && dst_frame_bytes % 16 == 0));
   kern = fast ? c->var->fast : c->var->generic;
-  /* one tile per row: every band map degenerates to the identity order, and the
-   * start delay that comes with a band map only costs (1024-px rows: 72 vs 84 %) */
-  if (g.tiles_x == 1 && g.band > 0 && c->band_override == INT32_MIN)
+  /* The variant's default band map is dropped for the identity order in two cases
+   * (profiles/r01_sweep_narrow_frames.log, r01_sweep_tile_multiple_widths.log):
+   *  - one tile per row: every band map degenerates to the identity order, and the
+   *    start delay that comes with a band map only costs (1024-px rows: 72 vs 84 %);
+   *  - the width is a whole number of tiles: a tile row is then a multiple of 32 KiB
+   *    of output, the eight XCDs of a band map write at power-of-two distances from
+   *    each other and collide in the memory channels (2048 / 3072 / 4096 / 5120 px:
+   *    70-77 % with band 1, 81-83 % in identity order; 1920 / 3840 / 7680 px, whose
+   *    last tile is partial, are the other way round by 2-4 points). */
+  if (g.band > 0 && c->band_override == INT32_MIN
+      && (g.tiles_x == 1 || f.width % c->var->tile_w == 0))
     g.band = 0;
   if (fast && c->var->persistent) {
     /* persistent arm: only "one chunk per XCD" or "identity" make sense, and
