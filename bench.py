@@ -84,41 +84,71 @@ def aggregate_mpix_per_s(pixels_per_step_per_rank, world_size, steps, elapsed_s)
 # ----------------------------------------------------------------------------------------------
 
 def cpu_baseline(budget_s=12.0, sample_frames=32):
+    """Four legs on this box's host cores, all on the same 32 frames, all byte-identical restatements of the
+    reference path (tests/test_oracle.py):
+      simd_1core       the two ORC programs as the pavgb / punpck sequences they compile to (oracle/bayer2rgb_simd.c,
+                       SSE2 as ORC's x86-64 backend of the 1.19 era emits, and AVX2 where the CPU has it), one
+                       thread -- what one reference element does per stream; this is `value`;
+      scalar_1core     the plain-C restatement (gcc -O3 auto-vectorised), one thread;
+      all_cores        the best SIMD form on EVERY host core (frames x row bands = jobs >= 2 per core);
+      reference_c_path the reference's own compiled row kernels (oracle/_ref, its -DDISABLE_ORC C path), one thread.
+    """
+    import numpy as np
     import __graft_entry__ as entry
     oracle = entry.load_oracle()
     ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0)) or ncores
+    except (AttributeError, OSError):
+        pass
     src = oracle.fill_synthetic(WIDTH, HEIGHT, sample_frames, SEED)
+    dst = np.empty((sample_frames, HEIGHT, 4 * WIDTH), np.uint8)
     r, g, b = oracle.LAYOUTS[FORMAT]
-    oracle.bayer2rgb_batch(src[:1], WIDTH, "rggb", r, g, b, nthreads=1)      # warm-up / page-in
+    oracle.bayer2rgb_batch_bands(src, WIDTH, "rggb", r, g, b, 1, min(ncores, sample_frames), "own", dst)  # page-in
 
-    def run(nthreads, budget, ref_rows=False):
+    def run(mode, nthreads, nbands, budget):
         reps, t0 = 0, time.perf_counter()
         while True:
-            oracle.bayer2rgb_batch(src, WIDTH, ORDERS[reps % 4], r, g, b, nthreads=nthreads, ref_rows=ref_rows)
+            oracle.bayer2rgb_batch_bands(src, WIDTH, ORDERS[reps % 4], r, g, b, nbands, nthreads, mode, dst)
             reps += 1
             el = time.perf_counter() - t0
             if el >= budget:
                 return WIDTH * HEIGHT * sample_frames * reps / el / 1e6, reps, el
 
-    v1, reps1, el1 = run(1, budget_s * 0.5)
-    nthreads = min(ncores, sample_frames)
-    vn, repsn, eln = run(nthreads, budget_s * 0.25)
+    share = budget_s / 5.0
+    isas = oracle.simd_isas()
+    simd = {}
+    for isa in isas:
+        v, reps, el = run(isa, 1, 1, share / len(isas) * 1.5)
+        simd[isa] = {"value": round(v, 1), "passes": reps, "seconds": round(el, 2)}
+    best_isa = max(simd, key=lambda k: simd[k]["value"])
+    vs, repss, els = run("own", 1, 1, share)
+    # all cores: frames x row bands, at least two jobs per core
+    nbands = max(1, -(-2 * ncores // sample_frames))
+    vn, repsn, eln = run(best_isa, ncores, nbands, share * 1.5)
     ref = None
     if oracle.have_ref_rows():
         # the reference's own compiled row kernels (gstbayerorc-dist.c, -DDISABLE_ORC = its C backup path)
         # under the restated frame driver; prebuilt in the build container, travels as a binary
-        vr, repsr, elr = run(1, budget_s * 0.25, ref_rows=True)
+        vr, repsr, elr = run("ref", 1, 1, share)
         ref = {"value": round(vr, 1), "cores": 1, "kind": "reference", "passes": repsr,
                "note": "oracle/_ref row kernels = reference gstbayerorc-dist.c built -DDISABLE_ORC -O2 (the "
                        "reference's no-ORC C path, not the ORC JIT), restated frame driver"}
     return {
-        "value": round(v1, 1), "unit": "Mpix/s", "cores": 1, "kind": "port",
-        "sample": "%d of the %d 4K frames (seed %d, frames 0-%d) -> %s, all 4 orders cycled, "
-                  "%d passes in %.1f s, oracle/bayer2rgb_oracle.c gcc -O3, 1 thread (the reference "
+        "value": simd[best_isa]["value"], "unit": "Mpix/s", "cores": 1, "kind": "port",
+        "sample": "%d of the %d 4K frames (seed %d, frames 0-%d) -> %s, all 4 orders cycled, %d passes in %.1f s; "
+                  "ORC-equivalent %s row kernels (oracle/bayer2rgb_simd.c: avgub = pavgb, mergebw/mergewl = "
+                  "punpck, gstbayerorc.orc:3-19, 43-92) under the restated frame driver, 1 thread (the reference "
                   "element is single-threaded per stream)" % (
-                      sample_frames, BATCH, SEED, sample_frames - 1, FORMAT, reps1, el1),
-        "all_cores": {"value": round(vn, 1), "cores": nthreads, "host_cores": ncores, "passes": repsn,
-                      "note": "frame-parallel pthreads, one frame per thread"},
+                      sample_frames, BATCH, SEED, sample_frames - 1, FORMAT, simd[best_isa]["passes"],
+                      simd[best_isa]["seconds"], best_isa.upper()),
+        "simd_1core": dict(simd, best=best_isa, cores=1),
+        "scalar_1core": {"value": round(vs, 1), "cores": 1, "passes": repss,
+                         "note": "oracle/bayer2rgb_oracle.c, plain C, gcc -O3 auto-vectorised"},
+        "all_cores": {"value": round(vn, 1), "cores": ncores, "host_cores": ncores, "passes": repsn,
+                      "isa": best_isa, "jobs": sample_frames * nbands,
+                      "note": "pthreads, %d frames x %d row bands = %d jobs round-robin over %d threads (every "
+                              "host core)" % (sample_frames, nbands, sample_frames * nbands, ncores)},
         "reference_c_path": ref,
     }
 
@@ -186,6 +216,33 @@ def host_path_note(pkg, device):
             "hipgraph_per_frame": round(graph, 1),
             "note": "host->host incl. H2D + D2H over PCIe, hipHostMalloc-pinned buffers, 3 frames in flight, 24 4K "
                     "frames; bound by PCIe (5 B/pixel over a Gen5 x16 link), not HBM; never `value`"}
+
+
+def build_hash():
+    """First 12 hex digits of the sha256 over the kernel sources: ties a profiled traffic figure to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("mibayer_kernels.hip", "mibayer_internal.h", "mibayer_abi.hip"):
+        with open(os.path.join(ROOT, "gst-plugins-bad_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def profiled_traffic(band):
+    """The PMC-measured HBM bytes per launch of the block order this run used, from the last profiled pass
+    (profiles/traffic_latest.json): NOT a measurement of this run, hence not `traffic`."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        plan = "band1" if band == 1 else ("chunk" if band > 1 else "identity")
+        entry = t["plans"][plan]
+        return {"bytes": entry["hbm_bytes_per_launch"], "read_bytes": entry.get("read_bytes"),
+                "write_bytes": entry.get("write_bytes"), "plan": plan, "box_serial": t.get("box_serial"),
+                "build": t.get("build"), "build_matches_this_run": t.get("build") == build_hash(),
+                "file": "profiles/traffic_latest.json", "source": t.get("source")}
+    except Exception:       # noqa: BLE001 -- no profile committed yet
+        return None
 
 
 class ControlPlane:
@@ -322,24 +379,56 @@ def run(args):
         tune[ORDERS[0]] = ctx0.autotune(d_src.data_ptr(), d_dst.data_ptr(), BATCH)
         for o in ORDERS[1:]:        # same geometry, same kernel: one plan for all four orders
             ctxs[o].copy_plan_from(ctx0)
-    parity = parity_spot_check(pkg, ctxs, d_src, d_dst, rank, world, stream)
 
+    def launch(i):
+        ctxs[ORDERS[i % 4]].process_device(d_src.data_ptr(), d_dst.data_ptr(), BATCH, stream=stream)
+
+    # Time-based pre-warm, untimed and stated in the JSON line: an MI355X that has been idle (context set-up,
+    # the host side of the autotune report, rendezvous) needs tens of milliseconds of work to reach its
+    # sustained clocks, and W = 5 steps are only 2 ms of it.  Launches of the very kernel of the timed region,
+    # in chunks, until the wall clock says `--prewarm-ms` have passed with the GPU busy.  Nothing between
+    # here and the timed region lets the GPU idle: the W warm-up steps follow back to back.
+    prewarm_launches, t0 = 0, time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < args.prewarm_ms:
+        for _ in range(16):
+            launch(prewarm_launches)
+            prewarm_launches += 1
+        tstream.synchronize()
+    prewarm_ms = (time.perf_counter() - t0) * 1e3
+
+    # HIP events on the launch stream: one before every timed step and one after the last, so the line
+    # carries the per-step distribution beside the mean
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] \
+        if not args.no_step_events else None
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
-    state = {"first_timed": args.warmup}
+    first_timed = args.warmup
 
     def step(i):
-        if i == state["first_timed"]:
+        k = i - first_timed
+        if step_events is not None and k >= 0:
+            step_events[k].record()
+        elif k == 0:
             ev0.record()
-        ctxs[ORDERS[i % 4]].process_device(d_src.data_ptr(), d_dst.data_ptr(), BATCH, stream=stream)
-        if i == state["first_timed"] + args.steps - 1:
-            ev1.record()
+        launch(i)
+        if k == args.steps - 1:
+            (step_events[args.steps] if step_events is not None else ev1).record()
 
     elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, dist)
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps       # HIP events on the launch stream
+    if step_events is not None:
+        kernel_ms = step_events[0].elapsed_time(step_events[args.steps]) / args.steps
+        per_step = sorted(step_events[k].elapsed_time(step_events[k + 1]) for k in range(args.steps))
+    else:
+        kernel_ms = ev0.elapsed_time(ev1) / args.steps       # HIP events on the launch stream
+        per_step = None
     pixels = WIDTH * HEIGHT * BATCH
     value = aggregate_mpix_per_s(pixels, world, args.steps, elapsed)
     achieved = BYTES_PER_PIXEL * pixels / (kernel_ms * 1e-3) / 1e9
+    # parity AFTER the timed region (host-side oracle work and 33 MB downloads would idle the GPU before it)
+    parity = parity_spot_check(pkg, ctxs, d_src, d_dst, rank, world, stream)
+
+    def pct(q):
+        return per_step[min(len(per_step) - 1, int(q * len(per_step)))]
 
     result = {
         "metric": "bayer2rgb Mpix/s @4K (device-resident batch)",
@@ -347,6 +436,7 @@ def run(args):
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic (counter-based PRNG frames generated in HBM, seed %d)" % SEED,
+        "prewarm_ms": round(prewarm_ms, 1), "prewarm_launches": prewarm_launches,
         "config": {"workload": "3840x2160 x 64 frames per GPU, bggr/rggb/grbg/gbrg -> BGRx cycled per step "
                                "(BASELINE.json configs[2]), one launch per step, frames sharded round-robin "
                                "over ranks, no collective",
@@ -358,17 +448,16 @@ def run(args):
                      "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes_per_launch": BYTES_PER_PIXEL * pixels},
     }
-    traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(traffic_file):
-        try:
-            with open(traffic_file) as f:
-                t = json.load(f)
-            band = ctx0.launch_geometry(BATCH)["band"]
-            plan = "band1" if band == 1 else ("chunk" if band > 1 else "identity")
-            result["roofline"]["traffic"] = t["plans"][plan]["hbm_bytes_per_launch"]
-            result["roofline"]["traffic_source"] = "%s; block order of this run: %s" % (t.get("source"), plan)
-        except Exception:
-            pass
+    if per_step is not None:
+        med = pct(0.5)
+        result["roofline"]["kernel_ms_per_step"] = {
+            "median": round(med, 4), "p10": round(pct(0.1), 4), "p90": round(pct(0.9), 4),
+            "min": round(per_step[0], 4), "max": round(per_step[-1], 4),
+            "frac_at_median": round(BYTES_PER_PIXEL * pixels / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    # `traffic` is a measurement of THIS run or null: PMC counters need a rocprofv3 wrapper around the process, so
+    # the unwrapped bench line says null and carries the last profiled figure under its own name, with the
+    # plan, the box and the build it was taken on (tools/summarize_profiles.py writes the file)
+    result["roofline"]["traffic_profiled"] = profiled_traffic(ctx0.launch_geometry(BATCH)["band"])
     if rank == 0 and world == 1:
         if not args.no_host_path:
             for c in ctxs.values():
@@ -395,6 +484,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+                    help="untimed time-based GPU pre-warm before the W warm-up steps (reported as prewarm_ms)")
+    ap.add_argument("--no-step-events", action="store_true",
+                    help="two HIP events around the timed region instead of one per step")
     ap.add_argument("--mode", choices=("batch", "stream"), default="batch",
                     help="batch = the headline device-resident metric (default); stream = configs[4] host-fed stream")
     ap.add_argument("--no-graph", action="store_true", help="stream mode: streams+events instead of hipGraph")

@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <vector>
 
 using namespace mibayer;
@@ -118,6 +119,8 @@ struct mibayer_ctx {
   int host_bands = 1;                   /* host path: horizontal bands a frame is cut into so that
                                            the upload of band b+1, the kernel of band b and the
                                            download of band b-1 overlap inside ONE frame */
+  /* rgb2bayer launch shape (R2BParams); MIBAYER_R2B_FLAT / _PX / _LDNT / _ROWS override */
+  int r2b_flat_k = 4, r2b_flat_px = 8, r2b_flat_ld = 0, r2b_rows = 2;
   int start_sleep = -1;                 /* s_sleep(1) iterations before a workgroup's first load;
                                            -1 = automatic (kStartSleepChunk with a band map on
                                            large grids, else 0); MIBAYER_START_SLEEP overrides */
@@ -337,6 +340,10 @@ static int launch (const mibayer_ctx *c, const void *d_src,
     q.total_rows = (long long) nframes * f.height;
     q.band = c->band_override != INT32_MIN ? c->band_override : -1;    /* chunk per XCD */
     q.start_sleep = c->start_sleep > 0 ? c->start_sleep : 0;
+    q.flat_k = c->r2b_flat_k;
+    q.flat_px = c->r2b_flat_px;
+    q.flat_ld = c->r2b_flat_ld;
+    q.rows = c->r2b_rows;
     for (int k = 0; k < 2; k++) {
       q.sel_lo[k] = c->r2b_lo[k];
       q.sel_hi[k] = c->r2b_hi[k];
@@ -525,6 +532,14 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
     c->band_override = atoi (e);
   if (const char *e = getenv ("MIBAYER_START_SLEEP"))
     c->start_sleep = atoi (e) >= 0 ? atoi (e) : -1;
+  if (const char *e = getenv ("MIBAYER_R2B_FLAT"))
+    c->r2b_flat_k = atoi (e);
+  if (const char *e = getenv ("MIBAYER_R2B_PX"))
+    c->r2b_flat_px = atoi (e);
+  if (const char *e = getenv ("MIBAYER_R2B_LDNT"))
+    c->r2b_flat_ld = atoi (e);
+  if (const char *e = getenv ("MIBAYER_R2B_ROWS"))
+    c->r2b_rows = atoi (e);
   if (const char *e = getenv ("MIBAYER_PERSIST_WGS"))
     c->persist_wgs_per_cu = atoi (e) > 0 ? atoi (e) : 4;
   {
@@ -1195,18 +1210,30 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
 
   const Variant *keep_var = c->var;
   const int keep_band = c->band_override;
-  /* The candidates are timed in interleaved rounds after a common warm-up and
-   * each keeps its best round: an idle GPU needs some milliseconds to clock up
-   * (the first candidate used to lose for that reason alone), and a slow round
-   * (another process, a DVFS step) must not decide the plan. */
-  const int kRounds = 3, kWarm = 24, kReps = 6;
-  float cand_ms[6];
+  /* The candidates are timed in interleaved rounds after a common, TIME-based
+   * warm-up, and each is judged by the MEDIAN of its rounds: an idle GPU needs
+   * tens of milliseconds to clock up (the first candidate used to lose for that
+   * reason alone), one slow round (another process, a DVFS step) must not
+   * decide the plan, and neither may one lucky round -- the plan has to be the
+   * one that is fastest in steady state, which is what the caller then runs. */
+  constexpr int kRounds = 5, kWarm = 16, kReps = 6, kCands = 6;
+  constexpr double kWarmMs = 60.0;
+  float round_ms[kCands][kRounds];
+  float cand_ms[kCands];
   for (float &m : cand_ms)
     m = 0.f;
   int rc = MIBAYER_OK;
   float ms = 0.f;
-  rc = mibayer_time_device (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes,
-      nframes, 0, kWarm, &ms);
+  {
+    timespec t0, t1;
+    clock_gettime (CLOCK_MONOTONIC, &t0);
+    do {
+      rc = mibayer_time_device (c, d_src, src_frame_bytes, d_dst,
+          dst_frame_bytes, nframes, 0, kWarm, &ms);
+      clock_gettime (CLOCK_MONOTONIC, &t1);
+    } while (rc == MIBAYER_OK && ((double) (t1.tv_sec - t0.tv_sec) * 1e3
+            + (double) (t1.tv_nsec - t0.tv_nsec) * 1e-6) < kWarmMs);
+  }
   for (int round = 0; round < kRounds && rc == MIBAYER_OK; round++) {
     for (int si = 0; si < nshapes && rc == MIBAYER_OK; si++) {
       for (int bi = 0; bi < nbands && rc == MIBAYER_OK; bi++) {
@@ -1215,11 +1242,22 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
           c->band_override = bands[bi];
         rc = mibayer_time_device (c, d_src, src_frame_bytes, d_dst,
             dst_frame_bytes, nframes, 1, kReps, &ms);
-        float &best = cand_ms[si * 3 + bi];
-        if (rc == MIBAYER_OK && (best == 0.f || ms < best))
-          best = ms;
+        round_ms[si * 3 + bi][round] = ms;
       }
     }
+  }
+  if (rc == MIBAYER_OK) {
+    for (int si = 0; si < nshapes; si++)
+      for (int bi = 0; bi < nbands; bi++) {
+        float *r = round_ms[si * 3 + bi];
+        for (int i = 1; i < kRounds; i++)       /* insertion sort of 5 */
+          for (int j = i; j > 0 && r[j] < r[j - 1]; j--) {
+            const float t = r[j];
+            r[j] = r[j - 1];
+            r[j - 1] = t;
+          }
+        cand_ms[si * 3 + bi] = r[kRounds / 2];
+      }
   }
   if (rc != MIBAYER_OK) {
     c->var = keep_var;

@@ -174,6 +174,16 @@ struct R2BParams {
   FastDiv div_height;
   uint32_t sel_lo[2];           /* v_perm selectors per row parity: pixels 0,1 */
   uint32_t sel_hi[2];           /*                                  pixels 2,3 */
+  /* launch shape (tuning; every combination is bit-exact):
+   *   flat_k  > 0: the flat kernel, the batch as one linear sequence of 4-pixel items (16 B in, one dword out),
+   *                flat_k groups per thread kept in flight; 0: the tile kernel (rows x 1024 px per block)
+   *   flat_px   4: one item per group (dword store), 8: two adjacent items per group (two 16-byte loads, one
+   *                8-byte store; needs an even number of dwords per row and 8-byte aligned destination rows)
+   *   flat_ld   1: nt hint on the loads (the input is read exactly once)
+   *   rows      rows per block of the tile kernel (2, 4, 8, 16)                                             */
+  int flat_k, flat_px, flat_ld, rows;
+  FastDiv div_out_dwords;       /* filled by launch_rgb2bayer (flat kernel) */
+  uint32_t item0, item_end;     /* first / one-past-last 4-pixel item of this launch (flat kernel) */
 };
 /* rows [row0, row0 + nrows) of the batch (nrows < 0: all); row0 must be a multiple of 16 */
 hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,

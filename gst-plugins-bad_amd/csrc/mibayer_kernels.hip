@@ -822,6 +822,113 @@ rgb2bayer_kernel (R2BParams p)
   }
 }
 
+/* Flat form: with no neighbourhood the batch is one linear sequence of 4-pixel
+ * items (16 B in -> one dword out); only the row parity (which pair of v_perm
+ * selectors) and, for padded strides, the addresses depend on where an item sits.
+ * No lane is wasted on a partial last tile (3840 px = 3.75 tiles of 1024 in the
+ * tile kernel: 6 % idle lanes), every thread keeps K groups of loads in flight,
+ * and with PX == 8 a lane owns 32 contiguous input bytes and stores 8 bytes
+ * (512 B per wave-store instead of 256).  Items are decoded with two
+ * multiply-shift divisions (row = item / dwords-per-row, frame = row / height). */
+template <int K, int PX, int LD, bool VEC16>
+__global__ void __launch_bounds__ (256)
+rgb2bayer_flat_kernel (R2BParams p)
+{
+  constexpr int IPG = PX / 4;           /* items per group */
+  const TileId tile = block_to_tile (blockIdx.x, p.map);       /* tiles_x == 1: .row = logical block */
+  if (!tile.valid)
+    return;
+  for (int z = 0; z < p.start_sleep; z++)
+    __builtin_amdgcn_s_sleep (1);
+  const uint32_t first = p.item0 + (tile.row * (uint32_t) (256 * K) + threadIdx.x) * IPG;
+  u32x4 px[K][IPG];
+  uint32_t par[K];
+  uint8_t *dptr[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const uint32_t item = first + (uint32_t) k * 256u * IPG;
+#pragma unroll
+    for (int h = 0; h < IPG; h++)
+      px[k][h] = (u32x4) (0u);
+    par[k] = 0;
+    dptr[k] = nullptr;
+    if (item < p.item_end) {
+      const uint32_t row = fastdiv (item, p.div_out_dwords);
+      const uint32_t xd = item - row * p.div_out_dwords.d;
+      const uint32_t f = fastdiv (row, p.div_height);
+      const uint32_t y = row - f * p.div_height.d;
+      par[k] = y & 1u;
+      const uint8_t *s = p.src + f * p.src_frame_bytes + (size_t) y * p.src_stride
+          + (size_t) xd * 16;
+      dptr[k] = p.dst + f * p.dst_frame_bytes + (size_t) y * p.dst_stride
+          + (size_t) xd * 4;
+#pragma unroll
+      for (int h = 0; h < IPG; h++) {
+        if constexpr (VEC16) {
+          if constexpr (LD == 1)
+            px[k][h] = __builtin_nontemporal_load ((const u32x4 *) s + h);
+          else
+            px[k][h] = ((const u32x4 *) s)[h];
+        } else {
+          const uint32_t *q = (const uint32_t *) s + 4 * h;
+          const int x0 = (int) (xd + h) * 4;
+          if (x0 + 0 < p.width) px[k][h].x = q[0];
+          if (x0 + 1 < p.width) px[k][h].y = q[1];
+          if (x0 + 2 < p.width) px[k][h].z = q[2];
+          if (x0 + 3 < p.width) px[k][h].w = q[3];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    if (dptr[k]) {
+      uint32_t out[IPG];
+#pragma unroll
+      for (int h = 0; h < IPG; h++) {
+        const uint32_t lo = __builtin_amdgcn_perm (px[k][h].y, px[k][h].x, p.sel_lo[par[k]]);
+        const uint32_t hi = __builtin_amdgcn_perm (px[k][h].w, px[k][h].z, p.sel_hi[par[k]]);
+        out[h] = lo | hi;
+      }
+      if constexpr (!VEC16) {
+        /* columns >= width inside the last dword of a row are written as 0 */
+        const uint32_t item = first + (uint32_t) k * 256u * IPG;
+        const uint32_t row = fastdiv (item, p.div_out_dwords);
+        const int valid = p.width - (int) (item - row * p.div_out_dwords.d) * 4;
+        if (valid < 4)
+          out[0] &= (1u << (8 * valid)) - 1u;
+      }
+      if constexpr (IPG == 2) {
+        u32x2 v;
+        v.x = out[0];
+        v.y = out[1];
+        __builtin_nontemporal_store (v, (u32x2 *) dptr[k]);
+      } else {
+        __builtin_nontemporal_store (out[0], (uint32_t *) dptr[k]);
+      }
+    }
+  }
+}
+
+typedef void (*R2BFn) (R2BParams);
+
+template <bool VEC16>
+static R2BFn flat_kernel_for (int k, int px, int ld)
+{
+#define R2B_FLAT(K, PX, LD) if (k == K && px == PX && ld == LD) return rgb2bayer_flat_kernel<K, PX, LD, VEC16>
+  R2B_FLAT (1, 4, 0); R2B_FLAT (1, 4, 1); R2B_FLAT (1, 8, 0); R2B_FLAT (1, 8, 1);
+  R2B_FLAT (2, 4, 0); R2B_FLAT (2, 4, 1); R2B_FLAT (2, 8, 0); R2B_FLAT (2, 8, 1);
+  R2B_FLAT (4, 4, 0); R2B_FLAT (4, 4, 1); R2B_FLAT (4, 8, 0); R2B_FLAT (4, 8, 1);
+  R2B_FLAT (8, 4, 0); R2B_FLAT (8, 4, 1); R2B_FLAT (8, 8, 0); R2B_FLAT (8, 8, 1);
+#undef R2B_FLAT
+  return nullptr;
+}
+
+static bool aligned_to (const void *ptr, unsigned a)
+{
+  return (((uintptr_t) ptr) & (a - 1)) == 0;
+}
+
 hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
     long long row0, long long nrows)
 {
@@ -834,27 +941,49 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
   }
   if (row0 < 0 || (row0 & 15) || row0 + nrows > p.total_rows)
     return hipErrorInvalidValue;
+  if (p.total_rows > 0x7fffffffLL)
+    return hipErrorInvalidValue;
+  q.div_height = make_fastdiv ((uint32_t) p.height);
+  q.div_out_dwords = make_fastdiv ((uint32_t) p.out_dwords);
+
+  /* ---- flat kernel ---------------------------------------------------------- */
+  const long long item_end = (row0 + nrows) * p.out_dwords;
+  if (q.flat_k > 0 && item_end <= 0x7fffffffLL) {
+    int px = q.flat_px == 8 ? 8 : 4;
+    /* two items per group: they must be in one row and the 8-byte store aligned */
+    if (px == 8 && ((p.out_dwords & 1) || (p.dst_stride & 7) || (p.dst_frame_bytes & 7)
+            || !aligned_to (p.dst, 8) || !vec16))
+      px = 4;
+    R2BFn fn = vec16 ? flat_kernel_for<true> (q.flat_k, px, q.flat_ld ? 1 : 0)
+        : flat_kernel_for<false> (q.flat_k, px, q.flat_ld ? 1 : 0);
+    if (fn) {
+      q.item0 = (uint32_t) (row0 * p.out_dwords);
+      q.item_end = (uint32_t) item_end;
+      const long long items = item_end - q.item0;
+      const long long per_block = 256LL * q.flat_k * (px / 4);
+      const long long nblocks = (items + per_block - 1) / per_block;
+      if (q.band < 0)           /* one contiguous chunk of the launch per XCD */
+        q.band = (int) ((nblocks + kNumXcd - 1) / kNumXcd);
+      const long long grid = grid_blocks_for (1, nblocks, q.band);
+      if (grid > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+      q.map = make_tile_map (1, 1, nblocks, q.band, 0);
+      hipLaunchKernelGGL (fn, dim3 ((unsigned) grid), dim3 (256), 0, stream, q);
+      return hipGetLastError ();
+    }
+  }
+
+  /* ---- tile kernel ------------------------------------------------------------ */
   q.total_rows = row0 + nrows;  /* the kernel's "row < total_rows" guard ends the band */
-  /* rows per block: 2, with one chunk of the batch per XCD and no start delay,
-   * measured best on MI355X in a shuffled A/B (76 % of peak; identity order 73 %,
-   * 4 or 8 rows 70-75 %, any start delay worse: this direction is read-dominated;
-   * profiles/r01_rgb2bayer.log).  MIBAYER_R2B_ROWS / MIBAYER_XCD_BAND /
-   * MIBAYER_START_SLEEP are tuning overrides */
-  static const int rows_per_block = [] {
-    const char *e = getenv ("MIBAYER_R2B_ROWS");
-    const int v = e ? atoi (e) : 2;
-    return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 2;
-  } ();
-  const int R2B_ROWS = rows_per_block;
+  const int R2B_ROWS = (q.rows == 4 || q.rows == 8 || q.rows == 16) ? q.rows : 2;
   const long long tile_rows = (nrows + R2B_ROWS - 1) / R2B_ROWS;
   const int tiles_x = (p.out_dwords + 255) / 256;
   if (q.band < 0)               /* one contiguous chunk of tile rows per XCD */
     q.band = (int) ((tile_rows + kNumXcd - 1) / kNumXcd);
   const long long grid = grid_blocks_for (tiles_x, tile_rows, q.band);
-  if (grid > 0x7fffffffLL || p.total_rows > 0x7fffffffLL)
+  if (grid > 0x7fffffffLL)
     return hipErrorInvalidValue;
   q.map = make_tile_map (tiles_x, 1, tile_rows, q.band, row0 / R2B_ROWS);
-  q.div_height = make_fastdiv ((uint32_t) p.height);
 #define R2B_LAUNCH(V, R) hipLaunchKernelGGL ((rgb2bayer_kernel<V, R>), \
       dim3 ((unsigned) grid), dim3 (256), 0, stream, q)
   switch (R2B_ROWS * 2 + (vec16 ? 1 : 0)) {

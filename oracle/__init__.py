@@ -41,6 +41,10 @@ def lib():
         L.oracle_bayer2rgb_batch.argtypes = [
             _u8p, ctypes.c_size_t, ctypes.c_int, _u8p, ctypes.c_size_t, ctypes.c_int,
         ] + [ctypes.c_int] * 9
+        L.oracle_bayer2rgb_mode.argtypes = frame_args + [ctypes.c_int] * 3
+        L.oracle_bayer2rgb_batch_bands.argtypes = [
+            _u8p, ctypes.c_size_t, ctypes.c_int, _u8p, ctypes.c_size_t, ctypes.c_int,
+        ] + [ctypes.c_int] * 10
         L.oracle_fill_synthetic.argtypes = [
             _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
             ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
@@ -113,6 +117,50 @@ def bayer2rgb_batch(src, width, pattern, r_off, g_off, b_off, nthreads=1, ref_ro
         width, H, pattern, r_off, g_off, b_off, N, nthreads, int(ref_rows))
     if rc != 0:
         raise ValueError("oracle rejected geometry/layout (rc=%d)" % rc)
+    return dst
+
+
+ROWS = {"own": 0, "ref": 1, "sse2": 2, "avx2": 3}
+
+
+def simd_isas():
+    """Row-kernel restatements of the ORC programs this CPU can run ("sse2", and "avx2" where present)."""
+    return ["sse2", "avx2"] if lib().oracle_simd_best_isa() >= 2 else ["sse2"]
+
+
+def bayer2rgb_mode(src, width, pattern, r_off, g_off, b_off, mode="own", y0=0, y1=-1, dst=None):
+    """One frame with the chosen row kernels ("own", "ref", "sse2", "avx2"); output rows y0..y1-1 only
+    (rows outside keep the 0xA5 guard fill, or whatever `dst` held)."""
+    if isinstance(pattern, str):
+        pattern = PATTERNS[pattern]
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    H, sstride = src.shape
+    if dst is None:
+        dst = np.full((H, 4 * width), 0xA5, np.uint8)
+    if mode == "ref":
+        load_ref_rows()
+    rc = lib().oracle_bayer2rgb_mode(_p(dst), dst.shape[1], _p(src), sstride, width, H, pattern,
+                                     r_off, g_off, b_off, ROWS[mode], y0, y1)
+    if rc != 0:
+        raise ValueError("oracle rejected geometry/layout/mode (rc=%d)" % rc)
+    return dst
+
+
+def bayer2rgb_batch_bands(src, width, pattern, r_off, g_off, b_off, nbands=1, nthreads=1, mode="own", dst=None):
+    """src: (N, H, src_stride) uint8 -> (N, H, 4*width) uint8; N x nbands jobs over nthreads pthreads."""
+    if isinstance(pattern, str):
+        pattern = PATTERNS[pattern]
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    N, H, sstride = src.shape
+    if dst is None:
+        dst = np.empty((N, H, 4 * width), np.uint8)
+    if mode == "ref":
+        load_ref_rows()
+    rc = lib().oracle_bayer2rgb_batch_bands(
+        _p(dst), H * 4 * width, 4 * width, _p(src), H * sstride, sstride,
+        width, H, pattern, r_off, g_off, b_off, N, nbands, nthreads, ROWS[mode])
+    if rc != 0:
+        raise ValueError("oracle rejected geometry/layout/mode (rc=%d)" % rc)
     return dst
 
 

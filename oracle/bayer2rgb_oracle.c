@@ -202,10 +202,64 @@ layout_of (int r, int g, int b)
   return -1;
 }
 
-/* gst_bayer2rgb_process, gstbayer2rgb.c:387-451 */
+/* ---- SIMD row kernels (bayer2rgb_simd.c) ----------------------------------- */
+
+void simd_sse2_horiz_upsample_unaligned (uint8_t *d0, uint8_t *d1,
+    const uint8_t *s, int n);
+void simd_avx2_horiz_upsample_unaligned (uint8_t *d0, uint8_t *d1,
+    const uint8_t *s, int n);
+void simd_merge (int isa, int layout, int type, uint8_t *d, const uint8_t *u0,
+    const uint8_t *u1, const uint8_t *c0, const uint8_t *c1, const uint8_t *d0,
+    const uint8_t *d1, int n);
+int oracle_simd_best_isa (void);
+
+/* gstbayer2rgb.c:354-381 with the body delegated to the SIMD kernel */
+static void
+simd_row_lines (int isa, uint8_t *ev, uint8_t *od, const uint8_t *s, int w)
+{
+  int x;
+  ev[0] = s[0];
+  od[0] = s[1];
+  ev[1] = avgub (s[0], s[2]);
+  od[1] = s[1];
+  if (isa == 2)
+    simd_avx2_horiz_upsample_unaligned (ev + 2, od + 2, s + 1, (w - 4) >> 1);
+  else
+    simd_sse2_horiz_upsample_unaligned (ev + 2, od + 2, s + 1, (w - 4) >> 1);
+  for (x = w - 2; x < w; x++) {
+    if ((x & 1) == 0) {
+      ev[x] = s[x];
+      od[x] = s[x - 1];
+    } else {
+      ev[x] = s[x - 1];
+      od[x] = s[x];
+    }
+  }
+}
+
+/* row kernels: 0 = the scalar restatement above, 1 = the reference's own
+ * compiled kernels (oracle/_ref), 2 = SSE2, 3 = AVX2 restatement of the ORC
+ * programs (bayer2rgb_simd.c) */
+enum { ROWS_OWN = 0, ROWS_REF = 1, ROWS_SSE2 = 2, ROWS_AVX2 = 3 };
+
+static void
+any_row_lines (int mode, uint8_t *ev, uint8_t *od, const uint8_t *s, int w)
+{
+  if (mode == ROWS_REF)
+    ref_row_lines (ev, od, s, w);
+  else if (mode == ROWS_OWN)
+    own_row_lines (ev, od, s, w);
+  else
+    simd_row_lines (mode - 1, ev, od, s, w);
+}
+
+/* gst_bayer2rgb_process, gstbayer2rgb.c:387-451; output rows y0 <= j < y1
+ * only (a horizontal band of the frame; 0, h = the reference's whole-frame
+ * loop).  A band primes the ring the way the reference primes it for row 0. */
 static int
-frame_driver (uint8_t *dst, int dst_stride, const uint8_t *src, int src_stride,
-    int w, int h, int pattern, int r_off, int g_off, int b_off, int use_ref)
+frame_driver_rows (uint8_t *dst, int dst_stride, const uint8_t *src,
+    int src_stride, int w, int h, int pattern, int r_off, int g_off, int b_off,
+    int mode, int y0, int y1)
 {
   int j, layout, swap_rows;
   uint8_t *ring;
@@ -214,8 +268,16 @@ frame_driver (uint8_t *dst, int dst_stride, const uint8_t *src, int src_stride,
     return -1;
   if (pattern < 0 || pattern > 3)
     return -1;
-  if (use_ref && !g_ref.handle)
+  if (mode == ROWS_REF && !g_ref.handle)
     return -1;
+  if (mode < ROWS_OWN || mode > ROWS_AVX2)
+    return -1;
+  if (mode == ROWS_AVX2 && oracle_simd_best_isa () < 2)
+    return -1;
+  if (y0 < 0 || y1 > h || y0 > y1)
+    return -1;
+  if (y0 == y1)
+    return 0;
 
   /* :400-407 "For RGGB, we swap the red offset and blue offset" (also GBRG) */
   if (pattern == ORACLE_BAYER_RGGB || pattern == ORACLE_BAYER_GBRG) {
@@ -235,30 +297,37 @@ frame_driver (uint8_t *dst, int dst_stride, const uint8_t *src, int src_stride,
     return -1;
 #define SLOT(n) (ring + (size_t) ((n) & 7) * w)
 
-  /* :432-436 prime: row 1 stands in for row -1 (slot 3), then row 0 */
-  if (use_ref) {
-    ref_row_lines (SLOT (6), SLOT (7), src + (size_t) src_stride, w);
-    ref_row_lines (SLOT (0), SLOT (1), src, w);
-  } else {
-    own_row_lines (SLOT (6), SLOT (7), src + (size_t) src_stride, w);
-    own_row_lines (SLOT (0), SLOT (1), src, w);
-  }
+  /* :432-436 prime: row 1 stands in for row -1 (slot 3), then row 0; a band
+   * that starts lower primes with rows y0-1 and y0 in the slots the whole-frame
+   * loop would hold them in */
+  any_row_lines (mode, SLOT (2 * y0 - 2), SLOT (2 * y0 - 1),
+      src + (size_t) (y0 > 0 ? y0 - 1 : 1) * src_stride, w);
+  any_row_lines (mode, SLOT (2 * y0), SLOT (2 * y0 + 1),
+      src + (size_t) y0 * src_stride, w);
 
   /* :438-448 */
-  for (j = 0; j < h; j++) {
+  for (j = y0; j < y1; j++) {
     int type = (j & 1) ^ swap_rows;     /* 0 = merge_bg, 1 = merge_gr */
     uint8_t *d = dst + (size_t) j * dst_stride;
     if (j < h - 1) {
       const uint8_t *s = src + (size_t) (j + 1) * src_stride;
-      if (use_ref)
-        ref_row_lines (SLOT (2 * j + 2), SLOT (2 * j + 3), s, w);
-      else
-        own_row_lines (SLOT (2 * j + 2), SLOT (2 * j + 3), s, w);
+      any_row_lines (mode, SLOT (2 * j + 2), SLOT (2 * j + 3), s, w);
+    } else if (j - y0 < 3) {
+      /* the last row pairs with whatever the ring slot (2j+2)&7 still holds:
+       * row h-4 in the whole-frame loop (row 1, the stand-in for row -1, when
+       * h == 3; :430-447).  A band that has not been running for three rows
+       * yet computes that row explicitly. */
+      any_row_lines (mode, SLOT (2 * j + 2), SLOT (2 * j + 3),
+          src + (size_t) (h >= 4 ? h - 4 : 1) * src_stride, w);
     }
-    if (use_ref) {
+    if (mode == ROWS_REF) {
       g_ref.merge[layout][type] (d, SLOT (2 * j - 2), SLOT (2 * j - 1),
           SLOT (2 * j), SLOT (2 * j + 1), SLOT (2 * j + 2), SLOT (2 * j + 3),
           w >> 1);
+    } else if (mode >= ROWS_SSE2) {
+      simd_merge (mode - 1, layout, type, d, SLOT (2 * j - 2),
+          SLOT (2 * j - 1), SLOT (2 * j), SLOT (2 * j + 1), SLOT (2 * j + 2),
+          SLOT (2 * j + 3), w >> 1);
     } else if (type == 0) {
       own_merge_bg (d, SLOT (2 * j - 2), SLOT (2 * j - 1), SLOT (2 * j),
           SLOT (2 * j + 1), SLOT (2 * j + 2), SLOT (2 * j + 3), w >> 1,
@@ -274,13 +343,21 @@ frame_driver (uint8_t *dst, int dst_stride, const uint8_t *src, int src_stride,
   return 0;
 }
 
+static int
+frame_driver (uint8_t *dst, int dst_stride, const uint8_t *src, int src_stride,
+    int w, int h, int pattern, int r_off, int g_off, int b_off, int mode)
+{
+  return frame_driver_rows (dst, dst_stride, src, src_stride, w, h, pattern,
+      r_off, g_off, b_off, mode, 0, h);
+}
+
 int
 oracle_bayer2rgb (uint8_t *dst, int dst_stride, const uint8_t *src,
     int src_stride, int width, int height, int pattern, int r_off, int g_off,
     int b_off)
 {
   return frame_driver (dst, dst_stride, src, src_stride, width, height,
-      pattern, r_off, g_off, b_off, 0);
+      pattern, r_off, g_off, b_off, ROWS_OWN);
 }
 
 int
@@ -289,10 +366,19 @@ oracle_bayer2rgb_refrows (uint8_t *dst, int dst_stride, const uint8_t *src,
     int b_off)
 {
   return frame_driver (dst, dst_stride, src, src_stride, width, height,
-      pattern, r_off, g_off, b_off, 1);
+      pattern, r_off, g_off, b_off, ROWS_REF);
 }
 
-/* ---- batch (frame-parallel) ------------------------------------------------ */
+int
+oracle_bayer2rgb_mode (uint8_t *dst, int dst_stride, const uint8_t *src,
+    int src_stride, int width, int height, int pattern, int r_off, int g_off,
+    int b_off, int mode, int y0, int y1)
+{
+  return frame_driver_rows (dst, dst_stride, src, src_stride, width, height,
+      pattern, r_off, g_off, b_off, mode, y0, y1 < 0 ? height : y1);
+}
+
+/* ---- batch (frame- and band-parallel) ------------------------------------------ */
 
 struct batch_job
 {
@@ -302,36 +388,47 @@ struct batch_job
   const uint8_t *src;
   size_t src_frame_bytes;
   int src_stride;
-  int w, h, pattern, r, g, b, nframes, nthreads, tid, use_ref, rc;
+  int w, h, pattern, r, g, b, nframes, nbands, nthreads, tid, mode, rc;
 };
 
 static void *
 batch_worker (void *arg)
 {
   struct batch_job *jb = (struct batch_job *) arg;
-  int f;
-  for (f = jb->tid; f < jb->nframes; f += jb->nthreads) {
-    int rc = frame_driver (jb->dst + (size_t) f * jb->dst_frame_bytes,
+  long job, njobs = (long) jb->nframes * jb->nbands;
+  for (job = jb->tid; job < njobs; job += jb->nthreads) {
+    const int f = (int) (job / jb->nbands), band = (int) (job % jb->nbands);
+    const int y0 = (int) ((long) jb->h * band / jb->nbands);
+    const int y1 = (int) ((long) jb->h * (band + 1) / jb->nbands);
+    int rc = frame_driver_rows (jb->dst + (size_t) f * jb->dst_frame_bytes,
         jb->dst_stride, jb->src + (size_t) f * jb->src_frame_bytes,
         jb->src_stride, jb->w, jb->h, jb->pattern, jb->r, jb->g, jb->b,
-        jb->use_ref);
+        jb->mode, y0, y1);
     if (rc)
       jb->rc = rc;
   }
   return NULL;
 }
 
+/* nframes x nbands independent jobs (frame f, rows h*b/nbands .. h*(b+1)/nbands),
+ * job k on thread k mod nthreads */
 int
-oracle_bayer2rgb_batch (uint8_t *dst, size_t dst_frame_bytes, int dst_stride,
-    const uint8_t *src, size_t src_frame_bytes, int src_stride,
+oracle_bayer2rgb_batch_bands (uint8_t *dst, size_t dst_frame_bytes,
+    int dst_stride, const uint8_t *src, size_t src_frame_bytes, int src_stride,
     int width, int height, int pattern, int r_off, int g_off, int b_off,
-    int nframes, int nthreads, int use_ref_rows)
+    int nframes, int nbands, int nthreads, int mode)
 {
   int t, rc = 0;
+  long njobs;
+  if (nbands < 1)
+    nbands = 1;
+  if (nbands > height)
+    nbands = height;
+  njobs = (long) nframes * nbands;
   if (nthreads < 1)
     nthreads = 1;
-  if (nthreads > nframes)
-    nthreads = nframes > 0 ? nframes : 1;
+  if (nthreads > njobs)
+    nthreads = njobs > 0 ? (int) njobs : 1;
   struct batch_job *jobs = calloc ((size_t) nthreads, sizeof *jobs);
   pthread_t *th = calloc ((size_t) nthreads, sizeof *th);
   if (!jobs || !th) {
@@ -342,21 +439,35 @@ oracle_bayer2rgb_batch (uint8_t *dst, size_t dst_frame_bytes, int dst_stride,
   for (t = 0; t < nthreads; t++) {
     struct batch_job jb = { dst, dst_frame_bytes, dst_stride, src,
       src_frame_bytes, src_stride, width, height, pattern, r_off, g_off,
-      b_off, nframes, nthreads, t, use_ref_rows, 0
+      b_off, nframes, nbands, nthreads, t, mode, 0
     };
     jobs[t] = jb;
-    if (t > 0)
-      pthread_create (&th[t], NULL, batch_worker, &jobs[t]);
+    if (t > 0 && pthread_create (&th[t], NULL, batch_worker, &jobs[t]) != 0) {
+      batch_worker (&jobs[t]);  /* no thread to be had: do its share here */
+      th[t] = 0;
+    }
   }
   batch_worker (&jobs[0]);
   for (t = 1; t < nthreads; t++)
-    pthread_join (th[t], NULL);
+    if (th[t])
+      pthread_join (th[t], NULL);
   for (t = 0; t < nthreads; t++)
     if (jobs[t].rc)
       rc = jobs[t].rc;
   free (jobs);
   free (th);
   return rc;
+}
+
+int
+oracle_bayer2rgb_batch (uint8_t *dst, size_t dst_frame_bytes, int dst_stride,
+    const uint8_t *src, size_t src_frame_bytes, int src_stride,
+    int width, int height, int pattern, int r_off, int g_off, int b_off,
+    int nframes, int nthreads, int use_ref_rows)
+{
+  return oracle_bayer2rgb_batch_bands (dst, dst_frame_bytes, dst_stride, src,
+      src_frame_bytes, src_stride, width, height, pattern, r_off, g_off, b_off,
+      nframes, 1, nthreads, use_ref_rows ? ROWS_REF : ROWS_OWN);
 }
 
 /* ---- rgb2bayer --------------------------------------------------------------- */

@@ -58,6 +58,34 @@ int oracle_bayer2rgb_batch (uint8_t *dst, size_t dst_frame_bytes, int dst_stride
     int width, int height, int pattern, int r_off, int g_off, int b_off,
     int nframes, int nthreads, int use_ref_rows);
 
+/* Row-kernel selection for the two entry points below: 0 = the scalar
+ * restatement, 1 = the reference's compiled row kernels (oracle/_ref, load them
+ * first), 2 = SSE2, 3 = AVX2 restatement of the ORC programs as the pavgb /
+ * punpck sequences they compile to (bayer2rgb_simd.c; -1 if the CPU lacks the
+ * ISA).  All four are byte-identical (tests/test_oracle.py). */
+enum {
+  ORACLE_ROWS_OWN = 0,
+  ORACLE_ROWS_REF = 1,
+  ORACLE_ROWS_SSE2 = 2,
+  ORACLE_ROWS_AVX2 = 3
+};
+/* 1 = SSE2 only, 2 = AVX2 available */
+int oracle_simd_best_isa (void);
+
+/* One frame, output rows y0 <= j < y1 only (y1 < 0: height): the unit of the
+ * band-parallel CPU baseline.  Rows outside the band are not touched. */
+int oracle_bayer2rgb_mode (uint8_t *dst, int dst_stride, const uint8_t *src,
+    int src_stride, int width, int height, int pattern, int r_off, int g_off,
+    int b_off, int mode, int y0, int y1);
+
+/* nframes x nbands independent jobs (frame f, rows h*b/nbands .. h*(b+1)/nbands)
+ * spread over nthreads pthreads: lets the all-cores baseline use every core of
+ * the host whatever the number of frames. */
+int oracle_bayer2rgb_batch_bands (uint8_t *dst, size_t dst_frame_bytes,
+    int dst_stride, const uint8_t *src, size_t src_frame_bytes, int src_stride,
+    int width, int height, int pattern, int r_off, int g_off, int b_off,
+    int nframes, int nbands, int nthreads, int mode);
+
 /* Inverse element rgb2bayer, reference gst/bayer/gstrgb2bayer.c:254-268: output
  * byte (j,i) is byte r_off / g_off / b_off of input pixel (j,i) according to the
  * CFA site ((j&1)<<1)|(i&1); the reference hard-codes ARGB (r,g,b = 1,2,3).

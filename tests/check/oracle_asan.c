@@ -17,12 +17,13 @@ main (void)
   int w, h, p, l, n = 0;
   unsigned seed = 12345;
 
-  for (w = 4; w <= 70; w += 2) {
+  for (w = 4; w <= 78; w += 2) {
     for (h = 3; h <= 9; h++) {
       int sstride = (w + 3) & ~3;
       uint8_t *src = malloc ((size_t) sstride * h);
       uint8_t *dst = malloc ((size_t) 4 * w * h);
       uint8_t *back = malloc ((size_t) sstride * h);
+      uint8_t *alt = malloc ((size_t) 4 * w * h);
       size_t i;
 
       for (i = 0; i < (size_t) sstride * h; i++) {
@@ -34,6 +35,21 @@ main (void)
           if (oracle_bayer2rgb (dst, 4 * w, src, sstride, w, h, p, layouts[l][0], layouts[l][1],
                   layouts[l][2]) != 0)
             return 2;
+          /* the SIMD restatements of the ORC programs and the band-parallel driver: same bytes, and no
+           * access outside the exact-size buffers (vector loops + scalar tails at every width) */
+          {
+            int mode, cut = 1 + (w + h + p) % (h - 1);
+            for (mode = ORACLE_ROWS_SSE2; mode <= ORACLE_ROWS_SSE2 + oracle_simd_best_isa () - 1; mode++) {
+              memset (alt, 0x5a, (size_t) 4 * w * h);
+              if (oracle_bayer2rgb_mode (alt, 4 * w, src, sstride, w, h, p, layouts[l][0], layouts[l][1],
+                      layouts[l][2], mode, 0, cut) != 0
+                  || oracle_bayer2rgb_mode (alt, 4 * w, src, sstride, w, h, p, layouts[l][0], layouts[l][1],
+                      layouts[l][2], mode, cut, h) != 0)
+                return 9;
+              if (memcmp (alt, dst, (size_t) 4 * w * h) != 0)
+                return 10;
+            }
+          }
           /* exact left inverse */
           if (oracle_rgb2bayer (back, sstride, dst, 4 * w, w, h, p, layouts[l][0], layouts[l][1],
                   layouts[l][2]) != 0)
@@ -47,6 +63,7 @@ main (void)
       free (src);
       free (dst);
       free (back);
+      free (alt);
     }
   }
   {
@@ -62,8 +79,13 @@ main (void)
   }
   {
     uint8_t *frames = malloc ((size_t) 3 * 5 * 36);
+    uint8_t *outs = malloc ((size_t) 3 * 5 * 4 * 34);
     oracle_fill_synthetic (frames, 34, 5, 36, (size_t) 5 * 36, 2, 3, 9);
+    if (oracle_bayer2rgb_batch_bands (outs, (size_t) 5 * 4 * 34, 4 * 34, frames, (size_t) 5 * 36, 36, 34, 5, 1,
+            2, 1, 0, 3, 4, 5, ORACLE_ROWS_SSE2) != 0)
+      return 11;
     free (frames);
+    free (outs);
   }
   printf ("sanitized oracle: %d conversions ok\n", n);
   return 0;

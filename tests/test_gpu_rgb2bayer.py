@@ -27,6 +27,33 @@ def test_rgb2bayer_matches_oracle_all_sizes(gpu_pkg, oracle):
                 assert (got_d[:, w:] == 0).all()         # padding columns are written as zero on the device
 
 
+@pytest.mark.parametrize("shape", ["0:2", "0:8", "1:4", "2:8", "4:4", "4:8", "8:8"])
+@pytest.mark.parametrize("ldnt", ["0", "1"])
+def test_rgb2bayer_every_launch_shape_is_bit_exact(gpu_pkg, oracle, shape, ldnt, monkeypatch):
+    """The tile kernel (flat = 0, rows per block) and every flat-kernel shape (groups per thread : pixels per group,
+    with and without the nt hint on the loads), in both block orders, on sizes that exercise row-straddling waves,
+    odd dword counts per row (8-pixel groups fall back to 4), padded strides, partial last dwords and batches."""
+    flat, px = shape.split(":")
+    monkeypatch.setenv("MIBAYER_R2B_FLAT", flat)
+    monkeypatch.setenv("MIBAYER_R2B_ROWS" if flat == "0" else "MIBAYER_R2B_PX", px)
+    monkeypatch.setenv("MIBAYER_R2B_LDNT", ldnt)
+    rng = np.random.default_rng(19)
+    for band in ("-1", "0"):
+        monkeypatch.setenv("MIBAYER_XCD_BAND", band)
+        for (w, h, n, pad) in [(1, 1, 1, 0), (5, 7, 2, 0), (12, 5, 3, 0), (66, 50, 2, 0), (130, 21, 5, 24),
+                               (1000, 33, 2, 0), (1024, 64, 3, 0), (2056, 19, 2, 16), (3840, 37, 2, 0)]:
+            src = rng.integers(0, 256, (n, h, 4 * w + pad), dtype=np.uint8)
+            with gpu_pkg.Context(w, h, "gbrg", (1, 2, 3), src_stride=4 * w + pad,
+                                 flags=gpu_pkg.FLAG_RGB2BAYER) as ctx:
+                got = ctx.process_batch_via_device(src)
+                one = ctx.process_host(src[0])
+            for f in range(n):
+                want = oracle.rgb2bayer(src[f], w, "gbrg", 1, 2, 3)
+                assert np.array_equal(got[f][:, :w], want[:, :w]), (shape, ldnt, band, w, h, f)
+                assert (got[f][:, w:] == 0).all()
+            assert np.array_equal(one[:, :w], oracle.rgb2bayer(src[0], w, "gbrg", 1, 2, 3)[:, :w])
+
+
 @pytest.mark.parametrize("bands", ["", "1", "3", "8"], ids=["default", "1", "3", "8"])
 def test_rgb2bayer_banded_synchronous_host_path(gpu_pkg, oracle, bands, monkeypatch):
     """Frames of 16 MB input and more go through the synchronous host path in horizontal bands (16-row units), like

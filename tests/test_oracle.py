@@ -93,6 +93,65 @@ def test_own_rows_equal_reference_rows(oracle):
                 assert np.array_equal(a, b_), (w, h, pat, lay)
 
 
+def test_simd_row_kernels_equal_reference_rows(oracle):
+    """The "ORC-equivalent" SSE2 / AVX2 row kernels (oracle/bayer2rgb_simd.c, the SIMD leg of bench.py's
+    cpu_baseline) against the reference's own compiled row kernels (oracle/_ref) and the scalar restatement:
+    widths around every vector-loop boundary (8 / 16 pixel pairs per iteration + scalar tails)."""
+    have_ref = oracle.have_ref_rows()
+    rng = np.random.default_rng(15)
+    sizes = [(4, 3), (6, 4), (18, 5), (20, 5), (22, 7), (34, 6), (36, 4), (38, 9), (66, 50), (130, 33),
+             (256, 8), (258, 8), (1920, 6), (3840, 5)]
+    for (w, h) in sizes:
+        stride = (w + 3) & ~3
+        src = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+        if w == 66:
+            src[::2] = 255      # rounding stress: 255/254 pairs and zeros
+            src[1::2] &= 1
+        for pat in PATTERNS:
+            for lay in LAYOUTS:
+                r, g, b = oracle.LAYOUTS[lay]
+                want = oracle.bayer2rgb(src, w, pat, r, g, b, ref_rows=have_ref)
+                for isa in oracle.simd_isas():
+                    got = oracle.bayer2rgb_mode(src, w, pat, r, g, b, mode=isa)
+                    assert np.array_equal(got, want), (w, h, pat, lay, isa)
+
+
+def test_row_bands_equal_whole_frame(oracle):
+    """Band-parallel driver of the all-cores baseline: any cut of a frame into horizontal bands reproduces the
+    whole-frame loop, including the last row's pairing with row H-4 when the last band is shorter than 4 rows."""
+    rng = np.random.default_rng(16)
+    for (w, h) in [(16, 3), (16, 4), (18, 5), (34, 9), (64, 48), (130, 33)]:
+        src = rng.integers(0, 256, (h, (w + 3) & ~3), dtype=np.uint8)
+        for pat in ("bggr", "grbg"):
+            want = oracle.bayer2rgb(src, w, pat, 2, 1, 0)
+            for mode in ["own"] + oracle.simd_isas():
+                for cut in range(1, h):
+                    dst = np.full((h, 4 * w), 0xA5, np.uint8)
+                    oracle.bayer2rgb_mode(src, w, pat, 2, 1, 0, mode=mode, y0=0, y1=cut, dst=dst)
+                    assert (dst[cut:] == 0xA5).all()
+                    oracle.bayer2rgb_mode(src, w, pat, 2, 1, 0, mode=mode, y0=cut, y1=h, dst=dst)
+                    assert np.array_equal(dst, want), (w, h, pat, mode, cut)
+    src = oracle.fill_synthetic(64, 48, 5, seed=12)
+    one = np.stack([oracle.bayer2rgb(f, 64, "gbrg", 0, 1, 2) for f in src])
+    for mode in ["own"] + oracle.simd_isas():
+        for nbands, nt in ((1, 3), (7, 4), (48, 16), (100, 5)):
+            got = oracle.bayer2rgb_batch_bands(src, 64, "gbrg", 0, 1, 2, nbands=nbands, nthreads=nt, mode=mode)
+            assert np.array_equal(got, one), (mode, nbands, nt)
+
+
+def test_simd_known_md5_answers(oracle):
+    """The SIMD forms reproduce the whole-element md5 known answers of the compiled reference element too."""
+    with open(os.path.join(ROOT, "tests", "golden", "known_md5.json")) as f:
+        entries = json.load(f)["entries"]
+    for e in entries:
+        if e["width"] * e["height"] > 3840 * 2160:
+            continue
+        src = oracle.fill_synthetic(e["width"], e["height"], 1, e["seed"])[0]
+        r, g, b = oracle.LAYOUTS[e["format"]]
+        for isa in oracle.simd_isas():
+            assert md5(oracle.bayer2rgb_mode(src, e["width"], e["pattern"], r, g, b, mode=isa)) == e["md5_output"], (e, isa)
+
+
 def test_extreme_inputs_closed_form_vs_ring(oracle):
     # rounding stress: all-0, all-255, 0/255 checkerboards, gradients
     w, h = 34, 12

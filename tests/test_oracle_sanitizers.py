@@ -12,7 +12,8 @@ def test_oracle_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "oracle_asan")
     cmd = ["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=gnu11", "-Wall",
            "-I", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "check", "oracle_asan.c"),
-           os.path.join(ROOT, "oracle", "bayer2rgb_oracle.c"), "-o", exe, "-ldl", "-lpthread"]
+           os.path.join(ROOT, "oracle", "bayer2rgb_oracle.c"), os.path.join(ROOT, "oracle", "bayer2rgb_simd.c"),
+           "-o", exe, "-ldl", "-lpthread"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0 and "sanitize" in res.stderr:
         pytest.skip("sanitizer runtime not available: " + res.stderr[-200:])
