@@ -102,6 +102,10 @@ ABI = {
     "mibayer_pool_pending": (ctypes.c_int, [_vp]),
     "mibayer_pool_submit": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "mibayer_pool_wait": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "mibayer_pool_alive": (ctypes.c_int, [_vp]),
+    "mibayer_pool_take_failure": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                                 ctypes.c_char_p, ctypes.c_size_t]),
+    "mibayer_pool_inject_fault": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_longlong]),
     "mibayer_process_device": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
                                               ctypes.c_int, _vp]),
     "mibayer_ctx_stream": (_vp, [_vp]),
@@ -114,6 +118,9 @@ ABI = {
     "mibayer_copy_plan": (ctypes.c_int, [_vp, _vp]),
     "mibayer_host_alloc": (_vp, [ctypes.c_size_t]),
     "mibayer_host_free": (None, [_vp]),
+    "mibayer_host_alloc_near": (_vp, [ctypes.c_int, ctypes.c_size_t]),
+    "mibayer_device_numa_node": (ctypes.c_int, [ctypes.c_int]),
+    "mibayer_host_numa_node": (ctypes.c_int, [_vp]),
     "mibayer_device_alloc": (_vp, [_vp, ctypes.c_size_t]),
     "mibayer_device_free": (None, [_vp, _vp]),
     "mibayer_copy_to_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
@@ -222,6 +229,19 @@ class Pool:
 
     def pending(self):
         return lib().mibayer_pool_pending(self._h)
+
+    def alive(self):
+        return lib().mibayer_pool_alive(self._h)
+
+    def inject_fault(self, shard, after_frames):
+        _check(lib().mibayer_pool_inject_fault(self._h, shard, after_frames), "mibayer_pool_inject_fault")
+
+    def take_failure(self):
+        """(devices dropped since the last call, ordinal of the latest, devices left, message)"""
+        dev, alive = ctypes.c_int(-1), ctypes.c_int(0)
+        buf = ctypes.create_string_buffer(300)
+        n = lib().mibayer_pool_take_failure(self._h, ctypes.byref(dev), ctypes.byref(alive), buf, len(buf))
+        return n, dev.value, alive.value, buf.value.decode()
 
     def close(self):
         if getattr(self, "_h", None):

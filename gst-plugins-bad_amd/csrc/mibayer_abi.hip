@@ -10,7 +10,12 @@
  * No CPU compute path exists in this library.
  */
 #include "../../include/mibayer.h"
+#include "mibayer_hooks.h"
 #include "mibayer_internal.h"
+
+#include <dlfcn.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <limits.h>
 #include <mutex>
@@ -60,6 +65,58 @@ struct DeviceGuard {
   {
     if (prev >= 0)
       (void) hipSetDevice (prev);
+  }
+};
+
+/* ROCTx ranges around the host side of every stage (upload / kernel / download
+ * enqueue, the wait for a frame, a device-resident launch): `rocprofv3
+ * --marker-trace` shows them on the timeline next to the copies and kernels they
+ * queue.  The reference's tracer hooks on this path are its debug category and
+ * the GST_DEBUG lines of the transform (gstbayer2rgb.c:92-93, :201, :465).  The
+ * ROCTx library is looked up at run time (rocprofiler-sdk's, then the legacy
+ * one): libmibayer.so keeps depending on the HIP runtime only, and without the
+ * library a range costs one predictable branch. */
+struct Roctx {
+  int (*push) (const char *) = nullptr;
+  int (*pop) () = nullptr;
+};
+
+const Roctx &roctx ()
+{
+  static const Roctx r = [] {
+    Roctx x;
+    const char *off = getenv ("MIBAYER_ROCTX");
+    if (off && off[0] == '0')
+      return x;
+    for (const char *name : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so",
+            "libroctx64.so.4", "libroctx64.so" }) {
+      void *h = dlopen (name, RTLD_NOW | RTLD_LOCAL);
+      if (!h)
+        continue;
+      x.push = (int (*) (const char *)) dlsym (h, "roctxRangePushA");
+      x.pop = (int (*) ()) dlsym (h, "roctxRangePop");
+      if (x.push && x.pop)
+        return x;
+      x.push = nullptr;
+      x.pop = nullptr;
+      dlclose (h);
+    }
+    return x;
+  } ();
+  return r;
+}
+
+struct Range {
+  bool on;
+  explicit Range (const char *name) : on (roctx ().push != nullptr)
+  {
+    if (on)
+      (void) roctx ().push (name);
+  }
+  ~Range ()
+  {
+    if (on)
+      (void) roctx ().pop ();
   }
 };
 
@@ -131,6 +188,8 @@ struct mibayer_ctx {
   hipStream_t s_d2h = nullptr;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   std::vector<Slot> ring;
+  Slot spare;                   /* mibayer_internal_run_spare: outside the ring */
+  bool spare_ready = false;
   int head = 0;                 /* next slot to submit into */
   int tail = 0;                 /* oldest in-flight slot    */
   int pending = 0;
@@ -582,32 +641,37 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   return MIBAYER_OK;
 }
 
+static void free_slot (Slot &s)
+{
+  if (s.d_src)
+    (void) hipFree (s.d_src);
+  if (s.d_dst)
+    (void) hipFree (s.d_dst);
+  if (s.ev_in)
+    (void) hipEventDestroy (s.ev_in);
+  if (s.ev_kernel)
+    (void) hipEventDestroy (s.ev_kernel);
+  if (s.ev_out)
+    (void) hipEventDestroy (s.ev_out);
+  for (int b = 0; b < kMaxHostBands; b++) {
+    if (s.ev_band_in[b])
+      (void) hipEventDestroy (s.ev_band_in[b]);
+    if (s.ev_band_kernel[b])
+      (void) hipEventDestroy (s.ev_band_kernel[b]);
+  }
+  if (s.exec)
+    (void) hipGraphExecDestroy (s.exec);
+  if (s.graph)
+    (void) hipGraphDestroy (s.graph);
+  if (s.s_graph)
+    (void) hipStreamDestroy (s.s_graph);
+  s = Slot ();
+}
+
 static void free_ring (mibayer_ctx *c)
 {
-  for (Slot &s : c->ring) {
-    if (s.d_src)
-      (void) hipFree (s.d_src);
-    if (s.d_dst)
-      (void) hipFree (s.d_dst);
-    if (s.ev_in)
-      (void) hipEventDestroy (s.ev_in);
-    if (s.ev_kernel)
-      (void) hipEventDestroy (s.ev_kernel);
-    if (s.ev_out)
-      (void) hipEventDestroy (s.ev_out);
-    for (int b = 0; b < kMaxHostBands; b++) {
-      if (s.ev_band_in[b])
-        (void) hipEventDestroy (s.ev_band_in[b]);
-      if (s.ev_band_kernel[b])
-        (void) hipEventDestroy (s.ev_band_kernel[b]);
-    }
-    if (s.exec)
-      (void) hipGraphExecDestroy (s.exec);
-    if (s.graph)
-      (void) hipGraphDestroy (s.graph);
-    if (s.s_graph)
-      (void) hipStreamDestroy (s.s_graph);
-  }
+  for (Slot &s : c->ring)
+    free_slot (s);
   c->ring.clear ();
 }
 
@@ -626,6 +690,7 @@ extern "C" void mibayer_destroy (mibayer_ctx *c)
     if (sl.s_graph)
       (void) hipStreamSynchronize (sl.s_graph);
   free_ring (c);
+  free_slot (c->spare);
   if (c->ev_t0)
     (void) hipEventDestroy (c->ev_t0);
   if (c->ev_t1)
@@ -707,39 +772,45 @@ extern "C" int mibayer_launch_geometry (const mibayer_ctx *c, int nframes,
 
 /* ---- host-memory frame path -------------------------------------------------------- */
 
+/* device-side frames and events of one slot; `bands`: per-band events too */
+static int alloc_slot (mibayer_ctx *c, Slot &s, bool bands)
+{
+  bool bad = false;
+  const hipError_t e_src = hipMalloc ((void **) &s.d_src, c->src_bytes);
+  const hipError_t e_dst = e_src == hipSuccess
+      ? hipMalloc ((void **) &s.d_dst, c->dst_bytes) : e_src;
+  if (e_src == hipErrorOutOfMemory || e_dst == hipErrorOutOfMemory) {
+    (void) hip_failed (hipErrorOutOfMemory, "hipMalloc (frame ring)");
+    (void) hipGetLastError ();
+    return MIBAYER_ERR_NOMEM;
+  }
+  bad |= hip_failed (e_src, "hipMalloc");
+  bad |= hip_failed (e_dst, "hipMalloc");
+  bad |= hip_failed (hipEventCreateWithFlags (&s.ev_in,
+          hipEventDisableTiming), "hipEventCreate");
+  bad |= hip_failed (hipEventCreateWithFlags (&s.ev_kernel,
+          hipEventDisableTiming), "hipEventCreate");
+  bad |= hip_failed (hipEventCreateWithFlags (&s.ev_out,
+          hipEventDisableTiming), "hipEventCreate");
+  for (int b = 0; bands && b < c->host_bands && c->host_bands > 1; b++) {
+    bad |= hip_failed (hipEventCreateWithFlags (&s.ev_band_in[b],
+            hipEventDisableTiming), "hipEventCreate");
+    bad |= hip_failed (hipEventCreateWithFlags (&s.ev_band_kernel[b],
+            hipEventDisableTiming), "hipEventCreate");
+  }
+  return bad ? MIBAYER_ERR_HIP : MIBAYER_OK;
+}
+
 static int ensure_ring (mibayer_ctx *c)
 {
   if (!c->ring.empty ())
     return MIBAYER_OK;
   c->ring.resize ((size_t) c->cfg.inflight);
   for (Slot &s : c->ring) {
-    bool bad = false;
-    const hipError_t e_src = hipMalloc ((void **) &s.d_src, c->src_bytes);
-    const hipError_t e_dst = e_src == hipSuccess
-        ? hipMalloc ((void **) &s.d_dst, c->dst_bytes) : e_src;
-    if (e_src == hipErrorOutOfMemory || e_dst == hipErrorOutOfMemory) {
-      (void) hip_failed (hipErrorOutOfMemory, "hipMalloc (frame ring)");
-      (void) hipGetLastError ();
+    const int rc = alloc_slot (c, s, true);
+    if (rc != MIBAYER_OK) {
       free_ring (c);
-      return MIBAYER_ERR_NOMEM;
-    }
-    bad |= hip_failed (e_src, "hipMalloc");
-    bad |= hip_failed (e_dst, "hipMalloc");
-    bad |= hip_failed (hipEventCreateWithFlags (&s.ev_in,
-            hipEventDisableTiming), "hipEventCreate");
-    bad |= hip_failed (hipEventCreateWithFlags (&s.ev_kernel,
-            hipEventDisableTiming), "hipEventCreate");
-    bad |= hip_failed (hipEventCreateWithFlags (&s.ev_out,
-            hipEventDisableTiming), "hipEventCreate");
-    for (int b = 0; b < c->host_bands && c->host_bands > 1; b++) {
-      bad |= hip_failed (hipEventCreateWithFlags (&s.ev_band_in[b],
-              hipEventDisableTiming), "hipEventCreate");
-      bad |= hip_failed (hipEventCreateWithFlags (&s.ev_band_kernel[b],
-              hipEventDisableTiming), "hipEventCreate");
-    }
-    if (bad) {
-      free_ring (c);
-      return MIBAYER_ERR_HIP;
+      return rc;
     }
   }
   c->head = c->tail = c->pending = 0;
@@ -893,6 +964,48 @@ static int enqueue_frame_banded (mibayer_ctx *c, Slot &s, const uint8_t *src,
   return MIBAYER_OK;
 }
 
+/* upload -> kernel -> download of one frame through slot `s`, chained by events
+ * across the three queues */
+static int enqueue_plain (mibayer_ctx *c, Slot &s, const uint8_t *src,
+    uint8_t *dst, size_t row_bytes)
+{
+  {
+    Range r ("mibayer:h2d");
+    HIP_TRY (hipMemcpyAsync (s.d_src, src, c->src_bytes, hipMemcpyHostToDevice,
+            c->s_h2d));
+    HIP_TRY (hipEventRecord (s.ev_in, c->s_h2d));
+  }
+  {
+    Range r ("mibayer:kernel");
+    HIP_TRY (hipStreamWaitEvent (c->s_compute, s.ev_in, 0));
+    const int rc = launch (c, s.d_src, c->src_bytes, s.d_dst, c->dst_bytes, 1,
+        c->s_compute);
+    if (rc != MIBAYER_OK)
+      return rc;
+    HIP_TRY (hipEventRecord (s.ev_kernel, c->s_compute));
+  }
+  Range r ("mibayer:d2h");
+  HIP_TRY (hipStreamWaitEvent (c->s_d2h, s.ev_kernel, 0));
+  if ((size_t) c->cfg.dst_stride == row_bytes) {
+    HIP_TRY (hipMemcpyAsync (dst, s.d_dst, c->dst_bytes, hipMemcpyDeviceToHost,
+            c->s_d2h));
+  } else {
+    /* padded destination rows: only the written bytes of each row may be
+     * touched (the reference never writes the padding either) */
+    HIP_TRY (hipMemcpy2DAsync (dst, (size_t) c->cfg.dst_stride, s.d_dst,
+            (size_t) c->cfg.dst_stride, row_bytes, (size_t) c->cfg.height,
+            hipMemcpyDeviceToHost, c->s_d2h));
+  }
+  HIP_TRY (hipEventRecord (s.ev_out, c->s_d2h));
+  return MIBAYER_OK;
+}
+
+static size_t written_row_bytes (const mibayer_ctx *c)
+{
+  return c->inverse ? (size_t) ((c->cfg.width + 3) & ~3)
+      : (size_t) 4 * c->cfg.width;
+}
+
 static int enqueue_frame (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
     void *tag, bool alone)
 {
@@ -902,8 +1015,7 @@ static int enqueue_frame (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
   if (c->pending == (int) c->ring.size ())
     return MIBAYER_ERR_BUSY;
   Slot &s = c->ring[(size_t) c->head];
-  const size_t row_bytes = c->inverse ? (size_t) ((c->cfg.width + 3) & ~3)
-      : (size_t) 4 * c->cfg.width;      /* bytes of a destination row that are written */
+  const size_t row_bytes = written_row_bytes (c);       /* bytes of a destination row that are written */
   if ((c->cfg.flags & MIBAYER_FLAG_HIPGRAPH) && !c->inverse
       && (size_t) c->cfg.dst_stride == row_bytes) {
     rc = graph_submit (c, s, src, dst);
@@ -925,28 +1037,9 @@ static int enqueue_frame (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
     c->pending++;
     return MIBAYER_OK;
   }
-  /* upload -> kernel -> download, chained by events across three queues */
-  HIP_TRY (hipMemcpyAsync (s.d_src, src, c->src_bytes, hipMemcpyHostToDevice,
-          c->s_h2d));
-  HIP_TRY (hipEventRecord (s.ev_in, c->s_h2d));
-  HIP_TRY (hipStreamWaitEvent (c->s_compute, s.ev_in, 0));
-  rc = launch (c, s.d_src, c->src_bytes, s.d_dst, c->dst_bytes, 1,
-      c->s_compute);
+  rc = enqueue_plain (c, s, src, dst, row_bytes);
   if (rc != MIBAYER_OK)
     return rc;
-  HIP_TRY (hipEventRecord (s.ev_kernel, c->s_compute));
-  HIP_TRY (hipStreamWaitEvent (c->s_d2h, s.ev_kernel, 0));
-  if ((size_t) c->cfg.dst_stride == row_bytes) {
-    HIP_TRY (hipMemcpyAsync (dst, s.d_dst, c->dst_bytes, hipMemcpyDeviceToHost,
-            c->s_d2h));
-  } else {
-    /* padded destination rows: only the 4*width written bytes of each row may
-     * be touched (the reference never writes the padding either) */
-    HIP_TRY (hipMemcpy2DAsync (dst, (size_t) c->cfg.dst_stride, s.d_dst,
-            (size_t) c->cfg.dst_stride, row_bytes, (size_t) c->cfg.height,
-            hipMemcpyDeviceToHost, c->s_d2h));
-  }
-  HIP_TRY (hipEventRecord (s.ev_out, c->s_d2h));
   s.tag = tag;
   c->head = (c->head + 1) % (int) c->ring.size ();
   c->pending++;
@@ -979,7 +1072,10 @@ static int wait_locked (mibayer_ctx *c, void **tag)
   if (c->pending == 0)
     return MIBAYER_ERR_EMPTY;
   Slot &s = c->ring[(size_t) c->tail];
-  HIP_TRY (hipEventSynchronize (s.ev_out));
+  {
+    Range r ("mibayer:wait");
+    HIP_TRY (hipEventSynchronize (s.ev_out));
+  }
   if (tag)
     *tag = s.tag;
   c->tail = (c->tail + 1) % (int) c->ring.size ();
@@ -1030,90 +1126,63 @@ extern "C" int mibayer_process_host (mibayer_ctx *c, const uint8_t *src,
   return wait_locked (c, NULL);
 }
 
-/* ---- multi-GPU frame sharding ---------------------------------------------------------- */
+/* ---- seam for the frame-sharding pool (mibayer_hooks.h, mibayer_pool.cpp) ------------------ */
 
-struct mibayer_pool {
-  std::vector<mibayer_ctx *> shards;
-  unsigned long long submitted = 0;     /* frames handed in  */
-  unsigned long long completed = 0;     /* frames handed back */
-};
-
-extern "C" int mibayer_pool_create (const mibayer_pool_cfg *cfg,
-    mibayer_pool **out)
+extern "C" int mibayer_internal_run_spare (mibayer_ctx *c, const uint8_t *src,
+    uint8_t *dst)
 {
-  if (!out)
+  if (!c || !src || !dst)
     return MIBAYER_ERR_ARG;
-  *out = NULL;
-  if (!cfg || cfg->struct_size != sizeof (mibayer_pool_cfg))
-    return MIBAYER_ERR_ARG;
-  if (cfg->ndevices < 1 || cfg->ndevices > MIBAYER_MAX_SHARDS)
-    return MIBAYER_ERR_ARG;
-  mibayer_pool *pool = new (std::nothrow) mibayer_pool ();
-  if (!pool)
-    return MIBAYER_ERR_NOMEM;
-  for (int i = 0; i < cfg->ndevices; i++) {
-    mibayer_cfg one = cfg->stream;
-    one.device = cfg->devices[i];
-    if (one.device < 0) {
-      mibayer_pool_destroy (pool);
-      return MIBAYER_ERR_NO_DEVICE;
-    }
-    mibayer_ctx *c = NULL;
-    int rc = mibayer_create (&one, &c);
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  if (!c->spare_ready) {
+    const int rc = alloc_slot (c, c->spare, false);
     if (rc != MIBAYER_OK) {
-      mibayer_pool_destroy (pool);
+      free_slot (c->spare);
       return rc;
     }
-    pool->shards.push_back (c);
+    c->spare_ready = true;
   }
-  *out = pool;
+  int rc = enqueue_plain (c, c->spare, src, dst, written_row_bytes (c));
+  if (rc != MIBAYER_OK) {
+    /* nothing of a half-queued frame may touch the buffers after the error */
+    (void) hipStreamSynchronize (c->s_h2d);
+    (void) hipStreamSynchronize (c->s_compute);
+    (void) hipStreamSynchronize (c->s_d2h);
+    return rc;
+  }
+  Range r ("mibayer:wait");
+  HIP_TRY (hipEventSynchronize (c->spare.ev_out));
   return MIBAYER_OK;
 }
 
-extern "C" void mibayer_pool_destroy (mibayer_pool *pool)
+extern "C" int mibayer_internal_is_pageable (const void *p)
 {
-  if (!pool)
+  hipPointerAttribute_t attr;
+  memset (&attr, 0, sizeof attr);
+  if (hipPointerGetAttributes (&attr, p) != hipSuccess) {
+    (void) hipGetLastError ();  /* "invalid value" is the answer for plain malloc memory */
+    return 1;
+  }
+  return attr.type == hipMemoryTypeUnregistered ? 1 : 0;
+}
+
+extern "C" void mibayer_internal_abandon (mibayer_ctx *c)
+{
+  if (!c)
     return;
-  for (mibayer_ctx *c : pool->shards)
-    mibayer_destroy (c);
-  delete pool;
-}
-
-extern "C" int mibayer_pool_capacity (const mibayer_pool *pool)
-{
-  if (!pool)
-    return MIBAYER_ERR_ARG;
-  return (int) pool->shards.size () * pool->shards[0]->cfg.inflight;
-}
-
-extern "C" int mibayer_pool_pending (const mibayer_pool *pool)
-{
-  return pool ? (int) (pool->submitted - pool->completed) : MIBAYER_ERR_ARG;
-}
-
-extern "C" int mibayer_pool_submit (mibayer_pool *pool, const uint8_t *src,
-    uint8_t *dst, void *tag)
-{
-  if (!pool)
-    return MIBAYER_ERR_ARG;
-  mibayer_ctx *c = pool->shards[pool->submitted % pool->shards.size ()];
-  int rc = mibayer_submit (c, src, dst, tag);
-  if (rc == MIBAYER_OK)
-    pool->submitted++;
-  return rc;
-}
-
-extern "C" int mibayer_pool_wait (mibayer_pool *pool, void **tag)
-{
-  if (!pool)
-    return MIBAYER_ERR_ARG;
-  if (pool->submitted == pool->completed)
-    return MIBAYER_ERR_EMPTY;
-  mibayer_ctx *c = pool->shards[pool->completed % pool->shards.size ()];
-  int rc = mibayer_wait (c, tag);
-  if (rc == MIBAYER_OK)
-    pool->completed++;
-  return rc;
+  DeviceGuard guard (c->device);
+  if (c->s_h2d)
+    (void) hipStreamSynchronize (c->s_h2d);
+  if (c->s_compute)
+    (void) hipStreamSynchronize (c->s_compute);
+  if (c->s_d2h)
+    (void) hipStreamSynchronize (c->s_d2h);
+  for (Slot &sl : c->ring)
+    if (sl.s_graph)
+      (void) hipStreamSynchronize (sl.s_graph);
+  (void) hipGetLastError ();
 }
 
 /* ---- device-resident batch path ------------------------------------------------------ */
@@ -1133,6 +1202,7 @@ extern "C" int mibayer_process_device (mibayer_ctx *c, const void *d_src,
   DeviceGuard guard (c->device);
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
+  Range r ("mibayer:process_device");
   return launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes,
       (hipStream_t) hip_stream);
 }
@@ -1316,6 +1386,80 @@ extern "C" void *mibayer_host_alloc (size_t bytes)
           "hipHostMalloc"))
     return NULL;
   return p;
+}
+
+/* NUMA node of the CPU memory closest to a device: the runtime's answer, else
+ * the PCI device's numa_node in sysfs; -1 = unknown / not a NUMA machine */
+extern "C" int mibayer_device_numa_node (int device)
+{
+  if (device < 0 || device >= device_count_cached ())
+    return -1;
+  int node = -1;
+  if (hipDeviceGetAttribute (&node, hipDeviceAttributeHostNumaId, device)
+      == hipSuccess && node >= 0)
+    return node;
+  (void) hipGetLastError ();
+  char bdf[64] = "";
+  if (hipDeviceGetPCIBusId (bdf, (int) sizeof bdf, device) != hipSuccess) {
+    (void) hipGetLastError ();
+    return -1;
+  }
+  for (char *q = bdf; *q; q++)
+    if (*q >= 'A' && *q <= 'F')
+      *q = (char) (*q - 'A' + 'a');
+  char path[160];
+  snprintf (path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE *f = fopen (path, "r");
+  if (!f)
+    return -1;
+  node = -1;
+  if (fscanf (f, "%d", &node) != 1)
+    node = -1;
+  fclose (f);
+  return node;
+}
+
+/* Pinned memory on the NUMA node next to `device`, for buffer pools that feed
+ * that GPU: on a two-socket host a pool allocated by whatever thread happened to
+ * configure it puts half of the frames behind the socket link.  The thread's
+ * memory policy is set to "prefer that node" around a hipHostMallocNumaUser
+ * allocation (which follows the caller's policy) and restored; freed with
+ * mibayer_host_free like any other pinned block.  Falls back to
+ * mibayer_host_alloc when the node is unknown. */
+extern "C" void *mibayer_host_alloc_near (int device, size_t bytes)
+{
+  const int node = mibayer_device_numa_node (device);
+  if (node < 0 || node >= 1024)
+    return mibayer_host_alloc (bytes);
+  constexpr int kMpolDefault = 0, kMpolPreferred = 1;
+  unsigned long mask[1024 / (8 * sizeof (unsigned long))];
+  memset (mask, 0, sizeof mask);
+  mask[(size_t) node / (8 * sizeof (unsigned long))]
+      |= 1ul << ((size_t) node % (8 * sizeof (unsigned long)));
+  const bool bound = syscall (SYS_set_mempolicy, kMpolPreferred, mask,
+      (unsigned long) (8 * sizeof mask)) == 0;
+  void *p = NULL;
+  const bool bad = hip_failed (hipHostMalloc (&p, bytes ? bytes : 1,
+          bound ? hipHostMallocNumaUser : hipHostMallocDefault), "hipHostMalloc");
+  if (bound)
+    (void) syscall (SYS_set_mempolicy, kMpolDefault, NULL, 0ul);
+  if (bad) {
+    (void) hipGetLastError ();
+    return mibayer_host_alloc (bytes);
+  }
+  return p;
+}
+
+/* NUMA node that holds the first page of `p` (-1 if the kernel does not say) */
+extern "C" int mibayer_host_numa_node (const void *p)
+{
+  if (!p)
+    return -1;
+  void *page = (void *) ((uintptr_t) p & ~(uintptr_t) 4095);
+  int status = -1;
+  if (syscall (SYS_move_pages, 0, 1ul, &page, NULL, &status, 0) != 0)
+    return -1;
+  return status;
 }
 
 extern "C" void mibayer_host_free (void *p)

@@ -1,0 +1,41 @@
+/* Internal seam between the frame-sharding pool (mibayer_pool.cpp: pure host
+ * logic, no HIP call in it) and the per-device stream context
+ * (mibayer_abi.hip).  The pool only ever talks to a device through the public
+ * per-context ABI of include/mibayer.h plus the three entry points below, so the
+ * whole failover / ordering / helper-thread logic can be built against a test
+ * double of the contexts and run on a machine without a GPU, under
+ * AddressSanitizer and ThreadSanitizer (tests/check/mock_mibayer.c,
+ * tests/test_pool_logic.py).  Exported, but not part of the public ABI. */
+#ifndef MIBAYER_HOOKS_H
+#define MIBAYER_HOOKS_H
+
+#include "../../include/mibayer.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One whole frame, synchronously, through a spare device-side slot of the
+ * context that is NOT part of its submit/wait ring: upload, kernel and download
+ * are queued behind whatever the context's streams already hold, and the call
+ * returns when `dst` is complete.  Safe to call from one other thread while the
+ * owner of the context uses mibayer_submit / mibayer_wait (the ring state is not
+ * touched; HIP streams are thread-safe); two concurrent calls on one context are
+ * not allowed.  This is what the pool's per-shard helper thread runs for frames
+ * in pageable memory, and what re-does the frames of a device that failed. */
+int mibayer_internal_run_spare (mibayer_ctx *ctx, const uint8_t *src,
+    uint8_t *dst);
+
+/* 1 when `p` is ordinary pageable host memory (an asynchronous copy from / to it
+ * blocks the calling thread while the runtime stages it), 0 for pinned /
+ * registered / device memory. */
+int mibayer_internal_is_pageable (const void *p);
+
+/* Best-effort quiesce of a context whose device reported an error: waits for
+ * whatever still completes, never fails. */
+void mibayer_internal_abandon (mibayer_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

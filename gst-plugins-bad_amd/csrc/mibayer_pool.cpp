@@ -1,0 +1,467 @@
+/*
+ * mibayer_pool -- round-robin frame sharding over GPUs (include/mibayer.h,
+ * "multi-GPU frame sharding").  Pure host logic: no HIP call in this file, the
+ * devices are reached through the per-context ABI and csrc/mibayer_hooks.h
+ * only, so the same code runs over a test double of the contexts under
+ * AddressSanitizer / ThreadSanitizer (tests/test_pool_logic.py).
+ *
+ * Frames are independent (the reference keeps no state between frames,
+ * gstbayer2rgb.c:387-451): frame g goes to the next device in rotation and the
+ * results come back in submission order.  On top of that, three things a
+ * production multi-GPU stream needs:
+ *
+ *  - FAILOVER.  The reference's only failure handling on this path is "warn and
+ *    carry on" (gstbayer2rgb.c:484-486).  Here a device whose context reports
+ *    MIBAYER_ERR_HIP / MIBAYER_ERR_NOMEM is dropped from the rotation, the
+ *    frames it still held are converted again on the surviving devices (same
+ *    bytes: the conversion is a pure function of the frame), order is kept, and
+ *    the event is reported once (mibayer_pool_take_failure).  The stream fails
+ *    only when no device is left.
+ *
+ *  - PAGEABLE BUFFERS.  hipMemcpyAsync from / to pageable memory blocks the
+ *    calling thread while the runtime stages it, so one streaming thread would
+ *    feed N GPUs one after the other.  A frame whose source or destination is
+ *    pageable is handed to a helper thread of its shard (one per shard, started
+ *    on first use), which runs the whole frame synchronously through a spare
+ *    slot of the context; the streaming thread only queues and, at wait time,
+ *    blocks on the oldest frame.  Pinned frames keep the direct, enqueue-only
+ *    path.  (A second CPU copy through a pinned bounce buffer was rejected: the
+ *    runtime's own staging moves ~40 GB/s, a memcpy thread ~10.)
+ *
+ *  - FAULT INJECTION for drills and tests: mibayer_pool_inject_fault() /
+ *    MIBAYER_INJECT_FAULT=shard:frames make a shard report a device error after
+ *    it has completed that many frames.
+ */
+#include "mibayer_hooks.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <thread>
+#include <vector>
+
+namespace {
+
+enum FrameState {
+  F_DIRECT,     /* in the ring of its shard's context (mibayer_submit)            */
+  F_QUEUED,     /* in the job queue of its shard's helper thread                  */
+  F_RUNNING,    /* the helper thread is converting it                             */
+  F_DONE,       /* converted by a helper thread (or by a synchronous re-do)       */
+  F_FAILED,     /* the helper thread got a device error for it                    */
+  F_REDO        /* its device failed: convert again on a surviving device         */
+};
+
+struct Frame {
+  const uint8_t *src;
+  uint8_t *dst;
+  void *tag;
+  int shard;    /* where it is (being) converted  */
+  int owner;    /* whose in-flight budget it uses */
+  int state;    /* FrameState; helper-thread frames: under Shard::mu */
+  int rc;
+};
+
+struct Shard {
+  mibayer_ctx *ctx = nullptr;
+  int device = 0;
+  bool alive = true;
+  int inflight = 0;             /* frames owned and not yet handed back (streaming thread) */
+  std::atomic<long long> completions { 0 };
+  std::atomic<long long> fail_after { -1 };     /* fault injection; -1 = never */
+  /* helper thread */
+  std::thread th;
+  bool th_started = false;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::deque<Frame *> jobs;
+  bool quit = false;
+  bool broken = false;
+  char errmsg[200] = "";
+
+  /* true exactly once, when the shard has completed `fail_after` frames */
+  bool fault_due ()
+  {
+    const long long n = ++completions;
+    const long long at = fail_after.load ();
+    return at >= 0 && n > at;
+  }
+};
+
+bool device_failure (int rc)
+{
+  return rc == MIBAYER_ERR_HIP || rc == MIBAYER_ERR_NOMEM;
+}
+
+void helper_main (Shard *sh)
+{
+  std::unique_lock<std::mutex> lk (sh->mu);
+  for (;;) {
+    sh->cv_job.wait (lk, [sh] { return sh->quit || !sh->jobs.empty (); });
+    if (sh->jobs.empty ())
+      return;                   /* quit */
+    Frame *f = sh->jobs.front ();
+    sh->jobs.pop_front ();
+    if (sh->broken) {
+      f->state = F_REDO;
+      sh->cv_done.notify_all ();
+      continue;
+    }
+    f->state = F_RUNNING;
+    lk.unlock ();
+    int rc = mibayer_internal_run_spare (sh->ctx, f->src, f->dst);
+    if (rc == MIBAYER_OK && sh->fault_due ())
+      rc = MIBAYER_ERR_HIP;
+    lk.lock ();
+    f->rc = rc;
+    if (rc == MIBAYER_OK) {
+      f->state = F_DONE;
+    } else {
+      f->state = F_FAILED;
+      if (device_failure (rc)) {
+        sh->broken = true;
+        snprintf (sh->errmsg, sizeof sh->errmsg, "%s", mibayer_last_hip_error ());
+      }
+    }
+    sh->cv_done.notify_all ();
+  }
+}
+
+}  /* namespace */
+
+struct mibayer_pool {
+  std::vector<Shard *> shards;
+  std::deque<Frame> fifo;       /* submission order; element addresses are stable */
+  int per_shard = 2;            /* stream.inflight */
+  size_t rr = 0;                /* shard whose turn it is */
+  size_t redo_rr = 0;
+  bool use_helpers = true;      /* MIBAYER_POOL_HELPERS=0: pageable frames on the calling thread */
+  /* failure report */
+  int unreported = 0;
+  int failed_device = -1;
+  char failure_msg[320] = "";
+};
+
+static int alive_count (const mibayer_pool *pool)
+{
+  int n = 0;
+  for (const Shard *s : pool->shards)
+    n += s->alive ? 1 : 0;
+  return n;
+}
+
+/* drop shard `idx` from the rotation; everything it still holds is re-done */
+static void kill_shard (mibayer_pool *pool, int idx, int rc, const char *why)
+{
+  Shard *sh = pool->shards[(size_t) idx];
+  if (!sh->alive)
+    return;
+  sh->alive = false;
+  {
+    std::lock_guard<std::mutex> lk (sh->mu);
+    sh->broken = true;
+    for (Frame *f : sh->jobs)
+      f->state = F_REDO;
+    sh->jobs.clear ();
+    if (!why || !why[0])
+      why = sh->errmsg;
+  }
+  for (Frame &f : pool->fifo)
+    if (f.shard == idx && f.state == F_DIRECT)
+      f.state = F_REDO;
+  pool->unreported++;
+  pool->failed_device = sh->device;
+  snprintf (pool->failure_msg, sizeof pool->failure_msg,
+      "shard %d (HIP device %d) dropped from the rotation: %.60s%s%.150s; %d device(s) left",
+      idx, sh->device, mibayer_strerror (rc), why && why[0] ? " -- " : "",
+      why ? why : "", alive_count (pool));
+  /* after this nothing of that context touches the callers' buffers any more */
+  mibayer_internal_abandon (sh->ctx);
+}
+
+/* the helper thread of a live shard has seen a device error that the streaming
+ * thread has not come across yet (the failed frame sits further back in the
+ * queue): take the shard out now, or re-done frames would bounce off it forever */
+static bool reap_if_broken (mibayer_pool *pool, int idx)
+{
+  Shard *sh = pool->shards[(size_t) idx];
+  bool broken;
+  {
+    std::lock_guard<std::mutex> lk (sh->mu);
+    broken = sh->broken;
+  }
+  if (broken && sh->alive)
+    kill_shard (pool, idx, MIBAYER_ERR_HIP, NULL);
+  return broken;
+}
+
+static void start_helper (Shard *sh)
+{
+  if (!sh->th_started) {
+    sh->th = std::thread (helper_main, sh);
+    sh->th_started = true;
+  }
+}
+
+static void queue_to_helper (Shard *sh, Frame *f)
+{
+  start_helper (sh);
+  std::lock_guard<std::mutex> lk (sh->mu);
+  f->state = F_QUEUED;
+  sh->jobs.push_back (f);
+  sh->cv_job.notify_one ();
+}
+
+extern "C" int mibayer_pool_create (const mibayer_pool_cfg *cfg,
+    mibayer_pool **out)
+{
+  if (!out)
+    return MIBAYER_ERR_ARG;
+  *out = NULL;
+  if (!cfg || cfg->struct_size != sizeof (mibayer_pool_cfg))
+    return MIBAYER_ERR_ARG;
+  if (cfg->ndevices < 1 || cfg->ndevices > MIBAYER_MAX_SHARDS)
+    return MIBAYER_ERR_ARG;
+  mibayer_pool *pool = new (std::nothrow) mibayer_pool ();
+  if (!pool)
+    return MIBAYER_ERR_NOMEM;
+  for (int i = 0; i < cfg->ndevices; i++) {
+    mibayer_cfg one = cfg->stream;
+    one.device = cfg->devices[i];
+    if (one.device < 0) {
+      mibayer_pool_destroy (pool);
+      return MIBAYER_ERR_NO_DEVICE;
+    }
+    mibayer_ctx *c = NULL;
+    int rc = mibayer_create (&one, &c);
+    if (rc != MIBAYER_OK) {
+      mibayer_pool_destroy (pool);
+      return rc;
+    }
+    Shard *sh = new (std::nothrow) Shard ();
+    if (!sh) {
+      mibayer_destroy (c);
+      mibayer_pool_destroy (pool);
+      return MIBAYER_ERR_NOMEM;
+    }
+    sh->ctx = c;
+    sh->device = one.device;
+    pool->shards.push_back (sh);
+  }
+  {
+    mibayer_cfg resolved;
+    if (mibayer_get_cfg (pool->shards[0]->ctx, &resolved) == MIBAYER_OK
+        && resolved.inflight > 0)
+      pool->per_shard = resolved.inflight;
+  }
+  if (const char *e = getenv ("MIBAYER_POOL_HELPERS"))
+    pool->use_helpers = atoi (e) != 0;
+  if (const char *e = getenv ("MIBAYER_INJECT_FAULT")) {
+    /* "shard:frames[,shard:frames...]" */
+    while (*e) {
+      char *end = NULL;
+      const long s = strtol (e, &end, 10);
+      if (end == e || *end != ':')
+        break;
+      e = end + 1;
+      const long long n = strtoll (e, &end, 10);
+      if (end == e)
+        break;
+      (void) mibayer_pool_inject_fault (pool, (int) s, n);
+      e = (*end == ',') ? end + 1 : end;
+    }
+  }
+  *out = pool;
+  return MIBAYER_OK;
+}
+
+extern "C" void mibayer_pool_destroy (mibayer_pool *pool)
+{
+  if (!pool)
+    return;
+  for (Shard *sh : pool->shards) {
+    if (sh->th_started) {
+      {
+        std::lock_guard<std::mutex> lk (sh->mu);
+        sh->quit = true;
+        sh->broken = true;      /* queued jobs are not started any more */
+        sh->cv_job.notify_all ();
+      }
+      sh->th.join ();
+    }
+    mibayer_destroy (sh->ctx);
+    delete sh;
+  }
+  delete pool;
+}
+
+extern "C" int mibayer_pool_capacity (const mibayer_pool *pool)
+{
+  if (!pool)
+    return MIBAYER_ERR_ARG;
+  return alive_count (pool) * pool->per_shard;
+}
+
+extern "C" int mibayer_pool_alive (const mibayer_pool *pool)
+{
+  return pool ? alive_count (pool) : MIBAYER_ERR_ARG;
+}
+
+extern "C" int mibayer_pool_pending (const mibayer_pool *pool)
+{
+  return pool ? (int) pool->fifo.size () : MIBAYER_ERR_ARG;
+}
+
+extern "C" int mibayer_pool_inject_fault (mibayer_pool *pool, int shard,
+    long long after_frames)
+{
+  if (!pool || shard < 0 || shard >= (int) pool->shards.size ())
+    return MIBAYER_ERR_ARG;
+  Shard *sh = pool->shards[(size_t) shard];
+  sh->fail_after.store (after_frames < 0 ? -1
+      : sh->completions.load () + after_frames);
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_pool_take_failure (mibayer_pool *pool, int *device,
+    int *alive, char *msg, size_t msg_len)
+{
+  if (!pool)
+    return MIBAYER_ERR_ARG;
+  if (pool->unreported == 0)
+    return 0;
+  const int n = pool->unreported;
+  pool->unreported = 0;
+  if (device)
+    *device = pool->failed_device;
+  if (alive)
+    *alive = alive_count (pool);
+  if (msg && msg_len)
+    snprintf (msg, msg_len, "%s", pool->failure_msg);
+  return n;
+}
+
+extern "C" int mibayer_pool_submit (mibayer_pool *pool, const uint8_t *src,
+    uint8_t *dst, void *tag)
+{
+  if (!pool || !src || !dst)
+    return MIBAYER_ERR_ARG;
+  const size_t n = pool->shards.size ();
+  for (;;) {
+    /* the next live shard in rotation */
+    size_t idx = n;
+    for (size_t k = 0; k < n; k++) {
+      const size_t i = (pool->rr + k) % n;
+      if (pool->shards[i]->alive) {
+        idx = i;
+        break;
+      }
+    }
+    if (idx == n)
+      return MIBAYER_ERR_HIP;   /* no device left */
+    Shard *sh = pool->shards[idx];
+    if (reap_if_broken (pool, (int) idx))
+      continue;
+    if (sh->inflight >= pool->per_shard)
+      return MIBAYER_ERR_BUSY;
+    Frame f = { src, dst, tag, (int) idx, (int) idx, F_DIRECT, MIBAYER_OK };
+    const bool pageable = pool->use_helpers
+        && (mibayer_internal_is_pageable (src)
+            || mibayer_internal_is_pageable (dst));
+    if (pageable) {
+      pool->fifo.push_back (f);
+      queue_to_helper (sh, &pool->fifo.back ());
+    } else {
+      const int rc = mibayer_submit (sh->ctx, src, dst, tag);
+      if (device_failure (rc)) {
+        kill_shard (pool, (int) idx, rc, mibayer_last_hip_error ());
+        continue;               /* this frame goes to the next live shard */
+      }
+      if (rc != MIBAYER_OK)
+        return rc;
+      pool->fifo.push_back (f);
+    }
+    sh->inflight++;
+    pool->rr = (idx + 1) % n;
+    return MIBAYER_OK;
+  }
+}
+
+extern "C" int mibayer_pool_wait (mibayer_pool *pool, void **tag)
+{
+  if (!pool)
+    return MIBAYER_ERR_ARG;
+  if (pool->fifo.empty ())
+    return MIBAYER_ERR_EMPTY;
+  Frame &f = pool->fifo.front ();
+  const size_t n = pool->shards.size ();
+  for (;;) {
+    Shard *sh = pool->shards[(size_t) f.shard];
+    int state;
+    {
+      std::unique_lock<std::mutex> lk (sh->mu);
+      sh->cv_done.wait (lk, [&f] {
+        return f.state != F_QUEUED && f.state != F_RUNNING;
+      });
+      state = f.state;
+    }
+    if (state == F_DONE)
+      break;
+    if (state == F_DIRECT) {
+      int rc = mibayer_wait (sh->ctx, NULL);
+      if (rc == MIBAYER_OK && sh->fault_due ())
+        rc = MIBAYER_ERR_HIP;
+      if (rc == MIBAYER_OK)
+        break;
+      if (!device_failure (rc))
+        return rc;
+      kill_shard (pool, f.shard, rc, mibayer_last_hip_error ());    /* f becomes F_REDO */
+      continue;
+    }
+    if (state == F_FAILED) {
+      if (!device_failure (f.rc))
+        return f.rc;
+      f.state = F_REDO;
+      kill_shard (pool, f.shard, f.rc, NULL);
+      continue;
+    }
+    /* F_REDO: once more on a device that is still in the rotation */
+    size_t idx = n;
+    for (size_t k = 0; k < n; k++) {
+      const size_t i = (pool->redo_rr + k) % n;
+      if (pool->shards[i]->alive) {
+        idx = i;
+        break;
+      }
+    }
+    if (idx == n)
+      return MIBAYER_ERR_HIP;   /* no device left: the stream has failed */
+    if (reap_if_broken (pool, (int) idx))
+      continue;
+    pool->redo_rr = (idx + 1) % n;
+    Shard *to = pool->shards[idx];
+    f.shard = (int) idx;
+    if (to->th_started) {
+      /* its helper thread owns the spare slot */
+      queue_to_helper (to, &f);
+      continue;
+    }
+    int rc = mibayer_internal_run_spare (to->ctx, f.src, f.dst);
+    if (rc == MIBAYER_OK && to->fault_due ())
+      rc = MIBAYER_ERR_HIP;
+    if (rc == MIBAYER_OK)
+      break;
+    if (!device_failure (rc))
+      return rc;
+    kill_shard (pool, (int) idx, rc, mibayer_last_hip_error ());
+  }
+  if (tag)
+    *tag = f.tag;
+  pool->shards[(size_t) f.owner]->inflight--;
+  pool->fifo.pop_front ();
+  return MIBAYER_OK;
+}

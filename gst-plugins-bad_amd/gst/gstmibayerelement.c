@@ -21,7 +21,16 @@
  *   - `inflight` > 1 and/or `devices` switch to a queued mode: input buffers
  *     are submitted to a round-robin pool of GPUs (frame g -> devices[g % N])
  *     and outputs are pushed in order as they complete; pending frames are
- *     drained before EOS / caps / segment events and dropped on flush.
+ *     drained before EOS / caps / segment events and dropped on flush
+ *     (FLUSH_START already, which arrives on another thread: the pool and the
+ *     queues sit behind `flow_lock`);
+ *   - a device that fails is dropped from the rotation by the pool, its frames are
+ *     converted again on the survivors, and the element posts ONE warning per
+ *     dropped device; the stream errors out only when no device is left.
+ * Geometry the HIP path cannot reproduce bit-exactly (odd width, width < 4,
+ * height < 3: the reference itself reads stale scratch / out of bounds there,
+ * gstbayer2rgb.c:365-380, :430-447) is refused in set_caps -> not-negotiated,
+ * the reference's own failure style (:263-265), not at the first buffer.
  *     In-tree precedent for queueing in submit_input_buffer/generate_output:
  *     sys/va/gstvadeinterlace.c:186-232, :467-531.
  */
@@ -100,25 +109,107 @@ post_gpu_failure (GstMiBayerElement * self, int rc)
       ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
 }
 
-/* wait for everything in flight; push it downstream (push == TRUE) or drop it */
+/* the pool dropped a device (flow_lock held): remember ONE note for the bus
+ * and follow the pool's new capacity */
+static void
+element_note_failures (GstMiBayerElement * self)
+{
+  char msg[300];
+  int device = -1, alive = 0;
+
+  if (self->pool == NULL
+      || mibayer_pool_take_failure (self->pool, &device, &alive, msg,
+          sizeof msg) <= 0)
+    return;
+  self->capacity = mibayer_pool_capacity (self->pool);
+  if (self->failure_note == NULL) {
+    self->failure_note = g_strdup (msg);
+  } else {
+    gchar *both = g_strconcat (self->failure_note, "; ", msg, NULL);
+
+    g_free (self->failure_note);
+    self->failure_note = both;
+  }
+}
+
+/* outside flow_lock: posting may run application code */
+static void
+element_post_notes (GstMiBayerElement * self)
+{
+  gchar *note;
+
+  g_mutex_lock (&self->flow_lock);
+  note = self->failure_note;
+  self->failure_note = NULL;
+  g_mutex_unlock (&self->flow_lock);
+  if (note != NULL) {
+    GST_ELEMENT_WARNING (self, RESOURCE, FAILED,
+        ("%s: a GPU failed and was dropped from the rotation; its frames were "
+            "converted again on the remaining device(s)", LABEL (self)),
+        ("%s", note));
+    g_free (note);
+  }
+}
+
+/* oldest frame (flow_lock held): wait for the GPU, unmap, hand the output buffer
+ * back.  *owned tells whether the caller now holds the only reference. */
+static GstFlowReturn
+element_collect_locked (GstMiBayerElement * self, GstBuffer ** outbuf,
+    gboolean * owned, int *gpu_rc)
+{
+  PendingFrame *p = g_queue_pop_head (&self->pending);
+  int rc;
+
+  *outbuf = NULL;
+  *owned = FALSE;
+  *gpu_rc = MIBAYER_OK;
+  if (p == NULL)
+    return GST_FLOW_OK;
+  rc = self->pool ? mibayer_pool_wait (self->pool, NULL) : MIBAYER_OK;
+  element_note_failures (self);
+  if (rc != MIBAYER_OK) {
+    pending_release (p, FALSE);
+    *gpu_rc = rc;
+    return GST_FLOW_ERROR;
+  }
+  *outbuf = p->outbuf;
+  *owned = p->owns_outbuf;
+  pending_release (p, TRUE);
+  return GST_FLOW_OK;
+}
+
+/* wait for everything in flight; push it downstream (push == TRUE) or drop it.
+ * The lock is never held across a push: FLUSH_START must get through while a
+ * push blocks downstream. */
 static GstFlowReturn
 element_drain (GstMiBayerElement * self, gboolean push)
 {
   GstFlowReturn ret = GST_FLOW_OK;
-  PendingFrame *p;
 
-  while ((p = g_queue_pop_head (&self->pending)) != NULL) {
-    GstBuffer *out = p->outbuf;
-    gboolean owned = p->owns_outbuf;
-    int rc = self->pool ? mibayer_pool_wait (self->pool, NULL) : MIBAYER_OK;
-    gboolean do_push = push && owned && rc == MIBAYER_OK && ret == GST_FLOW_OK;
+  for (;;) {
+    GstBuffer *out;
+    gboolean owned = TRUE, have;
+    int rc = MIBAYER_OK;
 
-    pending_release (p, do_push);
+    g_mutex_lock (&self->flow_lock);
+    out = g_queue_pop_head (&self->ready);
+    have = out != NULL;
+    if (!have && !g_queue_is_empty (&self->pending)) {
+      have = TRUE;
+      (void) element_collect_locked (self, &out, &owned, &rc);
+    }
+    g_mutex_unlock (&self->flow_lock);
+    if (!have)
+      break;
+    element_post_notes (self);
     if (rc != MIBAYER_OK) {
       post_gpu_failure (self, rc);
       ret = GST_FLOW_ERROR;
-    } else if (do_push) {
-      ret = gst_pad_push (GST_BASE_TRANSFORM_SRC_PAD (self), out);
+    } else if (out != NULL && owned) {
+      if (push && ret == GST_FLOW_OK && !g_atomic_int_get (&self->flushing))
+        ret = gst_pad_push (GST_BASE_TRANSFORM_SRC_PAD (self), out);
+      else
+        gst_buffer_unref (out);
     }
   }
   return ret;
@@ -128,12 +219,14 @@ static void
 element_drop_pool (GstMiBayerElement * self)
 {
   element_drain (self, FALSE);
+  g_mutex_lock (&self->flow_lock);
   if (self->pool) {
     mibayer_pool_destroy (self->pool);
     self->pool = NULL;
   }
   self->pool_stride = 0;
   self->capacity = 0;
+  g_mutex_unlock (&self->flow_lock);
 }
 
 /* reference gst_bayer2rgb_reset, gstbayer2rgb.c:278-287 */
@@ -155,11 +248,11 @@ element_parse_devices (GstMiBayerElement * self, mibayer_pool_cfg * pc)
   gchar **tok, **t;
 
   pc->ndevices = 0;
-  if (self->devices == NULL || self->devices[0] == '\0') {
-    pc->devices[pc->ndevices++] = self->device_id;
+  if (self->act.devices == NULL || self->act.devices[0] == '\0') {
+    pc->devices[pc->ndevices++] = self->act.device_id;
     return TRUE;
   }
-  tok = g_strsplit_set (self->devices, ",;: ", -1);
+  tok = g_strsplit_set (self->act.devices, ",;: ", -1);
   for (t = tok; *t != NULL; t++) {
     gchar *end = NULL;
     glong v;
@@ -199,7 +292,14 @@ element_ensure_pool (GstMiBayerElement * self, gint video_stride)
 
   if (self->pool && self->pool_stride == video_stride)
     return TRUE;
-  element_drop_pool (self);
+  /* (flow_lock held) a new stride with frames still in flight cannot happen:
+   * set_caps drained them; what is left is an idle pool of the old stride */
+  if (self->pool) {
+    mibayer_pool_destroy (self->pool);
+    self->pool = NULL;
+  }
+  self->pool_stride = 0;
+  self->capacity = 0;
 
   memset (&pc, 0, sizeof pc);
   pc.struct_size = sizeof pc;
@@ -217,12 +317,12 @@ element_ensure_pool (GstMiBayerElement * self, gint video_stride)
   pc.stream.r_off = self->r_off;
   pc.stream.g_off = self->g_off;
   pc.stream.b_off = self->b_off;
-  pc.stream.inflight = self->inflight;
-  pc.stream.flags = (self->use_hipgraph ? MIBAYER_FLAG_HIPGRAPH : 0)
+  pc.stream.inflight = self->act.inflight;
+  pc.stream.flags = (self->act.use_hipgraph ? MIBAYER_FLAG_HIPGRAPH : 0)
       | (inverse ? MIBAYER_FLAG_RGB2BAYER : 0);
   if (!element_parse_devices (self, &pc)) {
     GST_ELEMENT_ERROR (self, LIBRARY, SETTINGS,
-        ("%s: cannot parse devices=\"%s\"", LABEL (self), self->devices),
+        ("%s: cannot parse devices=\"%s\"", LABEL (self), self->act.devices),
         (NULL));
     return FALSE;
   }
@@ -233,8 +333,8 @@ element_ensure_pool (GstMiBayerElement * self, gint video_stride)
     if (rc == MIBAYER_ERR_NO_DEVICE) {
       GST_ELEMENT_ERROR (self, RESOURCE, NOT_FOUND,
           ("%s: no usable MI355X / HIP device (device-id=%d devices=%s)",
-              LABEL (self), self->device_id,
-              self->devices ? self->devices : ""),
+              LABEL (self), self->act.device_id,
+              self->act.devices ? self->act.devices : ""),
           ("%s; this element has no CPU path", mibayer_strerror (rc)));
     } else if (rc == MIBAYER_ERR_GEOMETRY) {
       GST_ELEMENT_ERROR (self, STREAM, FORMAT,
@@ -252,15 +352,15 @@ element_ensure_pool (GstMiBayerElement * self, gint video_stride)
   EL_DEBUG (self, "GPU pool: %d device(s), %d frame(s) in flight, "
       "%dx%d pattern %d stride %d%s", pc.ndevices, self->capacity, self->width,
       self->height, self->format, video_stride,
-      self->use_hipgraph ? ", hipGraph per frame" : "");
+      self->act.use_hipgraph ? ", hipGraph per frame" : "");
   return TRUE;
 }
 
 static inline gboolean
 element_is_queued_mode (GstMiBayerElement * self)
 {
-  return self->inflight > 1
-      || (self->devices != NULL && strchr (self->devices, ',') != NULL);
+  return self->act.inflight > 1
+      || (self->act.devices != NULL && strchr (self->act.devices, ',') != NULL);
 }
 
 /* ---- GObject ----------------------------------------------------------------- */
@@ -302,6 +402,7 @@ element_get_property (GObject * object, guint prop_id, GValue * value,
 {
   GstMiBayerElement *self = ELEMENT (object);
 
+  GST_OBJECT_LOCK (self);
   switch (prop_id) {
     case PROP_DEVICE_ID:
       g_value_set_int (value, self->device_id);
@@ -322,6 +423,7 @@ element_get_property (GObject * object, guint prop_id, GValue * value,
       G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
       break;
   }
+  GST_OBJECT_UNLOCK (self);
 }
 
 static void
@@ -332,6 +434,11 @@ element_finalize (GObject * object)
   element_drop_pool (self);
   g_free (self->devices);
   self->devices = NULL;
+  g_free (self->act.devices);
+  self->act.devices = NULL;
+  g_free (self->failure_note);
+  self->failure_note = NULL;
+  g_mutex_clear (&self->flow_lock);
   G_OBJECT_CLASS (BASE_CLASS (self))->finalize (object);
 }
 
@@ -419,6 +526,19 @@ element_set_caps (GstBaseTransform * base, GstCaps * incaps, GstCaps * outcaps)
 
   gst_structure_get_int (s, "width", &self->width);
   gst_structure_get_int (s, "height", &self->height);
+  /* The reference's templates say [1, MAX] for both and its set_caps takes
+   * anything, but its frame loop is only well defined for even widths >= 4 and
+   * heights >= 3 (it leaves the last column of an odd width unwritten and reads
+   * stale scratch for it, gstbayer2rgb.c:365-380; below three rows it reads rows
+   * that do not exist, :430-447).  There is nothing bit-exact to reproduce
+   * there, so such caps are refused here -- not-negotiated, the reference's own
+   * failure style (:263-265) -- instead of at the first buffer.  rgb2bayer has
+   * no neighbourhood and takes any size. */
+  if (!inverse && (self->width < 4 || (self->width & 1) || self->height < 3)) {
+    EL_WARNING (self, "refusing %dx%d: bayer2rgb needs an even width >= 4 and "
+        "a height >= 3", self->width, self->height);
+    return FALSE;
+  }
 
   order = gst_structure_get_string (s, "format");
   if (order == NULL)
@@ -455,9 +575,13 @@ element_make_pinned_pool (GstMiBayerElement * self, GstCaps * caps, guint size,
   GstBufferPool *pool;
   GstStructure *config;
 
+  mibayer_pool_cfg pc;
+
   if (mibayer_device_count () <= 0)
     return NULL;
-  pool = gst_mi_host_pool_new ();
+  /* pinned memory on the NUMA node next to the (first) GPU that will read it */
+  pool = gst_mi_host_pool_new (element_parse_devices (self, &pc)
+      ? pc.devices[0] : self->act.device_id);
   config = gst_buffer_pool_get_config (pool);
   gst_buffer_pool_config_set_params (config, caps, size, min, 0);
   if (!gst_buffer_pool_set_config (pool, config)) {
@@ -483,13 +607,13 @@ element_propose_allocation (GstBaseTransform * base, GstQuery * decide_query,
 
   if (!BASE_CLASS (self)->propose_allocation (base, decide_query, query))
     return FALSE;
-  if (!self->pinned_pool)
+  if (!self->act.pinned_pool)
     return TRUE;
   gst_query_parse_allocation (query, &caps, &need_pool);
   if (caps == NULL || !element_get_unit_size (base, caps, &size))
     return TRUE;
   /* every frame in flight keeps its input buffer mapped */
-  min = (guint) (MAX (self->inflight, 1) * element_ndevices (self) + 2);
+  min = (guint) (MAX (self->act.inflight, 1) * element_ndevices (self) + 2);
   pool = element_make_pinned_pool (self, caps, (guint) size, min);
   if (pool) {
     gst_query_add_allocation_pool (query, pool, (guint) size, min, 0);
@@ -506,7 +630,7 @@ element_decide_allocation (GstBaseTransform * base, GstQuery * query)
 {
   GstMiBayerElement *self = ELEMENT (base);
 
-  if (self->pinned_pool && gst_query_get_n_allocation_pools (query) == 0) {
+  if (self->act.pinned_pool && gst_query_get_n_allocation_pools (query) == 0) {
     GstCaps *caps = NULL;
     gsize size = 0;
 
@@ -528,11 +652,11 @@ element_decide_allocation (GstBaseTransform * base, GstQuery * query)
 
 /* ---- data flow -------------------------------------------------------------------- */
 
-/* map both buffers and hand the frame to the GPU pool; on success the mapped
- * frame is appended to self->pending */
+/* map both buffers and hand the frame to the GPU pool (flow_lock held); on
+ * success the mapped frame is appended to self->pending */
 static GstFlowReturn
 element_submit (GstMiBayerElement * self, GstBuffer * inbuf, GstBuffer * outbuf,
-    gboolean owns_outbuf)
+    gboolean owns_outbuf, int *gpu_rc)
 {
   const gboolean inverse = IS_INVERSE (self);
   GstBuffer *mosaic_buf = inverse ? outbuf : inbuf;
@@ -542,6 +666,7 @@ element_submit (GstMiBayerElement * self, GstBuffer * inbuf, GstBuffer * outbuf,
   guint8 *dst;
   int rc;
 
+  *gpu_rc = MIBAYER_OK;
   if (!gst_buffer_map (mosaic_buf, &p->mosaic,
           inverse ? GST_MAP_WRITE : GST_MAP_READ)) {
     g_free (p);
@@ -570,11 +695,25 @@ element_submit (GstMiBayerElement * self, GstBuffer * inbuf, GstBuffer * outbuf,
     src = p->mosaic.data;
     dst = GST_VIDEO_FRAME_PLANE_DATA (&p->video, 0);
   }
-  /* the call that replaces gst_bayer2rgb_process (gstbayer2rgb.c:475-477) /
-   * the pixel loop of gst_rgb2bayer_transform (gstrgb2bayer.c:254-268) */
-  rc = mibayer_pool_submit (self->pool, src, dst, p);
+  for (;;) {
+    GstBuffer *done = NULL;
+    gboolean owned = FALSE;
+
+    /* the call that replaces gst_bayer2rgb_process (gstbayer2rgb.c:475-477) /
+     * the pixel loop of gst_rgb2bayer_transform (gstrgb2bayer.c:254-268) */
+    rc = mibayer_pool_submit (self->pool, src, dst, p);
+    element_note_failures (self);
+    if (rc != MIBAYER_ERR_BUSY || g_queue_is_empty (&self->pending))
+      break;
+    /* a device was dropped and the pool holds fewer frames now: finish the
+     * oldest one to make room; it leaves the element before this one */
+    if (element_collect_locked (self, &done, &owned, &rc) != GST_FLOW_OK)
+      break;
+    if (done != NULL && owned)
+      g_queue_push_tail (&self->ready, done);
+  }
   if (rc != MIBAYER_OK) {
-    post_gpu_failure (self, rc);
+    *gpu_rc = rc;
     goto fail;
   }
   p->inbuf = gst_buffer_ref (inbuf);
@@ -591,27 +730,6 @@ fail:
   return GST_FLOW_ERROR;
 }
 
-/* oldest frame: wait for the GPU, unmap, hand the output buffer back */
-static GstFlowReturn
-element_collect (GstMiBayerElement * self, GstBuffer ** outbuf)
-{
-  PendingFrame *p = g_queue_pop_head (&self->pending);
-  int rc;
-
-  *outbuf = NULL;
-  if (p == NULL)
-    return GST_FLOW_OK;
-  rc = mibayer_pool_wait (self->pool, NULL);
-  if (rc != MIBAYER_OK) {
-    pending_release (p, FALSE);
-    post_gpu_failure (self, rc);
-    return GST_FLOW_ERROR;
-  }
-  *outbuf = p->outbuf;
-  pending_release (p, TRUE);
-  return GST_FLOW_OK;
-}
-
 /* reference gstbayer2rgb.c:456-487, gstrgb2bayer.c:230-278 -- synchronous mode,
  * the default */
 static GstFlowReturn
@@ -621,19 +739,26 @@ element_transform (GstBaseTransform * base, GstBuffer * inbuf,
   GstMiBayerElement *self = ELEMENT (base);
   GstFlowReturn ret;
   GstBuffer *done = NULL;
+  gboolean owned;
+  int rc = MIBAYER_OK;
 
   EL_DEBUG (self, "transforming buffer");
 
-  ret = element_submit (self, inbuf, outbuf, FALSE);
+  g_mutex_lock (&self->flow_lock);
+  ret = element_submit (self, inbuf, outbuf, FALSE, &rc);
+  if (ret == GST_FLOW_OK)       /* done == outbuf, still owned by the base class */
+    ret = element_collect_locked (self, &done, &owned, &rc);
+  g_mutex_unlock (&self->flow_lock);
+  element_post_notes (self);
   if (ret == GST_FLOW_CUSTOM_ERROR) {
     /* same as the reference: warn and skip (gstbayer2rgb.c:484-486,
      * gstrgb2bayer.c:274-276) */
     EL_WARNING (self, "Could not map buffer, skipping");
     return GST_FLOW_OK;
   }
-  if (ret != GST_FLOW_OK)
-    return ret;
-  return element_collect (self, &done);   /* done == outbuf, still owned by the base class */
+  if (rc != MIBAYER_OK)
+    post_gpu_failure (self, rc);
+  return ret;
 }
 
 /* queued mode: take the input the base class parked in queued_buf, submit it,
@@ -643,7 +768,10 @@ element_generate_output (GstBaseTransform * base, GstBuffer ** outbuf)
 {
   GstMiBayerElement *self = ELEMENT (base);
   GstBaseTransformClass *klass = GST_BASE_TRANSFORM_GET_CLASS (base);
+  GstFlowReturn ret = GST_FLOW_OK;
   GstBuffer *inbuf;
+  gboolean owned;
+  int rc = MIBAYER_OK;
 
   if (!element_is_queued_mode (self))
     return BASE_CLASS (self)->generate_output (base, outbuf);
@@ -651,30 +779,47 @@ element_generate_output (GstBaseTransform * base, GstBuffer ** outbuf)
   *outbuf = NULL;
   inbuf = base->queued_buf;
   base->queued_buf = NULL;
+  if (g_atomic_int_get (&self->flushing)) {
+    if (inbuf != NULL)
+      gst_buffer_unref (inbuf);
+    return GST_FLOW_FLUSHING;
+  }
   if (inbuf != NULL) {
     GstBuffer *out = NULL;
-    GstFlowReturn ret = klass->prepare_output_buffer (base, inbuf, &out);
 
+    ret = klass->prepare_output_buffer (base, inbuf, &out);
     if (ret != GST_FLOW_OK || out == NULL) {
       gst_buffer_unref (inbuf);
       return ret == GST_FLOW_OK ? GST_FLOW_ERROR : ret;
     }
-    ret = element_submit (self, inbuf, out, TRUE);
+    g_mutex_lock (&self->flow_lock);
+    ret = element_submit (self, inbuf, out, TRUE, &rc);
+    g_mutex_unlock (&self->flow_lock);
     gst_buffer_unref (inbuf);           /* the pending entry holds its own ref */
+    element_post_notes (self);
     if (ret == GST_FLOW_CUSTOM_ERROR) {
       EL_WARNING (self, "Could not map buffer, skipping");
       gst_buffer_unref (out);
       return GST_FLOW_OK;
     }
     if (ret != GST_FLOW_OK) {
+      if (rc != MIBAYER_OK)
+        post_gpu_failure (self, rc);
       gst_buffer_unref (out);
       return ret;
     }
   }
-  if (self->capacity > 0
+  /* the base class calls again for as long as a buffer comes out */
+  g_mutex_lock (&self->flow_lock);
+  *outbuf = g_queue_pop_head (&self->ready);
+  if (*outbuf == NULL && self->capacity > 0
       && (gint) g_queue_get_length (&self->pending) >= self->capacity)
-    return element_collect (self, outbuf);
-  return GST_FLOW_OK;
+    ret = element_collect_locked (self, outbuf, &owned, &rc);
+  g_mutex_unlock (&self->flow_lock);
+  element_post_notes (self);
+  if (rc != MIBAYER_OK)
+    post_gpu_failure (self, rc);
+  return ret;
 }
 
 static gboolean
@@ -690,8 +835,18 @@ element_sink_event (GstBaseTransform * base, GstEvent * event)
       /* frames in flight precede the event */
       element_drain (self, TRUE);
       break;
-    case GST_EVENT_FLUSH_STOP:
+    case GST_EVENT_FLUSH_START:
+      /* not serialised with the streaming thread: from here on nothing is
+       * submitted or pushed, and what is in flight is dropped as soon as the GPU
+       * lets go of the buffers (a DMA in progress cannot be recalled, but no
+       * frame waits for a push that the flush has made pointless) */
+      g_atomic_int_set (&self->flushing, 1);
       element_drain (self, FALSE);
+      break;
+    case GST_EVENT_FLUSH_STOP:
+      /* serialised: whatever the streaming thread still managed to queue */
+      element_drain (self, FALSE);
+      g_atomic_int_set (&self->flushing, 0);
       break;
     default:
       break;
@@ -733,6 +888,24 @@ element_query (GstBaseTransform * base, GstPadDirection direction,
   return BASE_CLASS (self)->query (base, direction, query);
 }
 
+/* READY -> PAUSED: latch the properties for the streaming thread */
+static gboolean
+element_start (GstBaseTransform * base)
+{
+  GstMiBayerElement *self = ELEMENT (base);
+
+  GST_OBJECT_LOCK (self);
+  self->act.device_id = self->device_id;
+  g_free (self->act.devices);
+  self->act.devices = g_strdup (self->devices);
+  self->act.inflight = self->inflight;
+  self->act.use_hipgraph = self->use_hipgraph;
+  self->act.pinned_pool = self->pinned_pool;
+  GST_OBJECT_UNLOCK (self);
+  g_atomic_int_set (&self->flushing, 0);
+  return TRUE;
+}
+
 static gboolean
 element_stop (GstBaseTransform * base)
 {
@@ -762,17 +935,21 @@ gst_mi_bayer_element_class_setup (GstMiBayerElementClass * klass,
 
   g_object_class_install_property (object_class, PROP_DEVICE_ID,
       g_param_spec_int ("device-id", "Device ID",
-          "HIP ordinal of the MI355X that converts this stream", 0, G_MAXINT,
+          "HIP ordinal of the MI355X that converts this stream (latched when "
+          "the element starts)", 0, G_MAXINT,
           DEFAULT_DEVICE_ID, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_DEVICES,
       g_param_spec_string ("devices", "Devices",
           "Comma-separated HIP ordinals; frames are sharded round-robin over "
-          "them (frame g -> devices[g % N]); empty = device-id only", NULL,
+          "them (frame g -> devices[g % N]); a device that fails is dropped and "
+          "its frames are redone on the others; empty = device-id only "
+          "(latched when the element starts)", NULL,
           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_INFLIGHT,
       g_param_spec_int ("inflight", "Frames in flight",
           "Frames in flight per device; 1 = strictly synchronous 1-in/1-out "
-          "like the stock element, more = queued mode (adds latency)", 1, 16,
+          "like the stock element, more = queued mode (adds latency; latched "
+          "when the element starts)", 1, 16,
           DEFAULT_INFLIGHT, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_HIPGRAPH,
       g_param_spec_boolean ("hipgraph", "hipGraph per frame",
@@ -797,6 +974,7 @@ gst_mi_bayer_element_class_setup (GstMiBayerElementClass * klass,
       GST_DEBUG_FUNCPTR (element_propose_allocation);
   transform_class->decide_allocation =
       GST_DEBUG_FUNCPTR (element_decide_allocation);
+  transform_class->start = GST_DEBUG_FUNCPTR (element_start);
   transform_class->stop = GST_DEBUG_FUNCPTR (element_stop);
 }
 
@@ -809,8 +987,17 @@ gst_mi_bayer_element_instance_setup (GstMiBayerElement * self)
   self->inflight = DEFAULT_INFLIGHT;
   self->use_hipgraph = DEFAULT_HIPGRAPH;
   self->pinned_pool = DEFAULT_PINNED_POOL;
+  self->act.device_id = DEFAULT_DEVICE_ID;
+  self->act.devices = NULL;
+  self->act.inflight = DEFAULT_INFLIGHT;
+  self->act.use_hipgraph = DEFAULT_HIPGRAPH;
+  self->act.pinned_pool = DEFAULT_PINNED_POOL;
   self->pool = NULL;
   self->pool_stride = 0;
   self->capacity = 0;
+  self->flushing = 0;
+  self->failure_note = NULL;
+  g_mutex_init (&self->flow_lock);
   g_queue_init (&self->pending);
+  g_queue_init (&self->ready);
 }

@@ -38,19 +38,36 @@ struct _GstMiBayerElement
   gint format;                  /* mibayer_pattern == reference enum (gstbayer2rgb.c:95-101) */
 
   /* additive, optional properties (the reference has none); the defaults give
-   * the reference's behaviour: one device, strictly 1-in/1-out synchronous */
+   * the reference's behaviour: one device, strictly 1-in/1-out synchronous.
+   * Written under the object lock by set_property at any time ... */
   gint device_id;
   gchar *devices;               /* "0,1,2,..." round-robin frame sharding; NULL = device-id */
   gint inflight;                /* frames in flight per device; 1 = synchronous */
   gboolean use_hipgraph;
   gboolean pinned_pool;
+  /* ... and latched into these by start(): the streaming thread only ever reads
+   * the latched copies, so a property changed while PLAYING takes effect at the
+   * next READY -> PAUSED and never races with the data flow */
+  struct
+  {
+    gint device_id;
+    gchar *devices;
+    gint inflight;
+    gboolean use_hipgraph;
+    gboolean pinned_pool;
+  } act;
 
   /* GPU side: one shard (mibayer_ctx) per device behind a round-robin pool;
    * (re)created when caps or the mapped video-frame stride change */
   mibayer_pool *pool;
   gint pool_stride;
-  gint capacity;                /* frames the pool may hold in flight */
+  gint capacity;                /* frames the pool may hold in flight (shrinks when a device is dropped) */
   GQueue pending;               /* PendingFrame*, oldest first */
+  GQueue ready;                 /* GstBuffer*: finished outputs collected early (the pool shrank), oldest first */
+  GMutex flow_lock;             /* pool / pending / ready: the streaming thread vs. FLUSH_START, which
+                                   arrives on another thread */
+  volatile gint flushing;       /* between FLUSH_START and FLUSH_STOP: nothing is submitted or pushed */
+  gchar *failure_note;          /* a device was dropped: posted as ONE element warning (flow_lock) */
 };
 
 struct _GstMiBayerElementClass

@@ -184,8 +184,9 @@ xfer_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query,
     return TRUE;
   gst_query_parse_allocation (query, &caps, NULL);
   if (caps && frame_size_from_caps (caps, &size)) {
-    GstBufferPool *pool = configured_pool (gst_mi_host_pool_new (), caps,
-        (guint) size, 2);
+    GstBufferPool *pool =
+        configured_pool (gst_mi_host_pool_new (GST_MI_HIP_XFER (trans)->
+            device_id), caps, (guint) size, 2);
 
     if (pool) {
       gst_query_add_allocation_pool (query, pool, (guint) size, 2, 0);
@@ -217,7 +218,8 @@ xfer_decide_allocation (GstBaseTransform * trans, GstQuery * query)
       pool = configured_pool (gst_mi_hip_pool_new (self->device_id), caps,
           (guint) size, 2);
     } else if (gst_query_get_n_allocation_pools (query) == 0) {
-      pool = configured_pool (gst_mi_host_pool_new (), caps, (guint) size, 2);
+      pool = configured_pool (gst_mi_host_pool_new (self->device_id), caps,
+          (guint) size, 2);
     }
     if (pool) {
       gst_query_add_allocation_pool (query, pool, (guint) size, 2, 0);
@@ -368,6 +370,7 @@ typedef struct
   gint width, height, r_off, g_off, b_off, format;
   gint device_id;
   mibayer_ctx *ctx;
+  gint ctx_device;              /* the device the context was created on */
 } GstMiHipBayer2RGB;
 
 typedef struct
@@ -491,6 +494,14 @@ hb2r_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
   self->g_off = GST_VIDEO_INFO_COMP_OFFSET (&info, 1);
   self->b_off = GST_VIDEO_INFO_COMP_OFFSET (&info, 2);
 
+  /* outside the domain in which the reference is well defined (see
+   * gstmibayerelement.c: set_caps): refuse the caps */
+  if (self->width < 4 || (self->width & 1) || self->height < 3) {
+    GST_WARNING_OBJECT (self, "refusing %dx%d: needs an even width >= 4 and a "
+        "height >= 3", self->width, self->height);
+    return FALSE;
+  }
+
   hb2r_drop_ctx (self);
   memset (&cfg, 0, sizeof cfg);
   cfg.struct_size = sizeof cfg;
@@ -509,6 +520,7 @@ hb2r_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
         ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
     return FALSE;
   }
+  self->ctx_device = cfg.device;
   return TRUE;
 }
 
@@ -552,6 +564,19 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
         ("hipbayer2rgb needs HIP device memory on both pads"), (NULL));
     return GST_FLOW_ERROR;
   }
+  /* the C ABI takes bare device pointers: a frame that lives on another GPU, or
+   * a buffer smaller than the negotiated frame, would fault on the device */
+  if (((GstMiHipMemory *) in_mem)->device != self->ctx_device
+      || ((GstMiHipMemory *) out_mem)->device != self->ctx_device) {
+    GST_ELEMENT_ERROR (self, CORE, NEGOTIATION,
+        ("hipbayer2rgb: buffers live on another GPU than device-id=%d",
+            self->ctx_device),
+        ("input memory on HIP device %d, output memory on %d; set the same "
+            "device-id on hipupload and hipbayer2rgb",
+            ((GstMiHipMemory *) in_mem)->device,
+            ((GstMiHipMemory *) out_mem)->device));
+    return GST_FLOW_ERROR;
+  }
   /* Stream-ordered, no host round trip: the launch is ordered after whatever
    * was last queued on the two memories, and both are marked with an event
    * after it.  The next user either orders its own stream after that event or
@@ -562,6 +587,19 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
     return GST_FLOW_ERROR;
   if (!gst_memory_map (out_mem, &out_map,
           GST_MAP_WRITE | GST_MAP_HIP | GST_MAP_HIP_ASYNC)) {
+    gst_memory_unmap (in_mem, &in_map);
+    return GST_FLOW_ERROR;
+  }
+  if (in_map.size < (gsize) GST_ROUND_UP_4 (self->width) * self->height
+      || out_map.size < (gsize) 4 * self->width * self->height) {
+    GST_ELEMENT_ERROR (self, STREAM, FORMAT,
+        ("hipbayer2rgb: device buffer smaller than a %dx%d frame", self->width,
+            self->height),
+        ("input %" G_GSIZE_FORMAT " bytes (need %" G_GSIZE_FORMAT "), output %"
+            G_GSIZE_FORMAT " bytes (need %" G_GSIZE_FORMAT ")", in_map.size,
+            (gsize) GST_ROUND_UP_4 (self->width) * self->height, out_map.size,
+            (gsize) 4 * self->width * self->height));
+    gst_memory_unmap (out_mem, &out_map);
     gst_memory_unmap (in_mem, &in_map);
     return GST_FLOW_ERROR;
   }
@@ -630,6 +668,7 @@ gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
   gst_video_info_init (&self->info);
   self->device_id = 0;
   self->ctx = NULL;
+  self->ctx_device = 0;
 }
 
 /* ======================================================================== */

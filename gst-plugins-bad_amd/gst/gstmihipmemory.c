@@ -69,8 +69,14 @@ gst_mi_hip_mem_map_full (GstMemory * memory, GstMapInfo * info, gsize maxsize)
    * orders its own stream after it (gst_mi_hip_memory_order_after) */
   if (!(info->flags & GST_MAP_HIP_ASYNC) && !gst_mi_hip_memory_wait (m))
     return NULL;
-  if (info->flags & GST_MAP_HIP)
+  if (info->flags & GST_MAP_HIP) {
+    if (info->flags & GST_MAP_WRITE) {
+      g_mutex_lock (&m->lock);
+      m->device_defined = TRUE; /* GPU work is about to define the contents */
+      g_mutex_unlock (&m->lock);
+    }
     return m->d_ptr;            /* device access: the caller orders its own GPU work */
+  }
 
   g_mutex_lock (&m->lock);
   if (m->staging == NULL)
@@ -78,8 +84,12 @@ gst_mi_hip_mem_map_full (GstMemory * memory, GstMapInfo * info, gsize maxsize)
   if (m->staging != NULL) {
     gboolean ok = TRUE;
 
-    /* bring the host mirror up to date unless another CPU map already did */
-    if (m->cpu_maps == 0 && (info->flags & GST_MAP_READ))
+    /* Bring the host mirror up to date unless another CPU map already did.  A
+     * WRITE-only map needs it too: unmap uploads the WHOLE mirror, so a writer
+     * that touches part of the buffer must find the rest of the frame in it --
+     * unless nothing has ever defined the device contents (a fresh buffer). */
+    if (m->cpu_maps == 0
+        && ((info->flags & GST_MAP_READ) || m->device_defined))
       ok = mibayer_dev_download (m->device, m->staging, m->d_ptr,
           memory->maxsize) == MIBAYER_OK;
     if (ok) {
@@ -109,6 +119,8 @@ gst_mi_hip_mem_unmap_full (GstMemory * memory, GstMapInfo * info)
             memory->maxsize) != MIBAYER_OK)
       GST_ERROR ("upload after CPU write failed: %s",
           mibayer_last_hip_error ());
+    else
+      m->device_defined = TRUE;
     m->cpu_dirty = FALSE;
   }
   g_mutex_unlock (&m->lock);
@@ -158,6 +170,7 @@ gst_mi_hip_memory_mark_access (GstMiHipMemory * m, gpointer hip_stream)
       hip_stream) == MIBAYER_OK;
   if (ok)
     m->access_pending = TRUE;
+  m->device_defined = TRUE;
   g_mutex_unlock (&m->lock);
   return ok;
 }
@@ -211,8 +224,10 @@ gst_mi_hip_memory_new (gint device, gsize size)
     return NULL;
   }
   m = g_new0 (GstMiHipMemory, 1);
-  gst_memory_init (GST_MEMORY_CAST (m), 0, gst_mi_hip_allocator_obtain (), NULL,
-      size, 0, 0, size);
+  /* no sub-memories (mem_share returns NULL): say so, so that gst_memory_share
+   * callers copy instead of failing */
+  gst_memory_init (GST_MEMORY_CAST (m), GST_MEMORY_FLAG_NO_SHARE,
+      gst_mi_hip_allocator_obtain (), NULL, size, 0, 0, size);
   m->d_ptr = d_ptr;
   m->device = device;
   g_mutex_init (&m->lock);

@@ -35,6 +35,8 @@ struct _GstMiHipMemory
   GMutex lock;
   gint cpu_maps;                /* outstanding CPU maps */
   gboolean cpu_dirty;           /* a CPU WRITE map is outstanding */
+  gboolean device_defined;      /* something has written the device copy (upload, GPU work): a
+                                   WRITE-only CPU map must start from it, not from a stale mirror */
   gpointer access_event;        /* HIP event of the last GPU access queued on this memory, created on first use */
   gboolean access_pending;      /* that event has not been waited for on the host yet */
 };

@@ -3,6 +3,11 @@
  * asynchronous DMA.  The memory is ordinary CPU-addressable memory: any element
  * can map it like system memory.
  *
+ * This file is compiled into BOTH plugins (`bayer` and `mihip`), and GStreamer
+ * loads plugins RTLD_LOCAL: each copy registers its own GType, under its own
+ * name (MI_HOST_POOL_TYPE_NAME, set per plugin by the Makefile) -- two
+ * registrations of one name would make the second plugin's pool unusable.
+ *
  * SURVEY.md section 8(f) rank 1.  Pattern the reference tree uses for the same
  * job: sys/nvcodec/gstcudabufferpool.c:56-207 (pool) and
  * sys/nvcodec/gstcudamemory.c:258-325 (CuMemAllocHost staging). */
@@ -26,6 +31,7 @@ struct _GstMiHostPool
 {
   GstBufferPool parent;
   guint size;                   /* bytes per buffer, from the pool config */
+  gint device;                  /* HIP ordinal the buffers are placed next to (NUMA); -1 = anywhere */
 };
 
 struct _GstMiHostPoolClass
@@ -34,7 +40,9 @@ struct _GstMiHostPoolClass
 };
 
 GType gst_mi_host_pool_get_type (void);
-GstBufferPool *gst_mi_host_pool_new (void);
+/* `device`: the HIP ordinal that will read / write the buffers: they are pinned on
+ * the NUMA node next to it (mibayer_host_alloc_near); -1 = no preference */
+GstBufferPool *gst_mi_host_pool_new (gint device);
 
 G_END_DECLS
 #endif

@@ -161,14 +161,36 @@ typedef struct mibayer_pool mibayer_pool;
 
 int mibayer_pool_create (const mibayer_pool_cfg *cfg, mibayer_pool **out);
 void mibayer_pool_destroy (mibayer_pool *pool);
-/* total frames that may be in flight = ndevices * stream.inflight */
+/* total frames that may be in flight = live devices * stream.inflight (shrinks
+ * when a device is dropped, see below) */
 int mibayer_pool_capacity (const mibayer_pool *pool);
 int mibayer_pool_pending (const mibayer_pool *pool);
-/* MIBAYER_ERR_BUSY when the shard whose turn it is has its ring full */
+/* MIBAYER_ERR_BUSY when the shard whose turn it is has its share of frames in
+ * flight: call mibayer_pool_wait() first.  Frames whose src or dst is pageable
+ * memory are converted by a helper thread of their shard (the copies block the
+ * thread that issues them), so this call only queues either way. */
 int mibayer_pool_submit (mibayer_pool *pool, const uint8_t *src, uint8_t *dst,
     void *tag);
 /* oldest frame first */
 int mibayer_pool_wait (mibayer_pool *pool, void **tag);
+
+/* Failure handling.  The reference's only reaction to a failure on this path is
+ * "warn and carry on" (gstbayer2rgb.c:484-486).  A device that reports a HIP
+ * error (or runs out of memory) is dropped from the rotation, the frames it
+ * still held are converted again on the surviving devices -- same bytes, same
+ * order -- and the stream carries on; submit / wait return MIBAYER_ERR_HIP only
+ * when no device is left.  mibayer_pool_take_failure() returns the number of
+ * devices dropped since the last call (0 = none) with the ordinal of the latest
+ * one, the number of devices left and a one-line description. */
+int mibayer_pool_alive (const mibayer_pool *pool);
+int mibayer_pool_take_failure (mibayer_pool *pool, int *device, int *alive,
+    char *msg, size_t msg_len);
+/* Failure drill: shard `shard` (index into devices[]) reports a device error
+ * once it has completed `after_frames` more frames; negative = cancel.  The
+ * environment variable MIBAYER_INJECT_FAULT="shard:frames[,shard:frames]" does
+ * the same at mibayer_pool_create(). */
+int mibayer_pool_inject_fault (mibayer_pool *pool, int shard,
+    long long after_frames);
 
 /* ---- device-resident batch path (roofline runs, GPU-side consumers) -------- */
 
@@ -215,6 +237,14 @@ int mibayer_copy_plan (mibayer_ctx *dst, const mibayer_ctx *src);
 /* Pinned (hipHostMalloc) memory for buffer pools feeding the host path. */
 void *mibayer_host_alloc (size_t bytes);
 void mibayer_host_free (void *p);
+/* The same, placed on the NUMA node next to HIP device `device` (the thread's
+ * memory policy is set around a hipHostMallocNumaUser allocation): a pool that
+ * feeds GPU k should not sit behind the socket link.  Falls back to
+ * mibayer_host_alloc() when the node is unknown.  Free with mibayer_host_free(). */
+void *mibayer_host_alloc_near (int device, size_t bytes);
+/* NUMA node next to a device (-1 = unknown) / holding the first page of p */
+int mibayer_device_numa_node (int device);
+int mibayer_host_numa_node (const void *p);
 
 /* Device memory on the context's device, for C callers without another
  * allocator. */

@@ -14,6 +14,13 @@
  *        frame of in2.raw, then EOS; write every buffer that comes out (frames in flight precede the new caps)
  *   element_harness states <pipeline> <cycles>
  *        NULL -> PLAYING -> (EOS) -> NULL, <cycles> times, on ONE pipeline instance
+ *   element_harness caps <launchline> <sinkcaps> <framebytes>
+ *        CAPS event + one buffer; prints caps_accepted=0|1 flow=<name> (set_caps refusing a geometry = not-negotiated)
+ *
+ * convert / flush also print warnings=<n> errors=<n> (element messages seen on a private bus) and, for flush,
+ * released_at_flush_start=0|1: whether every input buffer pushed before the flush had been let go of by the element
+ * when FLUSH_START returned (i.e. before FLUSH_STOP).  HARNESS_SET_MIDSTREAM="prop=value[,prop=value]" sets
+ * properties on the element after the first buffer (they must not disturb the running stream: latched at start).
  */
 #include <gst/gst.h>
 #include <gst/check/gstharness.h>
@@ -40,6 +47,88 @@ drain_to_file (GstHarness * h, FILE * out)
   return n;
 }
 
+static GstBus *
+attach_bus (GstHarness * h)
+{
+  GstBus *bus = gst_bus_new ();
+
+  gst_element_set_bus (h->element, bus);
+  return bus;
+}
+
+static void
+report_bus (GstBus * bus)
+{
+  GstMessage *msg;
+  int warnings = 0, errors = 0;
+
+  while ((msg = gst_bus_pop (bus)) != NULL) {
+    if (GST_MESSAGE_TYPE (msg) == GST_MESSAGE_WARNING) {
+      GError *err = NULL;
+      gchar *dbg = NULL;
+
+      gst_message_parse_warning (msg, &err, &dbg);
+      fprintf (stderr, "bus warning: %s (%s)\n", err->message, dbg ? dbg : "");
+      g_clear_error (&err);
+      g_free (dbg);
+      warnings++;
+    } else if (GST_MESSAGE_TYPE (msg) == GST_MESSAGE_ERROR) {
+      GError *err = NULL;
+      gchar *dbg = NULL;
+
+      gst_message_parse_error (msg, &err, &dbg);
+      fprintf (stderr, "bus error: %s (%s)\n", err->message, dbg ? dbg : "");
+      g_clear_error (&err);
+      g_free (dbg);
+      errors++;
+    }
+    gst_message_unref (msg);
+  }
+  fprintf (stdout, "warnings=%d errors=%d\n", warnings, errors);
+}
+
+static void
+set_midstream_properties (GstHarness * h)
+{
+  const gchar *spec = g_getenv ("HARNESS_SET_MIDSTREAM");
+  gchar **kv, **p;
+
+  if (!spec)
+    return;
+  kv = g_strsplit (spec, ";", -1);
+  for (p = kv; *p; p++) {
+    gchar **pair = g_strsplit (*p, "=", 2);
+
+    if (pair[0] && pair[1])
+      gst_util_set_object_arg (G_OBJECT (h->element), pair[0], pair[1]);
+    g_strfreev (pair);
+  }
+  g_strfreev (kv);
+}
+
+static int
+run_caps (char **argv)
+{
+  GstHarness *h = gst_harness_new_parse (argv[2]);
+  GstBus *bus;
+  GstFlowReturn flow;
+  gsize frame_bytes = (gsize) atol (argv[4]);
+
+  if (!h)
+    return 2;
+  bus = attach_bus (h);
+  /* A CAPS event is sticky: pushing it reports success whatever set_caps says, and the refusal surfaces as
+   * not-negotiated at the first buffer -- which is what a pipeline sees too. */
+  gst_harness_set_src_caps_str (h, argv[3]);
+  flow = gst_harness_push (h, gst_buffer_new_allocate (NULL, frame_bytes, NULL));
+  fprintf (stdout, "caps_accepted=%d flow=%s\n", flow == GST_FLOW_OK ? 1 : 0, gst_flow_get_name (flow));
+  report_bus (bus);
+  gst_element_set_bus (h->element, NULL);
+  gst_object_unref (bus);
+  gst_harness_teardown (h);
+  return 0;
+}
+
 static int
 run_harness (int argc, char **argv, int flush_after)
 {
@@ -50,26 +139,41 @@ run_harness (int argc, char **argv, int flush_after)
   FILE *in = fopen (in_path, "rb"), *out = fopen (out_path, "wb");
   guint8 *frame = g_malloc (frame_bytes);
   int pushed = 0, pulled = 0, n;
+  GstBus *bus;
+  GstBuffer *held[64];
 
   if (!h || !in || !out) {
     fprintf (stderr, "setup failed\n");
     return 2;
   }
+  bus = attach_bus (h);
   gst_harness_set_src_caps_str (h, caps);
   while (fread (frame, 1, frame_bytes, in) == frame_bytes) {
     GstBuffer *buf = gst_buffer_new_allocate (NULL, frame_bytes, NULL);
 
     gst_buffer_fill (buf, 0, frame, frame_bytes);
     GST_BUFFER_PTS (buf) = (GstClockTime) pushed * GST_SECOND / 30;
+    if (flush_after > 0 && pushed < flush_after && pushed < 64)
+      held[pushed] = gst_buffer_ref (buf);      /* to see when the element lets go of it */
     if (gst_harness_push (h, buf) != GST_FLOW_OK) {
       fprintf (stderr, "push %d failed\n", pushed);
+      report_bus (bus);
       return 3;
     }
     pushed++;
+    if (pushed == 1)
+      set_midstream_properties (h);
     if (flush_after > 0 && pushed == flush_after) {
       /* everything still inside the element must be dropped, nothing may leak out later */
-      int before = drain_to_file (h, out);
+      int before = drain_to_file (h, out), i, released = 1;
       gst_harness_push_event (h, gst_event_new_flush_start ());
+      /* FLUSH_START alone must already have dropped the frames in flight: ours is the only reference left */
+      for (i = 0; i < flush_after && i < 64; i++) {
+        if (GST_MINI_OBJECT_REFCOUNT_VALUE (held[i]) != 1)
+          released = 0;
+        gst_buffer_unref (held[i]);
+      }
+      fprintf (stdout, "released_at_flush_start=%d\n", released);
       gst_harness_push_event (h, gst_event_new_flush_stop (TRUE));
       fprintf (stdout, "before_flush_pulled=%d\n", before);
       pulled += before;
@@ -89,9 +193,12 @@ run_harness (int argc, char **argv, int flush_after)
   n = drain_to_file (h, out);
   pulled += n;
   fprintf (stdout, "pushed=%d pulled=%d\n", pushed, pulled);
+  report_bus (bus);
   fclose (in);
   fclose (out);
   g_free (frame);
+  gst_element_set_bus (h->element, NULL);
+  gst_object_unref (bus);
   gst_harness_teardown (h);
   return 0;
 }
@@ -194,6 +301,8 @@ main (int argc, char **argv)
     return run_harness (argc, argv, atoi (argv[7]));
   if (argc >= 10 && strcmp (argv[1], "renegotiate") == 0)
     return run_renegotiate (argv);
+  if (argc >= 5 && strcmp (argv[1], "caps") == 0)
+    return run_caps (argv);
   if (argc >= 4 && strcmp (argv[1], "states") == 0)
     return run_states (argv[2], atoi (argv[3]));
   fprintf (stderr, "usage: see the header of element_harness.c\n");

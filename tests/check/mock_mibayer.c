@@ -1,24 +1,36 @@
-/* TEST DOUBLE of libmibayer.so -- NOT a conversion path, NOT shipped, NOT a fallback.
+/* TEST DOUBLE of the per-device part of libmibayer.so -- NOT a conversion path, NOT shipped, NOT a fallback.
  *
- * The elements of plugin `bayer` (gst-plugins-bad_amd/gst/gstmibayerelement.c) talk to the GPU only through ten
- * entry points of include/mibayer.h, those of plugin `mihip` through nineteen.  This file implements exactly
- * those with NO demosaic in them, so that
- * the elements' own logic -- buffer ownership in the synchronous and the queued mode, ordering, draining on
- * EOS / caps / segment events, dropping on flush, pool re-creation on renegotiation -- can be exercised on a
- * machine without a GPU, under AddressSanitizer (tests/test_gst_element_logic.py).
+ * The elements of plugin `bayer` (gst-plugins-bad_amd/gst/gstmibayerelement.c) reach the GPU through the
+ * frame-sharding pool of include/mibayer.h; those of plugin `mihip` through the device-memory entry points.  This
+ * file implements the PER-DEVICE CONTEXT below the pool (mibayer_create / submit / wait / ..., the seam of
+ * csrc/mibayer_hooks.h) and the device-memory entry points with NO demosaic in them; the pool on top is the real
+ * csrc/mibayer_pool.cpp, compiled into the same test library.  So the elements' own logic -- buffer ownership in the
+ * synchronous and the queued mode, ordering, draining on EOS / caps / segment events, dropping on flush, pool
+ * re-creation on renegotiation -- AND the pool's ordering, failover and helper threads can be exercised on a machine
+ * without a GPU, under AddressSanitizer / ThreadSanitizer (tests/test_gst_element_logic.py, tests/test_pool_logic.py).
  *
  * What a "conversion" does here: nothing at submit time; at wait time (the moment the real library would have
  * finished its asynchronous work) it READS every source byte and WRITES every destination byte the real kernel
  * would write, so a buffer the element unmapped or released too early is a sanitizer report.  The output is a
  * stamp, not an image: bytes 0..3 of the frame = submission sequence number, every other written byte = the
- * first source byte of that frame.
+ * first source byte of that frame.  MOCK_MIBAYER_FAIL="index:frames" turns the index-th context into a failed
+ * device after that many frames; MOCK_MIBAYER_PAGEABLE=1 sends every frame down the pool's helper-thread path.
  */
 #include "mibayer.h"
 
 #include <stdlib.h>
 #include <string.h>
 
-#define MOCK_MAX_PENDING 1024
+#include <pthread.h>
+#include <stdio.h>
+
+#include "mibayer_hooks.h"
+
+#define MOCK_MAX_PENDING 64
+
+/* The frame-sharding pool on top of these contexts is the REAL one: csrc/mibayer_pool.cpp (pure host logic) is
+ * compiled into the test double's libmibayer.so, so its ordering, failover and helper-thread code runs here
+ * under the sanitizers.  Only the per-device context below is fake. */
 
 typedef struct
 {
@@ -28,13 +40,22 @@ typedef struct
   uint32_t seq;
 } mock_frame;
 
-struct mibayer_pool
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;     /* elements and helper threads run concurrently */
+static uint32_t g_seq;          /* host-path frames submitted since the first context of a pool was created */
+static int g_live_host_ctx;     /* contexts alive: the counter restarts with every new pool */
+static int g_created;           /* contexts created so far == index of the next one (fault injection) */
+
+struct mibayer_ctx
 {
   mibayer_cfg cfg;
-  int capacity;
-  mock_frame fifo[MOCK_MAX_PENDING];
+  size_t src_bytes, dst_bytes;
+  /* host path: a ring like the real context's */
+  mock_frame ring[MOCK_MAX_PENDING];
   int head, count;
-  uint32_t seq;
+  int index;                    /* n-th context created in this process */
+  int completed;                /* frames finished on this "device" */
+  int fail_after;               /* MOCK_MIBAYER_FAIL=index:frames -> device error after that many frames; -1 never */
+  int dead;
 };
 
 int
@@ -48,7 +69,7 @@ mibayer_device_count (void)
 const char *
 mibayer_strerror (int status)
 {
-  return status == MIBAYER_OK ? "ok" : "mock error";
+  return status == MIBAYER_OK ? "ok" : (status == MIBAYER_ERR_HIP ? "mock device error" : "mock error");
 }
 
 const char *
@@ -63,109 +84,152 @@ mibayer_host_alloc (size_t bytes)
   return malloc (bytes ? bytes : 1);    /* plain heap: the sanitizer sees its bounds */
 }
 
+void *
+mibayer_host_alloc_near (int device, size_t bytes)
+{
+  return mibayer_host_alloc (bytes);
+}
+
 void
 mibayer_host_free (void *p)
 {
   free (p);
 }
 
-int
-mibayer_pool_create (const mibayer_pool_cfg * cfg, mibayer_pool ** out)
+/* what a finished conversion leaves behind: reads every source byte, writes every destination byte the real
+ * kernel would write */
+static void
+mock_convert (const mibayer_ctx * c, const mock_frame * fr)
 {
-  mibayer_pool *p;
-  const mibayer_cfg *f;
-  int inverse;
-
-  if (!cfg || !out || cfg->struct_size != sizeof (*cfg) || cfg->ndevices < 1)
-    return MIBAYER_ERR_ARG;
-  f = &cfg->stream;
-  inverse = (f->flags & MIBAYER_FLAG_RGB2BAYER) != 0;
-  if (mibayer_device_count () <= 0)
-    return MIBAYER_ERR_NO_DEVICE;
-  /* the real library's geometry domain for bayer2rgb */
-  if (!inverse && (f->width < 4 || (f->width & 1) || f->height < 3))
-    return MIBAYER_ERR_GEOMETRY;
-  p = calloc (1, sizeof *p);
-  p->cfg = *f;
-  p->capacity = cfg->ndevices * (f->inflight > 0 ? f->inflight : 2);
-  if (p->capacity > MOCK_MAX_PENDING)
-    p->capacity = MOCK_MAX_PENDING;
-  *out = p;
-  return MIBAYER_OK;
-}
-
-void
-mibayer_pool_destroy (mibayer_pool * p)
-{
-  free (p);
-}
-
-int
-mibayer_pool_capacity (const mibayer_pool * p)
-{
-  return p ? p->capacity : MIBAYER_ERR_ARG;
-}
-
-int
-mibayer_pool_pending (const mibayer_pool * p)
-{
-  return p ? p->count : MIBAYER_ERR_ARG;
-}
-
-int
-mibayer_pool_submit (mibayer_pool * p, const uint8_t * src, uint8_t * dst,
-    void *tag)
-{
-  mock_frame *fr;
-
-  if (!p || !src || !dst)
-    return MIBAYER_ERR_ARG;
-  if (p->count == p->capacity)
-    return MIBAYER_ERR_BUSY;
-  fr = &p->fifo[(p->head + p->count) % MOCK_MAX_PENDING];
-  fr->src = src;
-  fr->dst = dst;
-  fr->tag = tag;
-  fr->seq = p->seq++;
-  p->count++;
-  return MIBAYER_OK;
-}
-
-int
-mibayer_pool_wait (mibayer_pool * p, void **tag)
-{
-  const mibayer_cfg *f;
-  mock_frame fr;
-  int inverse, y, src_row, dst_row;
-  unsigned sum = 0;
-
-  if (!p)
-    return MIBAYER_ERR_ARG;
-  if (p->count == 0)
-    return MIBAYER_ERR_EMPTY;
-  fr = p->fifo[p->head];
-  p->head = (p->head + 1) % MOCK_MAX_PENDING;
-  p->count--;
-  f = &p->cfg;
-  inverse = (f->flags & MIBAYER_FLAG_RGB2BAYER) != 0;
+  const mibayer_cfg *f = &c->cfg;
+  const int inverse = (f->flags & MIBAYER_FLAG_RGB2BAYER) != 0;
   /* bytes per row the real path reads / writes */
-  src_row = inverse ? 4 * f->width : ((f->width + 3) & ~3);
-  dst_row = inverse ? ((f->width + 3) & ~3) : 4 * f->width;
+  const int src_row = inverse ? 4 * f->width : ((f->width + 3) & ~3);
+  const int dst_row = inverse ? ((f->width + 3) & ~3) : 4 * f->width;
+  unsigned sum = 0;
+  int y;
+
   for (y = 0; y < f->height; y++) {
-    const uint8_t *s = fr.src + (size_t) y * f->src_stride;
+    const uint8_t *s = fr->src + (size_t) y * f->src_stride;
     int x;
 
     for (x = 0; x < src_row; x++)
       sum += s[x];              /* the source must still be mapped and alive */
   }
   for (y = 0; y < f->height; y++)
-    memset (fr.dst + (size_t) y * f->dst_stride, fr.src[0], (size_t) dst_row);
-  memcpy (fr.dst, &fr.seq, 4);
+    memset (fr->dst + (size_t) y * f->dst_stride, fr->src[0], (size_t) dst_row);
+  memcpy (fr->dst, &fr->seq, 4);
   if (sum == 0xffffffffu)       /* keep the reads */
-    fr.dst[4] ^= 1;
+    fr->dst[4] ^= 1;
+}
+
+/* 1 when this "device" fails now (and from now on) */
+static int
+mock_device_fails (mibayer_ctx * c)
+{
+  if (c->dead)
+    return 1;
+  if (c->fail_after >= 0 && c->completed >= c->fail_after) {
+    c->dead = 1;
+    return 1;
+  }
+  return 0;
+}
+
+int
+mibayer_submit (mibayer_ctx * c, const uint8_t * src, uint8_t * dst, void *tag)
+{
+  mock_frame *fr;
+
+  if (!c || !src || !dst)
+    return MIBAYER_ERR_ARG;
+  if (c->dead)
+    return MIBAYER_ERR_HIP;
+  if (c->count == c->cfg.inflight)
+    return MIBAYER_ERR_BUSY;
+  fr = &c->ring[(c->head + c->count) % MOCK_MAX_PENDING];
+  fr->src = src;
+  fr->dst = dst;
+  fr->tag = tag;
+  pthread_mutex_lock (&g_lock);
+  fr->seq = g_seq++;
+  pthread_mutex_unlock (&g_lock);
+  c->count++;
+  return MIBAYER_OK;
+}
+
+int
+mibayer_wait (mibayer_ctx * c, void **tag)
+{
+  mock_frame fr;
+
+  if (!c)
+    return MIBAYER_ERR_ARG;
+  if (c->count == 0)
+    return MIBAYER_ERR_EMPTY;
+  if (mock_device_fails (c))
+    return MIBAYER_ERR_HIP;     /* nothing was converted: the frame stays where it is */
+  fr = c->ring[c->head];
+  c->head = (c->head + 1) % MOCK_MAX_PENDING;
+  c->count--;
+  mock_convert (c, &fr);
+  c->completed++;
   if (tag)
     *tag = fr.tag;
   return MIBAYER_OK;
+}
+
+int
+mibayer_pending (const mibayer_ctx * c)
+{
+  return c ? c->count : MIBAYER_ERR_ARG;
+}
+
+int
+mibayer_get_cfg (const mibayer_ctx * c, mibayer_cfg * out)
+{
+  if (!c || !out)
+    return MIBAYER_ERR_ARG;
+  *out = c->cfg;
+  return MIBAYER_OK;
+}
+
+/* ---- the seam the real pool uses (csrc/mibayer_hooks.h) ---- */
+
+int
+mibayer_internal_run_spare (mibayer_ctx * c, const uint8_t * src, uint8_t * dst)
+{
+  mock_frame fr;
+
+  if (!c || !src || !dst)
+    return MIBAYER_ERR_ARG;
+  if (mock_device_fails (c))
+    return MIBAYER_ERR_HIP;
+  fr.src = src;
+  fr.dst = dst;
+  fr.tag = NULL;
+  pthread_mutex_lock (&g_lock);
+  fr.seq = g_seq++;
+  pthread_mutex_unlock (&g_lock);
+  mock_convert (c, &fr);
+  c->completed++;
+  return MIBAYER_OK;
+}
+
+/* MOCK_MIBAYER_PAGEABLE=1: every host buffer counts as pageable, i.e. every frame takes the helper-thread path */
+int
+mibayer_internal_is_pageable (const void *p)
+{
+  const char *e = getenv ("MOCK_MIBAYER_PAGEABLE");
+
+  return e && atoi (e) != 0;
+}
+
+void
+mibayer_internal_abandon (mibayer_ctx * c)
+{
+  if (c)
+    c->count = 0;               /* whatever the dead device held is never written */
 }
 
 /* ---- the entry points plugin `mihip` uses (device memory, events, device-resident launches) ------------------
@@ -177,12 +241,7 @@ mibayer_pool_wait (mibayer_pool * p, void **tag)
  * access" event gets the bytes from before the launch, and the stamp check of the test fails.  Freeing memory
  * that a pending launch still uses aborts. */
 
-#include <pthread.h>
-#include <stdio.h>
-
 #define MOCK_MAX_OPS 4096
-
-static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;     /* elements may run in different streaming threads */
 
 typedef struct
 {
@@ -195,12 +254,6 @@ typedef struct
 
 static mock_op g_ops[MOCK_MAX_OPS];
 static uint32_t g_nops;         /* launches queued so far == sequence number of the next one */
-
-struct mibayer_ctx
-{
-  mibayer_cfg cfg;
-  size_t src_bytes, dst_bytes;
-};
 
 typedef struct
 {
@@ -233,21 +286,54 @@ int
 mibayer_create (const mibayer_cfg * cfg, mibayer_ctx ** out)
 {
   mibayer_ctx *c;
+  int inverse;
 
   if (!cfg || !out || cfg->struct_size != sizeof (*cfg))
     return MIBAYER_ERR_ARG;
   if (mibayer_device_count () <= 0)
     return MIBAYER_ERR_NO_DEVICE;
-  if (cfg->width < 4 || (cfg->width & 1) || cfg->height < 3)
+  inverse = (cfg->flags & MIBAYER_FLAG_RGB2BAYER) != 0;
+  /* the real library's geometry domain for bayer2rgb */
+  if (!inverse && (cfg->width < 4 || (cfg->width & 1) || cfg->height < 3))
     return MIBAYER_ERR_GEOMETRY;
   c = calloc (1, sizeof *c);
   c->cfg = *cfg;
   if (c->cfg.src_stride == 0)
-    c->cfg.src_stride = (cfg->width + 3) & ~3;
+    c->cfg.src_stride = inverse ? 4 * cfg->width : ((cfg->width + 3) & ~3);
   if (c->cfg.dst_stride == 0)
-    c->cfg.dst_stride = 4 * cfg->width;
+    c->cfg.dst_stride = inverse ? ((cfg->width + 3) & ~3) : 4 * cfg->width;
+  if (c->cfg.inflight <= 0)
+    c->cfg.inflight = 2;
+  if (c->cfg.inflight > MOCK_MAX_PENDING)
+    c->cfg.inflight = MOCK_MAX_PENDING;
   c->src_bytes = (size_t) c->cfg.src_stride * cfg->height;
   c->dst_bytes = (size_t) c->cfg.dst_stride * cfg->height;
+  c->fail_after = -1;
+  pthread_mutex_lock (&g_lock);
+  if (g_live_host_ctx++ == 0)
+    g_seq = 0;                  /* a new pool stamps its frames from 0 */
+  c->index = g_created++;
+  pthread_mutex_unlock (&g_lock);
+  {
+    /* MOCK_MIBAYER_FAIL="index:frames[,index:frames]": the index-th context created in this process turns into
+     * a failed device once it has completed that many frames */
+    const char *e = getenv ("MOCK_MIBAYER_FAIL");
+
+    while (e && *e) {
+      char *end = NULL;
+      long idx = strtol (e, &end, 10), n;
+
+      if (end == e || *end != ':')
+        break;
+      e = end + 1;
+      n = strtol (e, &end, 10);
+      if (end == e)
+        break;
+      if (idx == c->index)
+        c->fail_after = (int) n;
+      e = (*end == ',') ? end + 1 : end;
+    }
+  }
   *out = c;
   return MIBAYER_OK;
 }
@@ -269,6 +355,9 @@ mibayer_destroy (mibayer_ctx * c)
   if (!c)
     return;
   mibayer_sync (c);
+  pthread_mutex_lock (&g_lock);
+  g_live_host_ctx--;
+  pthread_mutex_unlock (&g_lock);
   free (c);
 }
 

@@ -401,6 +401,138 @@ def test_pool_round_robin_shards_keep_order(gpu_pkg, oracle, flags):
             L.mibayer_host_free(pd)
 
 
+@pytest.mark.parametrize("memory", ["pinned", "pageable"])
+def test_pool_drops_a_failed_device_and_redoes_its_frames(gpu_pkg, oracle, memory):
+    """Failure drill on real hardware (SURVEY.md section 5 "a failed device is dropped from the round-robin set"): four
+    shards on the visible GPU(s); shard 1 reports a device error after 3 frames, shard 3 after 7.  Every frame still
+    comes back once, in submission order, bit-exact; the pool reports each drop once and shrinks its capacity; the
+    stream fails only when the last shard is gone.  `pageable` buffers take the per-shard helper-thread path."""
+    w, h, n = 1920, 1080, 41
+    ndev = gpu_pkg.device_count()
+    devices = [i % ndev for i in range(4)]
+    src = oracle.fill_synthetic(w, h, n, seed=53)
+    want = oracle.bayer2rgb_batch(src, w, "grbg", 0, 1, 2, nthreads=4)
+    L = gpu_pkg.lib()
+    with gpu_pkg.Pool(devices, w, h, "grbg", "RGBx", inflight=2) as pool:
+        cap0 = pool.capacity
+        if memory == "pinned":
+            bufs = [(_pinned(L, w * h, (h, w)), _pinned(L, 4 * w * h, (h, 4 * w))) for _ in range(cap0)]
+        else:
+            bufs = [((0, np.empty((h, w), np.uint8)), (0, np.empty((h, 4 * w), np.uint8))) for _ in range(cap0)]
+        pool.inject_fault(1, 3)
+        pool.inject_fault(3, 7)
+        outs, order, notes = {}, [], []
+
+        def collect():
+            t = pool.wait()
+            order.append(t)
+            outs[t - 1] = bufs[(t - 1) % cap0][1][1].copy()
+            nf, dev, alive, msg = pool.take_failure()
+            if nf:
+                notes.append((nf, dev, alive, msg))
+
+        for i in range(n):
+            (_, s_arr), (_, d_arr) = bufs[i % cap0]
+            while True:
+                if pool.pending() >= min(cap0, lib_capacity(gpu_pkg, pool)):
+                    collect()
+                    continue
+                s_arr[:] = src[i]
+                d_arr[:] = 0
+                try:
+                    pool.submit(s_arr, d_arr, tag=i + 1)
+                    break
+                except gpu_pkg.MibayerError as e:
+                    assert e.status == gpu_pkg.ERR_BUSY
+                    collect()
+        while pool.pending():
+            collect()
+        assert order == list(range(1, n + 1))
+        for i in range(n):
+            assert np.array_equal(outs[i], want[i]), i
+        assert sum(x[0] for x in notes) == 2 and pool.alive() == 2 and lib_capacity(gpu_pkg, pool) == 4
+        assert all("dropped from the rotation" in x[3] for x in notes)
+        # the last two go as well: now, and only now, the stream is dead
+        pool.inject_fault(0, 0)
+        pool.inject_fault(2, 0)
+        (_, s_arr), (_, d_arr) = bufs[0]
+        with pytest.raises(gpu_pkg.MibayerError) as e:
+            for k in range(6):
+                pool.submit(s_arr, d_arr, tag=100 + k)
+                pool.wait()
+        assert e.value.status == gpu_pkg.ERR_HIP and pool.alive() == 0
+        if memory == "pinned":
+            for (ps, _), (pd, _) in bufs:
+                L.mibayer_host_free(ps)
+                L.mibayer_host_free(pd)
+
+
+def lib_capacity(gpu_pkg, pool):
+    return gpu_pkg.lib().mibayer_pool_capacity(pool._h)
+
+
+def test_pageable_frames_go_through_helper_threads_and_match(gpu_pkg, oracle, monkeypatch):
+    """Pageable numpy buffers: one helper thread per shard runs the blocking copies (MIBAYER_POOL_HELPERS=0 = the old
+    behaviour, everything on the calling thread).  Same bytes, same order, both ways, with pinned frames (the direct,
+    enqueue-only path) interleaved on the same shards."""
+    w, h, n = 1280, 720, 19
+    ndev = gpu_pkg.device_count()
+    src = oracle.fill_synthetic(w, h, n, seed=57)
+    want = oracle.bayer2rgb_batch(src, w, "bggr", 3, 2, 1, nthreads=4)
+    L = gpu_pkg.lib()
+    pinned = {i: (_pinned(L, w * h, (h, w)), _pinned(L, 4 * w * h, (h, 4 * w))) for i in range(2, n, 3)}
+    for helpers in ("1", "0"):
+        monkeypatch.setenv("MIBAYER_POOL_HELPERS", helpers)
+        with gpu_pkg.Pool([i % ndev for i in range(3)], w, h, "bggr", "xBGR", inflight=2) as pool:
+            dsts, order = [], []
+            for i in range(n):
+                if pool.pending() == pool.capacity:
+                    order.append(pool.wait())
+                if i in pinned:
+                    s_arr, d_arr = pinned[i][0][1], pinned[i][1][1]
+                    s_arr[:] = src[i]
+                    d_arr[:] = 0
+                else:
+                    s_arr, d_arr = src[i], np.zeros((h, 4 * w), np.uint8)
+                dsts.append(d_arr)
+                pool.submit(s_arr, d_arr, tag=i + 1)
+            while pool.pending():
+                order.append(pool.wait())
+            assert order == list(range(1, n + 1))
+            for i in range(n):
+                assert np.array_equal(dsts[i], want[i]), (helpers, i)
+    for (ps, _), (pd, _) in pinned.values():
+        L.mibayer_host_free(ps)
+        L.mibayer_host_free(pd)
+
+
+def test_numa_local_pinned_allocation(gpu_pkg, oracle):
+    """mibayer_host_alloc_near(device): pinned memory on the NUMA node next to the GPU (a no-op on one-node hosts);
+    the block works like any other pinned block and is freed by mibayer_host_free."""
+    import ctypes
+    L = gpu_pkg.lib()
+    node = L.mibayer_device_numa_node(0)
+    assert node >= -1
+    w, h = 1920, 1080
+    ps, pd = L.mibayer_host_alloc_near(0, w * h), L.mibayer_host_alloc_near(0, 4 * w * h)
+    assert ps and pd
+    s = np.ctypeslib.as_array(ctypes.cast(ps, ctypes.POINTER(ctypes.c_uint8)), (w * h,)).reshape(h, w)
+    d = np.ctypeslib.as_array(ctypes.cast(pd, ctypes.POINTER(ctypes.c_uint8)), (4 * w * h,)).reshape(h, 4 * w)
+    s[:] = oracle.fill_synthetic(w, h, 1, seed=59)[0]
+    got_node = L.mibayer_host_numa_node(ctypes.c_void_p(pd))
+    if node >= 0 and got_node >= 0:
+        assert got_node == node, (got_node, node)          # the pages sit next to the GPU
+    with gpu_pkg.Context(w, h, "rggb", "BGRx", device=0) as ctx:
+        ctx.process_host(s, d)
+    assert np.array_equal(d, oracle.bayer2rgb(s, w, "rggb", 2, 1, 0))
+    L.mibayer_host_free(ps)
+    L.mibayer_host_free(pd)
+    assert L.mibayer_device_numa_node(99) == -1
+    p = L.mibayer_host_alloc_near(99, 4096)                 # unknown device: plain pinned memory
+    assert p
+    L.mibayer_host_free(p)
+
+
 def test_hipgraph_host_path_with_changing_pointers(gpu_pkg, oracle):
     """Graph mode patches the two host pointers into the instantiated graph per frame: pageable and pinned,
     fresh and recycled pointers must all give the oracle's bytes."""

@@ -1,0 +1,90 @@
+"""The frame-sharding pool's own logic (gst-plugins-bad_amd/csrc/mibayer_pool.cpp: round-robin order, device failover,
+helper threads for pageable buffers) on a machine WITHOUT a GPU.
+
+The pool is pure host code above the per-device context ABI, so the REAL source file is compiled against the test double
+of the contexts (tests/check/mock_mibayer.c) and driven by tests/check/pool_logic.cpp -- once under AddressSanitizer,
+once under ThreadSanitizer (the helper threads share frame states with the streaming thread).  Exit codes of the driver
+encode which invariant broke (order, source identity, capacity accounting)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "gst-plugins-bad_amd", "csrc")
+CHECK = os.path.join(ROOT, "tests", "check")
+
+
+@pytest.fixture(scope="module", params=["address", "thread"])
+def driver(request, tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("poollogic_" + request.param))
+    san = ["-O1", "-g", "-fsanitize=" + request.param, "-fno-omit-frame-pointer", "-Wall"]
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    obj = os.path.join(d, "mock.o")
+    res = subprocess.run(["gcc"] + san + inc + ["-c", os.path.join(CHECK, "mock_mibayer.c"), "-o", obj],
+                         capture_output=True, text=True)
+    if res.returncode != 0 and "sanitize" in res.stderr:
+        pytest.skip("sanitizer runtime not available: " + res.stderr[-200:])
+    assert res.returncode == 0, res.stderr[-2000:]
+    exe = os.path.join(d, "pool_logic")
+    res = subprocess.run(["g++", "-std=c++17"] + san + inc
+                         + [os.path.join(CHECK, "pool_logic.cpp"), os.path.join(CSRC, "mibayer_pool.cpp"), obj,
+                            "-o", exe, "-lpthread"], capture_output=True, text=True)
+    if res.returncode != 0 and "sanitize" in res.stderr:
+        pytest.skip("sanitizer runtime not available: " + res.stderr[-200:])
+    assert res.returncode == 0, res.stderr[-2000:]
+    # probe: some kernels refuse TSan's memory layout
+    probe = subprocess.run([exe, "1", "1", "1", "0", "-", "ok"], capture_output=True, text=True)
+    if probe.returncode != 0 and "unexpected memory mapping" in probe.stderr:
+        pytest.skip("ThreadSanitizer cannot run here: " + probe.stderr[-200:])
+    return exe
+
+
+def run(exe, shards, inflight, frames, pageable, faults, expect, env=None):
+    res = subprocess.run([exe, str(shards), str(inflight), str(frames), str(int(pageable)), faults, expect],
+                         capture_output=True, text=True, timeout=120, env=dict(os.environ, **(env or {})))
+    out = res.stdout + res.stderr
+    assert "Sanitizer" not in out, out[-4000:]
+    assert res.returncode == 0, (res.returncode, out[-2000:])
+    return dict(kv.split("=") for kv in res.stdout.split() if "=" in kv), res.stderr
+
+
+@pytest.mark.parametrize("pageable", [False, True], ids=["pinned", "pageable"])
+def test_round_robin_order_without_faults(driver, pageable):
+    for shards, inflight, frames in ((1, 1, 5), (1, 3, 17), (4, 2, 50), (8, 1, 33), (16, 2, 70)):
+        kv, _ = run(driver, shards, inflight, frames, pageable, "-", "ok")
+        assert kv["delivered"] == str(frames) and kv["dropped_devices"] == "0"
+        assert kv["alive"] == str(shards) and kv["capacity"] == str(shards * inflight)
+
+
+@pytest.mark.parametrize("pageable", [False, True], ids=["pinned", "pageable"])
+def test_a_failed_device_is_dropped_and_its_frames_are_redone(driver, pageable):
+    # one of four devices fails after 3 frames: every frame still comes out once, in order, from its own source
+    kv, err = run(driver, 4, 2, 60, pageable, "1:3", "ok")
+    assert kv["delivered"] == "60" and kv["dropped_devices"] == "1" and kv["alive"] == "3" and kv["capacity"] == "6"
+    assert "dropped from the rotation" in err and err.count("note:") == 1          # reported exactly once
+    # it fails at once; two fail at different times; all but one fail
+    for faults, alive in (("2:0", 3), ("0:5,3:9", 2), ("0:1,1:2,2:3", 1)):
+        kv, _ = run(driver, 4, 3, 80, pageable, faults, "ok")
+        assert kv["delivered"] == "80" and kv["alive"] == str(alive), (faults, kv)
+        assert kv["dropped_devices"] == str(4 - alive)
+
+
+@pytest.mark.parametrize("pageable", [False, True], ids=["pinned", "pageable"])
+def test_the_stream_fails_only_when_no_device_is_left(driver, pageable):
+    kv, _ = run(driver, 2, 2, 40, pageable, "0:3,1:6", "dead")
+    assert kv["alive"] == "0" and kv["capacity"] == "0" and kv["rc"] == "-5"        # MIBAYER_ERR_HIP
+    assert 3 <= int(kv["delivered"]) <= 9           # what completed before the oldest undeliverable frame came out
+    kv, _ = run(driver, 1, 2, 10, pageable, "0:4", "dead")
+    assert kv["delivered"] in ("3", "4") and kv["rc"] == "-5"   # 4 completed; the last may still be undelivered
+
+
+def test_environment_fault_injection_matches_the_api(driver):
+    kv, _ = run(driver, 3, 2, 30, False, "-", "ok", env={"MIBAYER_INJECT_FAULT": "2:4"})
+    assert kv["delivered"] == "30" and kv["alive"] == "2"
+
+
+def test_helpers_can_be_switched_off(driver):
+    # MIBAYER_POOL_HELPERS=0: pageable frames take the direct path on the calling thread (A/B knob)
+    kv, _ = run(driver, 4, 2, 40, True, "1:2", "ok", env={"MIBAYER_POOL_HELPERS": "0"})
+    assert kv["delivered"] == "40" and kv["alive"] == "3"
