@@ -141,6 +141,12 @@ struct Slot {
   hipGraphNode_t n_h2d = nullptr, n_kernel = nullptr, n_d2h = nullptr;
   const void *g_src = nullptr;    /* host pointers currently baked into exec */
   void *g_dst = nullptr;
+  /* MIBAYER_FLAG_HIPGRAPH, default form: the compute-queue segment of the frame
+   * (wait for the upload event -> kernel -> record the kernel event) captured
+   * once per slot; the copies stay on the copy queues */
+  hipGraph_t cgraph = nullptr;
+  hipGraphExec_t cexec = nullptr;
+  bool cgraph_events = false;     /* the graph holds the event nodes too */
 };
 
 int device_count_cached ()
@@ -173,6 +179,10 @@ struct mibayer_ctx {
                                            set by MIBAYER_XCD_BAND or mibayer_autotune() */
   int num_cus = 256;                    /* hipDeviceProp_t.multiProcessorCount */
   int persist_wgs_per_cu = 4;           /* MIBAYER_PERSIST_WGS (tuning), persistent arms */
+  int graph_mode = 0;                   /* MIBAYER_FLAG_HIPGRAPH: 0 = the compute-queue segment of a frame as
+                                           a graph per slot (default), 1 = the whole upload -> kernel ->
+                                           download chain as a graph per slot on the slot's own queue
+                                           (MIBAYER_GRAPH_MODE=chain; A/B arm) */
   int host_bands = 1;                   /* host path: horizontal bands a frame is cut into so that
                                            the upload of band b+1, the kernel of band b and the
                                            download of band b-1 overlap inside ONE frame */
@@ -603,6 +613,8 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
     c->r2b_flat_ld = atoi (e);
   if (const char *e = getenv ("MIBAYER_R2B_ROWS"))
     c->r2b_rows = atoi (e);
+  if (const char *e = getenv ("MIBAYER_GRAPH_MODE"))
+    c->graph_mode = (strcmp (e, "chain") == 0 || strcmp (e, "1") == 0) ? 1 : 0;
   if (const char *e = getenv ("MIBAYER_PERSIST_WGS"))
     c->persist_wgs_per_cu = atoi (e) > 0 ? atoi (e) : 4;
   {
@@ -659,6 +671,10 @@ static void free_slot (Slot &s)
     if (s.ev_band_kernel[b])
       (void) hipEventDestroy (s.ev_band_kernel[b]);
   }
+  if (s.cexec)
+    (void) hipGraphExecDestroy (s.cexec);
+  if (s.cgraph)
+    (void) hipGraphDestroy (s.cgraph);
   if (s.exec)
     (void) hipGraphExecDestroy (s.exec);
   if (s.graph)
@@ -964,10 +980,72 @@ static int enqueue_frame_banded (mibayer_ctx *c, Slot &s, const uint8_t *src,
   return MIBAYER_OK;
 }
 
+/* BASELINE.json configs[4] "pinned double-buffered H2D/D2H + hipGraph-captured
+ * launch": what the compute queue does for a frame -- wait for the slot's upload
+ * event, run the kernel on the slot's device frames, record the slot's kernel
+ * event -- never changes from frame to frame (the slot's device pointers and
+ * events are fixed), so it is captured once per slot as a three-node graph and
+ * replayed with one hipGraphLaunch per frame; nothing is patched per frame.  The
+ * copies stay plain asynchronous copies on the two copy queues, where frame
+ * n+1's upload and frame n's download keep overlapping exactly as without the
+ * graph.  If the runtime refuses the event nodes the graph holds the kernel only
+ * and the wait / record stay stream calls. */
+static int compute_graph_launch (mibayer_ctx *c, Slot &s)
+{
+  if (!s.cexec) {
+    KParams p;
+    KernelFn kern;
+    unsigned grid;
+    const int rc = plan_launch (c, s.d_src, c->src_bytes, s.d_dst, c->dst_bytes,
+        1, p, kern, grid);
+    if (rc != MIBAYER_OK)
+      return rc;
+    void *args[1] = { &p };
+    hipKernelNodeParams kp;
+    memset (&kp, 0, sizeof kp);
+    kp.func = (void *) kern;
+    kp.gridDim = dim3 (grid);
+    kp.blockDim = dim3 ((unsigned) c->var->threads);
+    kp.kernelParams = args;
+    for (int with_events = 1; with_events >= 0 && !s.cexec; with_events--) {
+      hipGraphNode_t n_wait = nullptr, n_kernel = nullptr, n_rec = nullptr;
+      bool bad = hip_failed (hipGraphCreate (&s.cgraph, 0), "hipGraphCreate");
+      if (with_events)
+        bad = bad || hip_failed (hipGraphAddEventWaitNode (&n_wait, s.cgraph,
+                NULL, 0, s.ev_in), "hipGraphAddEventWaitNode");
+      bad = bad || hip_failed (hipGraphAddKernelNode (&n_kernel, s.cgraph,
+              with_events ? &n_wait : NULL, with_events ? 1 : 0, &kp),
+          "hipGraphAddKernelNode");
+      if (with_events)
+        bad = bad || hip_failed (hipGraphAddEventRecordNode (&n_rec, s.cgraph,
+                &n_kernel, 1, s.ev_kernel), "hipGraphAddEventRecordNode");
+      bad = bad || hip_failed (hipGraphInstantiate (&s.cexec, s.cgraph, NULL,
+              NULL, 0), "hipGraphInstantiate");
+      if (bad) {
+        (void) hipGetLastError ();
+        if (s.cgraph)
+          (void) hipGraphDestroy (s.cgraph);
+        s.cgraph = nullptr;
+        s.cexec = nullptr;
+        if (!with_events)
+          return MIBAYER_ERR_HIP;
+      } else {
+        s.cgraph_events = with_events != 0;
+      }
+    }
+  }
+  if (!s.cgraph_events)
+    HIP_TRY (hipStreamWaitEvent (c->s_compute, s.ev_in, 0));
+  HIP_TRY (hipGraphLaunch (s.cexec, c->s_compute));
+  if (!s.cgraph_events)
+    HIP_TRY (hipEventRecord (s.ev_kernel, c->s_compute));
+  return MIBAYER_OK;
+}
+
 /* upload -> kernel -> download of one frame through slot `s`, chained by events
  * across the three queues */
 static int enqueue_plain (mibayer_ctx *c, Slot &s, const uint8_t *src,
-    uint8_t *dst, size_t row_bytes)
+    uint8_t *dst, size_t row_bytes, bool compute_graph = false)
 {
   {
     Range r ("mibayer:h2d");
@@ -975,7 +1053,12 @@ static int enqueue_plain (mibayer_ctx *c, Slot &s, const uint8_t *src,
             c->s_h2d));
     HIP_TRY (hipEventRecord (s.ev_in, c->s_h2d));
   }
-  {
+  if (compute_graph) {
+    Range r ("mibayer:kernel(graph)");
+    const int rc = compute_graph_launch (c, s);
+    if (rc != MIBAYER_OK)
+      return rc;
+  } else {
     Range r ("mibayer:kernel");
     HIP_TRY (hipStreamWaitEvent (c->s_compute, s.ev_in, 0));
     const int rc = launch (c, s.d_src, c->src_bytes, s.d_dst, c->dst_bytes, 1,
@@ -1016,7 +1099,8 @@ static int enqueue_frame (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
     return MIBAYER_ERR_BUSY;
   Slot &s = c->ring[(size_t) c->head];
   const size_t row_bytes = written_row_bytes (c);       /* bytes of a destination row that are written */
-  if ((c->cfg.flags & MIBAYER_FLAG_HIPGRAPH) && !c->inverse
+  const bool want_graph = (c->cfg.flags & MIBAYER_FLAG_HIPGRAPH) && !c->inverse;
+  if (want_graph && c->graph_mode == 1
       && (size_t) c->cfg.dst_stride == row_bytes) {
     rc = graph_submit (c, s, src, dst);
     if (rc != MIBAYER_OK)
@@ -1028,7 +1112,7 @@ static int enqueue_frame (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
   }
   /* bands pay when this frame has the link to itself (measured at 4K: +7 %
    * synchronous, -6 % with three frames in flight, which overlap anyway) */
-  if (c->host_bands > 1 && alone && c->pending == 0) {
+  if (c->host_bands > 1 && alone && c->pending == 0 && !want_graph) {
     rc = enqueue_frame_banded (c, s, src, dst, row_bytes);
     if (rc != MIBAYER_OK)
       return rc;
@@ -1037,7 +1121,7 @@ static int enqueue_frame (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
     c->pending++;
     return MIBAYER_OK;
   }
-  rc = enqueue_plain (c, s, src, dst, row_bytes);
+  rc = enqueue_plain (c, s, src, dst, row_bytes, want_graph);
   if (rc != MIBAYER_OK)
     return rc;
   s.tag = tag;

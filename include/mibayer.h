@@ -86,9 +86,11 @@ typedef struct mibayer_cfg {
   uint32_t flags;         /* MIBAYER_FLAG_* or 0                             */
 } mibayer_cfg;
 
-/* Host path: run each frame's upload -> kernel -> download chain as one
- * instantiated hipGraph per ring slot (one hipGraphLaunch per frame instead of
- * three enqueues, two event waits and three event records). */
+/* Host path: the compute-queue segment of every frame (wait for the upload ->
+ * kernel -> signal the download) is captured once per ring slot as a hipGraph
+ * and replayed with one hipGraphLaunch per frame; the pinned H2D / D2H copies
+ * stay asynchronous copies on the two copy queues (BASELINE.json configs[4]:
+ * "pinned double-buffered H2D/D2H + hipGraph-captured launch"). */
 #define MIBAYER_FLAG_HIPGRAPH 1u
 
 /* Inverse direction, the plugin's sibling element rgb2bayer (reference

@@ -533,6 +533,43 @@ def test_numa_local_pinned_allocation(gpu_pkg, oracle):
     L.mibayer_host_free(p)
 
 
+@pytest.mark.parametrize("mechanism", ["streams", "hipgraph", "hipgraph_chain"])
+def test_config5_4k_stream_pinned_double_buffered_ring(gpu_pkg, oracle, mechanism, monkeypatch):
+    """BASELINE.json configs[4] at full size on one GPU's share: a 3840x2160 stream of 72 frames through TWO pinned
+    source and TWO pinned destination buffers (double-buffered H2D/D2H, two frames in flight), every output frame
+    compared with the oracle -- for the streams+events chain, for the hipGraph-captured launch (the compute-queue
+    segment of each slot as a graph) and for the whole-chain-per-slot graph arm."""
+    w, h, n, chunk = 3840, 2160, 72, 12
+    flags = 0 if mechanism == "streams" else gpu_pkg.FLAG_HIPGRAPH
+    if mechanism == "hipgraph_chain":
+        monkeypatch.setenv("MIBAYER_GRAPH_MODE", "chain")
+    L = gpu_pkg.lib()
+    r, g, b = gpu_pkg.FORMATS["BGRx"]
+    srcs = [_pinned(L, w * h, (h, w)) for _ in range(2)]
+    dsts = [_pinned(L, 4 * w * h, (h, 4 * w)) for _ in range(2)]
+    nthreads = min(os.cpu_count() or 1, 64)
+    with gpu_pkg.Context(w, h, "gbrg", "BGRx", inflight=2, flags=flags) as ctx:
+        checked = 0
+        for c0 in range(0, n, chunk):
+            frames = oracle.fill_synthetic(w, h, chunk, seed=4, first_frame=c0)
+            want = oracle.bayer2rgb_batch_bands(frames, w, "gbrg", r, g, b, nbands=4, nthreads=nthreads,
+                                                mode=oracle.simd_isas()[-1])
+            for i in range(chunk):
+                if ctx.pending() == 2:
+                    t = ctx.wait()
+                    assert np.array_equal(dsts[t % 2][1], want[t - c0]), (mechanism, t)
+                    checked += 1
+                srcs[i % 2][1][:] = frames[i]
+                ctx.submit(srcs[i % 2][1], dsts[i % 2][1], tag=c0 + i)
+            while ctx.pending():        # the chunk's last two frames, before `want` is replaced
+                t = ctx.wait()
+                assert np.array_equal(dsts[t % 2][1], want[t - c0]), (mechanism, t)
+                checked += 1
+        assert checked == n
+    for p, _ in srcs + dsts:
+        L.mibayer_host_free(p)
+
+
 def test_hipgraph_host_path_with_changing_pointers(gpu_pkg, oracle):
     """Graph mode patches the two host pointers into the instantiated graph per frame: pageable and pinned,
     fresh and recycled pointers must all give the oracle's bytes."""
