@@ -843,7 +843,8 @@ rgb2bayer_flat_kernel (R2BParams p)
   const uint32_t first = p.item0 + (tile.row * (uint32_t) (256 * K) + threadIdx.x) * IPG;
   u32x4 px[K][IPG];
   uint32_t par[K];
-  uint8_t *dptr[K];
+  size_t doff[K];               /* byte offset into p.dst (kept as an offset: the stores stay global_store) */
+  bool valid[K];
 #pragma unroll
   for (int k = 0; k < K; k++) {
     const uint32_t item = first + (uint32_t) k * 256u * IPG;
@@ -851,8 +852,9 @@ rgb2bayer_flat_kernel (R2BParams p)
     for (int h = 0; h < IPG; h++)
       px[k][h] = (u32x4) (0u);
     par[k] = 0;
-    dptr[k] = nullptr;
-    if (item < p.item_end) {
+    doff[k] = 0;
+    valid[k] = item < p.item_end;
+    if (valid[k]) {
       const uint32_t row = fastdiv (item, p.div_out_dwords);
       const uint32_t xd = item - row * p.div_out_dwords.d;
       const uint32_t f = fastdiv (row, p.div_height);
@@ -860,8 +862,7 @@ rgb2bayer_flat_kernel (R2BParams p)
       par[k] = y & 1u;
       const uint8_t *s = p.src + f * p.src_frame_bytes + (size_t) y * p.src_stride
           + (size_t) xd * 16;
-      dptr[k] = p.dst + f * p.dst_frame_bytes + (size_t) y * p.dst_stride
-          + (size_t) xd * 4;
+      doff[k] = f * p.dst_frame_bytes + (size_t) y * p.dst_stride + (size_t) xd * 4;
 #pragma unroll
       for (int h = 0; h < IPG; h++) {
         if constexpr (VEC16) {
@@ -882,29 +883,26 @@ rgb2bayer_flat_kernel (R2BParams p)
   }
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    if (dptr[k]) {
+    if (valid[k]) {
+      /* both selector pairs live in SGPRs: a select, not an indexed kernarg load */
+      const uint32_t sel_lo = par[k] ? p.sel_lo[1] : p.sel_lo[0];
+      const uint32_t sel_hi = par[k] ? p.sel_hi[1] : p.sel_hi[0];
       uint32_t out[IPG];
 #pragma unroll
       for (int h = 0; h < IPG; h++) {
-        const uint32_t lo = __builtin_amdgcn_perm (px[k][h].y, px[k][h].x, p.sel_lo[par[k]]);
-        const uint32_t hi = __builtin_amdgcn_perm (px[k][h].w, px[k][h].z, p.sel_hi[par[k]]);
+        /* pixels that were not loaded (x >= width) are zero, and so are their output bytes */
+        const uint32_t lo = __builtin_amdgcn_perm (px[k][h].y, px[k][h].x, sel_lo);
+        const uint32_t hi = __builtin_amdgcn_perm (px[k][h].w, px[k][h].z, sel_hi);
         out[h] = lo | hi;
       }
-      if constexpr (!VEC16) {
-        /* columns >= width inside the last dword of a row are written as 0 */
-        const uint32_t item = first + (uint32_t) k * 256u * IPG;
-        const uint32_t row = fastdiv (item, p.div_out_dwords);
-        const int valid = p.width - (int) (item - row * p.div_out_dwords.d) * 4;
-        if (valid < 4)
-          out[0] &= (1u << (8 * valid)) - 1u;
-      }
+      uint8_t *d = p.dst + doff[k];
       if constexpr (IPG == 2) {
         u32x2 v;
         v.x = out[0];
         v.y = out[1];
-        __builtin_nontemporal_store (v, (u32x2 *) dptr[k]);
+        __builtin_nontemporal_store (v, (u32x2 *) d);
       } else {
-        __builtin_nontemporal_store (out[0], (uint32_t *) dptr[k]);
+        __builtin_nontemporal_store (out[0], (uint32_t *) d);
       }
     }
   }
@@ -918,6 +916,7 @@ static R2BFn flat_kernel_for (int k, int px, int ld)
 #define R2B_FLAT(K, PX, LD) if (k == K && px == PX && ld == LD) return rgb2bayer_flat_kernel<K, PX, LD, VEC16>
   R2B_FLAT (1, 4, 0); R2B_FLAT (1, 4, 1); R2B_FLAT (1, 8, 0); R2B_FLAT (1, 8, 1);
   R2B_FLAT (2, 4, 0); R2B_FLAT (2, 4, 1); R2B_FLAT (2, 8, 0); R2B_FLAT (2, 8, 1);
+  R2B_FLAT (3, 4, 0); R2B_FLAT (3, 4, 1); R2B_FLAT (3, 8, 0); R2B_FLAT (3, 8, 1);
   R2B_FLAT (4, 4, 0); R2B_FLAT (4, 4, 1); R2B_FLAT (4, 8, 0); R2B_FLAT (4, 8, 1);
   R2B_FLAT (8, 4, 0); R2B_FLAT (8, 4, 1); R2B_FLAT (8, 8, 0); R2B_FLAT (8, 8, 1);
 #undef R2B_FLAT

@@ -20,7 +20,7 @@ if args and "x" in args[0]:
     W, H, N = (int(v) for v in args.pop(0).split("x"))
 if not args:
     args = ["%d:%d:%d:%d:0" % (k, px, ld, band) for k, px, ld, band in
-            itertools.product((1, 2, 4, 8), (4, 8), (0, 1), (-1, 0))]
+            itertools.product((1, 2, 3, 4), (4, 8), (0, 1), (-1, 0))]
     args += ["0:2:0:-1:0", "0:4:0:-1:0", "0:2:0:0:0"]
 arms = []
 for spec in args:
