@@ -1646,6 +1646,65 @@ extern "C" int mibayer_dev_download (int device, void *dst, const void *d_src,
   return MIBAYER_OK;
 }
 
+extern "C" void *mibayer_dev_stream_create (int device)
+{
+  if (device < 0 || device >= device_count_cached ())
+    return NULL;
+  DeviceGuard guard (device);
+  if (!guard.ok)
+    return NULL;
+  hipStream_t s = nullptr;
+  if (hip_failed (hipStreamCreateWithFlags (&s, hipStreamNonBlocking),
+          "hipStreamCreate"))
+    return NULL;
+  return (void *) s;
+}
+
+extern "C" void mibayer_dev_stream_destroy (int device, void *hip_stream)
+{
+  if (!hip_stream || device < 0 || device >= device_count_cached ())
+    return;
+  DeviceGuard guard (device);
+  (void) hipStreamSynchronize ((hipStream_t) hip_stream);
+  (void) hipStreamDestroy ((hipStream_t) hip_stream);
+}
+
+extern "C" int mibayer_dev_upload_async (int device, void *d_dst,
+    const void *src, size_t bytes, void *hip_stream)
+{
+  if (!d_dst || !src || !hip_stream)
+    return MIBAYER_ERR_ARG;
+  if (device < 0 || device >= device_count_cached ())
+    return MIBAYER_ERR_NO_DEVICE;
+  DeviceGuard guard (device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  Range r ("mibayer:h2d(async upload)");
+  HIP_TRY (hipMemcpyAsync (d_dst, src, bytes, hipMemcpyHostToDevice,
+          (hipStream_t) hip_stream));
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_dev_event_query (int device, void *event)
+{
+  if (!event)
+    return MIBAYER_ERR_ARG;
+  if (device < 0 || device >= device_count_cached ())
+    return MIBAYER_ERR_NO_DEVICE;
+  DeviceGuard guard (device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  const hipError_t e = hipEventQuery ((hipEvent_t) event);
+  if (e == hipSuccess)
+    return 1;
+  if (e == hipErrorNotReady) {
+    (void) hipGetLastError ();
+    return 0;
+  }
+  (void) hip_failed (e, "hipEventQuery");
+  return MIBAYER_ERR_HIP;
+}
+
 extern "C" void *mibayer_dev_event_create (int device)
 {
   if (device < 0 || device >= device_count_cached ())

@@ -37,7 +37,8 @@ GST_DEBUG_CATEGORY_STATIC (gst_mi_hip_debug);
 enum
 {
   PROP_0,
-  PROP_DEVICE_ID
+  PROP_DEVICE_ID,
+  PROP_ASYNC
 };
 
 /* bytes of one frame for either media type; same rules as bayer2rgb's
@@ -105,10 +106,25 @@ buffer_hip_memory (GstBuffer * buf)
 /* hipupload / hipdownload                                                   */
 /* ======================================================================== */
 
+/* hipupload: one host buffer whose DMA into device memory is still in flight */
+typedef struct
+{
+  GstBuffer *host_buf;          /* our reference keeps the memory (and its pool slot) alive */
+  GstMapInfo map;
+  gpointer event;               /* recorded on the copy queue right after the copy */
+} PendingUpload;
+
+#define MAX_PENDING_UPLOADS 4
+
 typedef struct
 {
   GstBaseTransform parent;
   gint device_id;
+  gboolean async;               /* hipupload: do not wait for the DMA (property "async") */
+  /* hipupload, async: the copy queue and the host buffers it still reads */
+  gpointer stream;
+  gint stream_device;
+  GQueue pending;               /* PendingUpload*, oldest first */
 } GstMiHipXfer;
 
 typedef struct
@@ -129,6 +145,8 @@ xfer_set_property (GObject * object, guint prop_id, const GValue * value,
 {
   if (prop_id == PROP_DEVICE_ID)
     GST_MI_HIP_XFER (object)->device_id = g_value_get_int (value);
+  else if (prop_id == PROP_ASYNC)
+    GST_MI_HIP_XFER (object)->async = g_value_get_boolean (value);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
 }
@@ -139,8 +157,158 @@ xfer_get_property (GObject * object, guint prop_id, GValue * value,
 {
   if (prop_id == PROP_DEVICE_ID)
     g_value_set_int (value, GST_MI_HIP_XFER (object)->device_id);
+  else if (prop_id == PROP_ASYNC)
+    g_value_set_boolean (value, GST_MI_HIP_XFER (object)->async);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
+}
+
+/* ---- asynchronous upload: deferred release of the host buffers --------------- */
+/* The synchronous uploader waits for every DMA, so upstream cannot fill the next
+ * frame while this one crosses PCIe.  Asynchronously, the copy is queued on the
+ * element's own copy queue, the device memory is marked with an event recorded
+ * after it (downstream orders its GPU work after that event, or waits for it on
+ * a CPU map -- the protocol of gstmihipmemory.h), and the element returns at
+ * once.  What has to outlive the call is the HOST buffer: the DMA engine still
+ * reads it, and handing it back to its pool would let upstream overwrite a frame
+ * that has not left yet.  So each upload keeps a mapped reference to its input
+ * buffer in `pending`, released when its own event has fired: polled at the
+ * next buffer, waited for when more than MAX_PENDING_UPLOADS pile up and
+ * before EOS / flush / stop. */
+
+static void
+pending_upload_free (GstMiHipXfer * self, PendingUpload * p)
+{
+  gst_buffer_unmap (p->host_buf, &p->map);
+  gst_buffer_unref (p->host_buf);
+  if (p->event)
+    mibayer_dev_event_destroy (self->stream_device, p->event);
+  g_free (p);
+}
+
+/* release what has completed; wait == TRUE: everything */
+static void
+xfer_reap_uploads (GstMiHipXfer * self, gboolean wait, guint keep)
+{
+  PendingUpload *p;
+
+  while ((p = g_queue_peek_head (&self->pending)) != NULL) {
+    gboolean must = wait || g_queue_get_length (&self->pending) > keep;
+
+    if (p->event != NULL) {
+      if (must)
+        mibayer_dev_event_wait (self->stream_device, p->event);
+      else if (mibayer_dev_event_query (self->stream_device, p->event) == 0)
+        break;                  /* still copying: younger ones are too */
+    }
+    g_queue_pop_head (&self->pending);
+    pending_upload_free (self, p);
+  }
+}
+
+static void
+xfer_drop_stream (GstMiHipXfer * self)
+{
+  xfer_reap_uploads (self, TRUE, 0);
+  if (self->stream) {
+    mibayer_dev_stream_destroy (self->stream_device, self->stream);
+    self->stream = NULL;
+  }
+}
+
+static gboolean
+xfer_upload_async (GstMiHipXfer * self, GstBuffer * inbuf, GstMemory * dev_mem)
+{
+  GstMiHipMemory *m = (GstMiHipMemory *) dev_mem;
+  PendingUpload *p;
+  GstMapInfo dev_map;
+  gsize n;
+
+  if (self->stream != NULL && self->stream_device != m->device)
+    xfer_drop_stream (self);
+  if (self->stream == NULL) {
+    self->stream = mibayer_dev_stream_create (m->device);
+    self->stream_device = m->device;
+    if (self->stream == NULL)
+      return FALSE;
+  }
+  xfer_reap_uploads (self, FALSE, MAX_PENDING_UPLOADS - 1);
+
+  p = g_new0 (PendingUpload, 1);
+  if (!gst_buffer_map (inbuf, &p->map, GST_MAP_READ)) {
+    g_free (p);
+    return FALSE;
+  }
+  if (!gst_memory_map (dev_mem, &dev_map,
+          GST_MAP_WRITE | GST_MAP_HIP | GST_MAP_HIP_ASYNC)) {
+    gst_buffer_unmap (inbuf, &p->map);
+    g_free (p);
+    return FALSE;
+  }
+  n = MIN (p->map.size, dev_map.size);
+  /* the copy starts after whatever the device memory's last user queued */
+  if (!gst_mi_hip_memory_order_after (m, self->stream))
+    gst_mi_hip_memory_wait (m);
+  if (mibayer_dev_upload_async (m->device, dev_map.data, p->map.data, n,
+          self->stream) != MIBAYER_OK) {
+    gst_memory_unmap (dev_mem, &dev_map);
+    gst_buffer_unmap (inbuf, &p->map);
+    g_free (p);
+    return FALSE;
+  }
+  /* two markers behind the copy: the memory's, for whoever touches it next, and
+   * ours, for the release of the host buffer */
+  p->event = mibayer_dev_event_create (m->device);
+  if (!gst_mi_hip_memory_mark_access (m, self->stream) || p->event == NULL
+      || mibayer_dev_event_record (m->device, p->event,
+          self->stream) != MIBAYER_OK) {
+    /* no event to defer on: finish now */
+    mibayer_dev_stream_destroy (m->device, self->stream);       /* synchronises */
+    self->stream = NULL;
+    gst_memory_unmap (dev_mem, &dev_map);
+    gst_buffer_unmap (inbuf, &p->map);
+    if (p->event)
+      mibayer_dev_event_destroy (m->device, p->event);
+    g_free (p);
+    return TRUE;
+  }
+  gst_memory_unmap (dev_mem, &dev_map);
+  p->host_buf = gst_buffer_ref (inbuf);
+  g_queue_push_tail (&self->pending, p);
+  return TRUE;
+}
+
+static gboolean
+xfer_sink_event (GstBaseTransform * trans, GstEvent * event)
+{
+  GstMiHipXfer *self = GST_MI_HIP_XFER (trans);
+
+  switch (GST_EVENT_TYPE (event)) {
+    case GST_EVENT_EOS:
+    case GST_EVENT_FLUSH_STOP:
+    case GST_EVENT_CAPS:
+      /* serialised with the streaming thread: hand every host buffer back */
+      xfer_reap_uploads (self, TRUE, 0);
+      break;
+    default:
+      break;
+  }
+  return GST_BASE_TRANSFORM_CLASS (gst_mi_hip_xfer_parent_class)->sink_event
+      (trans, event);
+}
+
+static gboolean
+xfer_stop (GstBaseTransform * trans)
+{
+  xfer_drop_stream (GST_MI_HIP_XFER (trans));
+  return TRUE;
+}
+
+static void
+xfer_finalize (GObject * object)
+{
+  xfer_drop_stream (GST_MI_HIP_XFER (object));
+  G_OBJECT_CLASS (gst_mi_hip_xfer_parent_class)->finalize (object);
 }
 
 static GstCaps *
@@ -186,10 +354,12 @@ xfer_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query,
   if (caps && frame_size_from_caps (caps, &size)) {
     GstBufferPool *pool =
         configured_pool (gst_mi_host_pool_new (GST_MI_HIP_XFER (trans)->
-            device_id), caps, (guint) size, 2);
+            device_id), caps, (guint) size, MAX_PENDING_UPLOADS + 2);
 
     if (pool) {
-      gst_query_add_allocation_pool (query, pool, (guint) size, 2, 0);
+      /* asynchronous uploads hold up to MAX_PENDING_UPLOADS input buffers */
+      gst_query_add_allocation_pool (query, pool, (guint) size,
+          MAX_PENDING_UPLOADS + 2, 0);
       gst_object_unref (pool);
     }
   }
@@ -249,6 +419,12 @@ xfer_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
             : "input"), (NULL));
     return GST_FLOW_ERROR;
   }
+  if (to_device && self->async) {
+    if (xfer_upload_async (self, inbuf, dev_mem))
+      return GST_FLOW_OK;
+    GST_WARNING_OBJECT (self, "asynchronous upload unavailable (%s): "
+        "copying synchronously", mibayer_last_hip_error ());
+  }
   if (!gst_buffer_map (host_buf, &host_map,
           to_device ? GST_MAP_READ : GST_MAP_WRITE))
     return GST_FLOW_ERROR;
@@ -282,9 +458,18 @@ gst_mi_hip_xfer_class_init (GstMiHipXferClass * klass)
 
   object_class->set_property = xfer_set_property;
   object_class->get_property = xfer_get_property;
+  object_class->finalize = xfer_finalize;
   g_object_class_install_property (object_class, PROP_DEVICE_ID,
       g_param_spec_int ("device-id", "Device ID", "HIP ordinal of the MI355X",
           0, G_MAXINT, 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (object_class, PROP_ASYNC,
+      g_param_spec_boolean ("async", "Asynchronous upload",
+          "hipupload: queue the host-to-device copy and return; the host buffer "
+          "is released when the copy has completed, downstream GPU work is "
+          "ordered after it (no effect on hipdownload)", TRUE,
+          G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  transform_class->sink_event = GST_DEBUG_FUNCPTR (xfer_sink_event);
+  transform_class->stop = GST_DEBUG_FUNCPTR (xfer_stop);
   transform_class->passthrough_on_same_caps = FALSE;
   transform_class->transform_caps = GST_DEBUG_FUNCPTR (xfer_transform_caps);
   transform_class->get_unit_size = GST_DEBUG_FUNCPTR (xfer_get_unit_size);
@@ -299,6 +484,10 @@ static void
 gst_mi_hip_xfer_init (GstMiHipXfer * self)
 {
   self->device_id = 0;
+  self->async = TRUE;
+  self->stream = NULL;
+  self->stream_device = 0;
+  g_queue_init (&self->pending);
 }
 
 #define SYS_CAPS "video/x-raw; video/x-bayer"

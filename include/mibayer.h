@@ -265,6 +265,19 @@ int mibayer_dev_upload (int device, void *d_dst, const void *src, size_t bytes);
 int mibayer_dev_download (int device, void *dst, const void *d_src,
     size_t bytes);
 
+/* Context-free copy queue and asynchronous upload, for an uploader that does
+ * not want to wait for its DMA (gst/gstmihipelements.c, hipupload: the host
+ * buffer is kept alive until the event recorded after the copy has fired, the
+ * pattern of the reference tree's sys/nvcodec/gstcudaupload.c made
+ * asynchronous).  `src` must stay valid until an event recorded on the stream
+ * after the call has completed; from pageable memory the call itself blocks. */
+void *mibayer_dev_stream_create (int device);
+void mibayer_dev_stream_destroy (int device, void *hip_stream);
+int mibayer_dev_upload_async (int device, void *d_dst, const void *src,
+    size_t bytes, void *hip_stream);
+/* 1 = the work recorded in the event has completed, 0 = not yet, < 0 = error */
+int mibayer_dev_event_query (int device, void *event);
+
 /* Context-free events, for stream-ordered hand-over of a device buffer from one
  * user to the next without a host round trip (GstMiHipMemory carries one as
  * its "last access" marker): record after the work that touches the buffer,

@@ -245,19 +245,22 @@ mibayer_internal_abandon (mibayer_ctx * c)
 
 typedef struct
 {
-  mibayer_ctx *ctx;
+  mibayer_ctx *ctx;             /* NULL: an asynchronous upload of `bytes` bytes, not a launch */
   const uint8_t *src;
   uint8_t *dst;
+  size_t bytes;
   uint32_t seq;
   int done;
 } mock_op;
 
 static mock_op g_ops[MOCK_MAX_OPS];
-static uint32_t g_nops;         /* launches queued so far == sequence number of the next one */
+static uint32_t g_nops;         /* launches and asynchronous copies queued so far, in device order */
+static uint32_t g_nlaunches;    /* launches among them == stamp of the next launch */
 
 typedef struct
 {
-  uint32_t marker;              /* launches queued before the record */
+  uint32_t marker;              /* launches / async copies queued before the record */
+  int queried;                  /* mibayer_dev_event_query says "not yet" once per record */
 } mock_event;
 
 static void
@@ -270,8 +273,16 @@ mock_complete_upto (uint32_t marker, const mibayer_ctx * only)
     unsigned sum = 0;
     size_t k;
 
-    if (op->done || (only && op->ctx != only))
+    (void) only;                /* one in-order device: earlier work of other contexts completes too */
+    if (op->done)
       continue;
+    if (op->ctx == NULL) {
+      /* asynchronous upload: the DMA reads the host buffer NOW -- if the element has let go of it, the
+       * sanitizer reports the use after free */
+      memcpy (op->dst, op->src, op->bytes);
+      op->done = 1;
+      continue;
+    }
     for (k = 0; k < op->ctx->src_bytes; k++)
       sum += op->src[k];        /* the source must still be alive */
     memset (op->dst, op->src[0], op->ctx->dst_bytes);
@@ -381,7 +392,7 @@ mibayer_process_device (mibayer_ctx * c, const void *d_src,
   op->ctx = c;
   op->src = d_src;
   op->dst = d_dst;
-  op->seq = g_nops;
+  op->seq = g_nlaunches++;
   op->done = 0;
   g_nops++;
   pthread_mutex_unlock (&g_lock);
@@ -419,6 +430,59 @@ mibayer_dev_upload (int device, void *d_dst, const void *src, size_t bytes)
   return MIBAYER_OK;
 }
 
+void *
+mibayer_dev_stream_create (int device)
+{
+  return device == 0 ? malloc (1) : NULL;
+}
+
+void
+mibayer_dev_stream_destroy (int device, void *hip_stream)
+{
+  pthread_mutex_lock (&g_lock);
+  mock_complete_upto (g_nops, NULL);    /* destroying a queue synchronises it */
+  pthread_mutex_unlock (&g_lock);
+  free (hip_stream);
+}
+
+/* queued, not executed: the copy happens when something ordered after it completes */
+int
+mibayer_dev_upload_async (int device, void *d_dst, const void *src, size_t bytes, void *hip_stream)
+{
+  mock_op *op;
+
+  if (!d_dst || !src || !hip_stream)
+    return MIBAYER_ERR_ARG;
+  pthread_mutex_lock (&g_lock);
+  op = &g_ops[g_nops % MOCK_MAX_OPS];
+  op->ctx = NULL;
+  op->src = src;
+  op->dst = d_dst;
+  op->bytes = bytes;
+  op->seq = g_nops;
+  op->done = 0;
+  g_nops++;
+  pthread_mutex_unlock (&g_lock);
+  return MIBAYER_OK;
+}
+
+int
+mibayer_dev_event_query (int device, void *event)
+{
+  mock_event *ev = event;
+
+  if (!ev)
+    return MIBAYER_ERR_ARG;
+  if (!ev->queried) {
+    ev->queried = 1;
+    return 0;                   /* "still copying" */
+  }
+  pthread_mutex_lock (&g_lock);
+  mock_complete_upto (ev->marker, NULL);
+  pthread_mutex_unlock (&g_lock);
+  return 1;
+}
+
 int
 mibayer_dev_download (int device, void *dst, const void *d_src, size_t bytes)
 {
@@ -445,6 +509,7 @@ mibayer_dev_event_record (int device, void *event, void *hip_stream)
     return MIBAYER_ERR_ARG;
   pthread_mutex_lock (&g_lock);
   ((mock_event *) event)->marker = g_nops;
+  ((mock_event *) event)->queried = 0;
   pthread_mutex_unlock (&g_lock);
   return MIBAYER_OK;
 }

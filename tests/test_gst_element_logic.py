@@ -279,3 +279,22 @@ def test_both_plugins_in_one_process_keep_their_pinned_pools(rig):
                  "hipdownload ! rgb2bayer ! fakesink"):
         kv = run(rig, "states", desc, 2, extra_env={"G_DEBUG": "fatal-criticals"})
         assert kv["cycles_ok"] == "2"
+
+
+@pytest.mark.parametrize("upload", ["hipupload", "hipupload async=false"])
+def test_asynchronous_upload_keeps_the_host_buffer_until_the_copy_is_done(rig, tmp_path, upload):
+    """hipupload queues its DMA and returns: the double executes an asynchronous copy only when something ordered after
+    it completes, and reads the HOST buffer at that moment -- an input buffer handed back before its copy was done is
+    a use-after-free report.  The double also answers the first completion query of every event with "not yet", so both
+    the polling and the waiting release path run.  Frames, order and bytes as with the synchronous uploader."""
+    w, h, n = 258, 37, 14
+    inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
+    frames(n, 260 * h, first=70).tofile(inp)
+    for tail in ("hipbayer2rgb ! hipdownload", "hipdownload ! bayer2rgb", "hipbayer2rgb"):
+        kv = run(rig, "convert", "%s ! %s" % (upload, tail), B2R % ("gbrg", w, h), inp, 260 * h, outp)
+        assert kv["pushed"] == str(n) and kv["pulled"] == str(n), tail
+        _, fill = stamps(outp, n, 4 * w * h)
+        assert fill == list(range(70, 70 + n)), tail
+    kv = run(rig, "states", "videotestsrc num-buffers=12 ! video/x-bayer,format=rggb,width=64,height=48 ! %s ! "
+             "hipbayer2rgb ! queue ! hipdownload ! fakesink" % upload, 3)
+    assert kv["cycles_ok"] == "3"
