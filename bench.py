@@ -218,6 +218,7 @@ def host_path_rate(pkg, device, frames=24, inflight=3, flags=0, graph_mode=None)
 
 
 def host_path_note(pkg, device):
+    host_path_rate(pkg, device, 12, 3, 0)       # first touch of the copy queues and the PCIe link: not measured
     plain, _ = host_path_rate(pkg, device, 24, 3, 0)
     graph, _ = host_path_rate(pkg, device, 24, 3, pkg.FLAG_HIPGRAPH)
     chain, _ = host_path_rate(pkg, device, 24, 3, pkg.FLAG_HIPGRAPH, "chain")

@@ -164,6 +164,34 @@ int device_count_cached ()
 
 }  /* namespace */
 
+/* The three queues of the host path (uploads, kernels, downloads), one set per
+ * DEVICE, shared by every context on it.  Contexts used to own their queues;
+ * with N contexts on one GPU (devices=0,0,0,0, or several elements on one card)
+ * that put N download queues on the one PCIe-facing DMA engine, and the engine
+ * spent its time switching between them: 4 shards x 2 frames through pinned
+ * buffers ran at 25.6 GB/s D2H against 53 GB/s for one context
+ * (profiles/r02_pool_pageable.log).  In one queue per direction the copies go
+ * back to back; frames of different contexts are independent chains of events,
+ * so sharing a queue costs no concurrency that the hardware could have used --
+ * there is one DMA engine per direction and one kernel fills the GPU.
+ * MIBAYER_SHARED_QUEUES=0 restores private queues (A/B). */
+struct DeviceQueues {
+  hipStream_t h2d = nullptr, compute = nullptr, d2h = nullptr;
+  int refs = 0;
+};
+
+static std::mutex g_queues_mu;
+static DeviceQueues g_queues[64];
+
+static bool shared_queues_enabled ()
+{
+  static const bool on = [] {
+    const char *e = getenv ("MIBAYER_SHARED_QUEUES");
+    return !(e && e[0] == '0');
+  } ();
+  return on;
+}
+
 struct mibayer_ctx {
   mibayer_cfg cfg;
   int device = 0;
@@ -196,6 +224,7 @@ struct mibayer_ctx {
   hipStream_t s_h2d = nullptr;
   hipStream_t s_compute = nullptr;
   hipStream_t s_d2h = nullptr;
+  bool shared_queues = false;           /* the three above belong to g_queues[device] */
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   std::vector<Slot> ring;
   Slot spare;                   /* mibayer_internal_run_spare: outside the ring */
@@ -635,12 +664,39 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
     return MIBAYER_ERR_HIP;
   }
   bool bad = false;
-  bad |= hip_failed (hipStreamCreateWithFlags (&c->s_h2d,
-          hipStreamNonBlocking), "hipStreamCreate");
-  bad |= hip_failed (hipStreamCreateWithFlags (&c->s_compute,
-          hipStreamNonBlocking), "hipStreamCreate");
-  bad |= hip_failed (hipStreamCreateWithFlags (&c->s_d2h,
-          hipStreamNonBlocking), "hipStreamCreate");
+  if (shared_queues_enabled () && dev < 64) {
+    std::lock_guard<std::mutex> lk (g_queues_mu);
+    DeviceQueues &q = g_queues[dev];
+    if (q.refs == 0) {
+      bad |= hip_failed (hipStreamCreateWithFlags (&q.h2d, hipStreamNonBlocking),
+          "hipStreamCreate");
+      bad |= hip_failed (hipStreamCreateWithFlags (&q.compute,
+              hipStreamNonBlocking), "hipStreamCreate");
+      bad |= hip_failed (hipStreamCreateWithFlags (&q.d2h, hipStreamNonBlocking),
+          "hipStreamCreate");
+      if (bad) {
+        for (hipStream_t *st : { &q.h2d, &q.compute, &q.d2h }) {
+          if (*st)
+            (void) hipStreamDestroy (*st);
+          *st = nullptr;
+        }
+      }
+    }
+    if (!bad) {
+      q.refs++;
+      c->s_h2d = q.h2d;
+      c->s_compute = q.compute;
+      c->s_d2h = q.d2h;
+      c->shared_queues = true;
+    }
+  } else {
+    bad |= hip_failed (hipStreamCreateWithFlags (&c->s_h2d,
+            hipStreamNonBlocking), "hipStreamCreate");
+    bad |= hip_failed (hipStreamCreateWithFlags (&c->s_compute,
+            hipStreamNonBlocking), "hipStreamCreate");
+    bad |= hip_failed (hipStreamCreateWithFlags (&c->s_d2h,
+            hipStreamNonBlocking), "hipStreamCreate");
+  }
   bad |= hip_failed (hipEventCreate (&c->ev_t0), "hipEventCreate");
   bad |= hip_failed (hipEventCreate (&c->ev_t1), "hipEventCreate");
   if (bad) {
@@ -711,12 +767,23 @@ extern "C" void mibayer_destroy (mibayer_ctx *c)
     (void) hipEventDestroy (c->ev_t0);
   if (c->ev_t1)
     (void) hipEventDestroy (c->ev_t1);
-  if (c->s_h2d)
-    (void) hipStreamDestroy (c->s_h2d);
-  if (c->s_compute)
-    (void) hipStreamDestroy (c->s_compute);
-  if (c->s_d2h)
-    (void) hipStreamDestroy (c->s_d2h);
+  if (c->shared_queues) {
+    std::lock_guard<std::mutex> lk (g_queues_mu);
+    DeviceQueues &q = g_queues[c->device];
+    if (--q.refs == 0) {
+      (void) hipStreamDestroy (q.h2d);
+      (void) hipStreamDestroy (q.compute);
+      (void) hipStreamDestroy (q.d2h);
+      q = DeviceQueues ();
+    }
+  } else {
+    if (c->s_h2d)
+      (void) hipStreamDestroy (c->s_h2d);
+    if (c->s_compute)
+      (void) hipStreamDestroy (c->s_compute);
+    if (c->s_d2h)
+      (void) hipStreamDestroy (c->s_d2h);
+  }
   delete c;
 }
 

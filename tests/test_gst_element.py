@@ -228,10 +228,12 @@ def test_pinned_pools_are_proposed_and_used(plugin, gpu_pkg, oracle, tmp_path):
 
 @pytest.mark.gpu
 @needs_gst
-def test_out_of_domain_geometry_is_a_clear_error(plugin, gpu_pkg, tmp_path):
-    """Odd widths are where the reference reads stale scratch (gstbayer2rgb.c:365-380): this element refuses them
-    with a STREAM/FORMAT error instead of producing undefined pixels."""
-    res = launch(tmp_path, "videotestsrc num-buffers=1 ! video/x-bayer,format=bggr,width=65,height=48 "
-                           "! bayer2rgb ! fakesink")
-    assert res.returncode != 0
-    assert "unsupported frame geometry 65x48" in res.stderr + res.stdout
+def test_out_of_domain_geometry_is_refused_at_negotiation(plugin, gpu_pkg, tmp_path):
+    """Odd widths are where the reference reads stale scratch (gstbayer2rgb.c:365-380), heights below 3 where it reads
+    rows that do not exist (:430-447): set_caps refuses them -- not-negotiated, the reference's own failure style
+    (:263-265), before any buffer is allocated -- instead of producing undefined pixels or failing at the first frame."""
+    for w, h in ((65, 48), (2, 48), (64, 2)):
+        res = launch(tmp_path, "videotestsrc num-buffers=1 ! video/x-bayer,format=bggr,width=%d,height=%d "
+                               "! bayer2rgb ! fakesink" % (w, h))
+        assert res.returncode != 0
+        assert "not-negotiated" in res.stderr + res.stdout, (w, h)

@@ -26,5 +26,6 @@ python -c "
 import json; b=json.load(open('$O/driver_args_1.json')); print('host_path', b.get('host_path')); c=b.get('cpu_baseline',{}); print('cpu', c.get('value'), c.get('all_cores'))"
 echo "== stream mode (configs[4])"; timeout 600 python bench.py --mode stream 2>/dev/null | tail -1 | tee $O/stream.json | cut -c1-1200
 echo "== alloc placement probe"; timeout 600 python tools/alloc_placement_probe.py 5 2>&1 | tee $O/alloc_placement.log
-echo "== pool pageable bench"; timeout 600 python tools/pool_pageable_bench.py 4 200 2>&1 | tee $O/pool_pageable.log
+echo "== pool pageable bench, shared per-device queues (default)"; timeout 600 python tools/pool_pageable_bench.py 4 200 2>&1 | tee $O/pool_pageable.log
+echo "== pool pageable bench, private queues per context"; MIBAYER_SHARED_QUEUES=0 timeout 600 python tools/pool_pageable_bench.py 4 200 2>&1 | tee $O/pool_pageable_private.log
 echo "== rgb2bayer sweep"; timeout 600 python tools/r2b_sweep.py 2>&1 | tee $O/r2b_sweep.log | head -16
