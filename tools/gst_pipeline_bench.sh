@@ -22,6 +22,8 @@ DEV='video/x-raw(memory:HIPMemory),format=BGRx'
 # (ten times the frames: this pipeline is fast enough for process start-up noise to matter)
 a=$(run 20 "hipupload ! hipbayer2rgb" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb" "$DEV")
 line "hipupload ! hipbayer2rgb (stays on GPU)" $a $b $((10*N))
+a=$(run 20 "hipupload async=false ! hipbayer2rgb" "$DEV"); b=$(run $((10*N+20)) "hipupload async=false ! hipbayer2rgb" "$DEV")
+line "hipupload async=false ! hipbayer2rgb" $a $b $((10*N))
 a=$(run 20 "hipupload ! hipbayer2rgb ! hipdownload"); b=$(run $((N+20)) "hipupload ! hipbayer2rgb ! hipdownload")
 line "hipupload ! hipbayer2rgb ! hipdownload" $a $b
 # the inverse element: 4 B/px in, 1 B/px out
@@ -36,7 +38,7 @@ for mode in "rgb2bayer" "rgb2bayer inflight=4"; do
   a=$(run_inv 20 "$mode"); b=$(run_inv $((N+20)) "$mode")
   line "$mode" $a $b
 done
-for mode in "bayer2rgb" "bayer2rgb inflight=2" "bayer2rgb inflight=4" "bayer2rgb inflight=3 devices=0,0" "bayer2rgb inflight=4 hipgraph=true" "bayer2rgb pinned-pool=false"; do
+for mode in "bayer2rgb" "bayer2rgb inflight=2" "bayer2rgb inflight=4" "bayer2rgb inflight=3 devices=0,0" "bayer2rgb inflight=4 hipgraph=true" "bayer2rgb pinned-pool=false" "bayer2rgb inflight=2 devices=0,0,0,0" "bayer2rgb inflight=2 devices=0,0,0,0 pinned-pool=false"; do
   a=$(run 20 "$mode"); b=$(run $((N+20)) "$mode")
   echo "$mode | $a $b $N" | awk -F'|' '{split($2,v," "); dt=v[2]-v[1]; printf "%-44s %7.1f fps  %8.1f Mpix/s  (%.3f s for %d frames)\n", $1, v[3]/dt, v[3]*3840*2160/dt/1e6, dt, v[3]}'
 done

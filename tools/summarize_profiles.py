@@ -62,7 +62,8 @@ if os.path.exists(bench):
 stats = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
-    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu --no-host-path`", "",
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-host-path` "
+              "(the driver's arguments)", "",
               "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---:|---:|---:|---:|---:|"]
     for r in csv.DictReader(open(stats[0])):
         lines.append("| `%s` | %s | %.0f | %s | %s | %s |" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]),
@@ -72,12 +73,12 @@ if stats:
     if trace:
         rows = [r for r in csv.DictReader(open(trace[0])) if "bayer2rgb" in r["Kernel_Name"]]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-        timed = rows[-100:]
+        timed = rows[-21:-1]        # the very last dispatch is the parity spot check after the timed region
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in timed]
-        lines.append("Timed region only (the last 100 bayer2rgb dispatches of the trace = the 100 timed steps, kernel `%s`): "
+        lines.append("Timed region only (the 20 bayer2rgb dispatches before the final parity launch = the 20 timed steps, kernel `%s`): "
                      "**avg %.0f ns**, min %d, max %d." % (timed[-1]["Kernel_Name"][:60], sum(d) / len(d), min(d), max(d)))
         lines.append("")
-    lines.append("(calls include the autotune launches of `mibayer_autotune`, which try two tile shapes x three block orders in three rounds; "
+    lines.append("(calls include the launches of `mibayer_autotune` -- two tile shapes x three block orders, five rounds -- and the ~150 ms time-based pre-warm; "
                  "profiled runs clock ~2 % lower than unprofiled ones, MI355X_MICROARCH.md \"DVFS\")")
     lines.append("")
 
@@ -131,8 +132,16 @@ if plans:
     lines += ["", "Halo lines that live in another XCD's L2 are fetched through the fabric again (the 256 MB Infinity Cache "
                   "absorbs them before HBM): all of them for the identity order, the rows above/below a tile row for "
                   "band 1, none for the chunk order.", ""]
+    serial, build = None, None
+    if os.path.exists(box):
+        for ln in open(box):
+            if "Serial Number:" in ln:
+                serial = ln.split()[-1]
+    bh = os.path.join(src, "build_hash.txt")
+    if os.path.exists(bh):
+        build = open(bh).read().strip()
     with open(os.path.join(dst, "traffic_latest.json"), "w") as f:
-        json.dump({"plans": out, "algorithmic_bytes_per_launch": ALG_R + ALG_W,
+        json.dump({"plans": out, "algorithmic_bytes_per_launch": ALG_R + ALG_W, "box_serial": serial, "build": build,
                    "source": "profiles/%s_summary.md (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + --pmc "
                              "WRITE_SIZE, separate passes, mean over the timed bench launches, per block order)" % tag},
                   f, indent=1)
