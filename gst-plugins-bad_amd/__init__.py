@@ -374,7 +374,7 @@ class Context:
 
     def autotune(self, d_src, d_dst, nframes, src_frame_bytes=None, dst_frame_bytes=None):
         """Measured plan selection (mibayer_autotune); returns the one-line report."""
-        buf = ctypes.create_string_buffer(512)
+        buf = ctypes.create_string_buffer(1024)
         _check(lib().mibayer_autotune(
             self._h, _vp(d_src), src_frame_bytes or self.src_bytes, _vp(d_dst),
             dst_frame_bytes or self.dst_bytes, nframes, buf, len(buf)), "mibayer_autotune")

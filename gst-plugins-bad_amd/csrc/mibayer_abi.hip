@@ -1425,10 +1425,14 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
   /* candidate plans: {configured shape, one other production shape under
    * "auto"} x {band 1, one chunk per XCD, identity}; the band orders carry the
    * automatic start delay */
-  const Variant *shapes[2] = { c->var, nullptr };
+  const Variant *shapes[3] = { c->var, nullptr, nullptr };
   int nshapes = 1;
-  if (c->cfg.variant == 0)
-    shapes[nshapes++] = (c->var != &variant (3)) ? &variant (3) : &variant (1);
+  if (c->cfg.variant == 0) {
+    /* the other production shapes (1024x8, 512x16, 256x32 px tiles) */
+    for (int v = 3; v >= 1; v--)
+      if (c->var != &variant (v))
+        shapes[nshapes++] = &variant (v);
+  }
   const bool band_forced = getenv ("MIBAYER_XCD_BAND") != NULL;
   const int bands[3] = { 1, -1, 0 };
   const int nbands = band_forced ? 1 : 3;
@@ -1441,7 +1445,7 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
    * reason alone), one slow round (another process, a DVFS step) must not
    * decide the plan, and neither may one lucky round -- the plan has to be the
    * one that is fastest in steady state, which is what the caller then runs. */
-  constexpr int kRounds = 5, kWarm = 16, kReps = 6, kCands = 6;
+  constexpr int kRounds = 5, kWarm = 16, kReps = 6, kCands = 9;
   constexpr double kWarmMs = 60.0;
   float round_ms[kCands][kRounds];
   float cand_ms[kCands];

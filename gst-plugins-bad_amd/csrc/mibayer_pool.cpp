@@ -20,13 +20,17 @@
  *
  *  - PAGEABLE BUFFERS.  hipMemcpyAsync from / to pageable memory blocks the
  *    calling thread while the runtime stages it, so one streaming thread would
- *    feed N GPUs one after the other.  A frame whose source or destination is
- *    pageable is handed to a helper thread of its shard (one per shard, started
- *    on first use), which runs the whole frame synchronously through a spare
- *    slot of the context; the streaming thread only queues and, at wait time,
- *    blocks on the oldest frame.  Pinned frames keep the direct, enqueue-only
- *    path.  (A second CPU copy through a pinned bounce buffer was rejected: the
- *    runtime's own staging moves ~40 GB/s, a memcpy thread ~10.)
+ *    feed N GPUs one after the other.  In a pool of more than one shard, the
+ *    first frame whose source or destination is pageable turns its shard over to
+ *    a helper thread (one per shard, started on first use): from then on the
+ *    helper drives that context's submit / wait ring -- so uploads, kernels and
+ *    downloads of consecutive frames keep overlapping inside the shard -- and
+ *    the streaming thread only queues and, at wait time, blocks on the oldest
+ *    frame.  Shards that only ever see pinned frames keep the direct,
+ *    enqueue-only path, and so does a single-shard pool (a helper would add a
+ *    hand-off and no parallelism).  (A second CPU copy through a pinned bounce
+ *    buffer was rejected: the runtime's own staging moves ~40 GB/s, a memcpy
+ *    thread ~10.)
  *
  *  - FAULT INJECTION for drills and tests: mibayer_pool_inject_fault() /
  *    MIBAYER_INJECT_FAULT=shard:frames make a shard report a device error after
@@ -48,9 +52,9 @@
 namespace {
 
 enum FrameState {
-  F_DIRECT,     /* in the ring of its shard's context (mibayer_submit)            */
+  F_DIRECT,     /* in the ring of its shard's context, submitted by the streaming thread */
   F_QUEUED,     /* in the job queue of its shard's helper thread                  */
-  F_RUNNING,    /* the helper thread is converting it                             */
+  F_RUNNING,    /* the helper thread has it (being submitted, or in the context's ring) */
   F_DONE,       /* converted by a helper thread (or by a synchronous re-do)       */
   F_FAILED,     /* the helper thread got a device error for it                    */
   F_REDO        /* its device failed: convert again on a surviving device         */
@@ -78,7 +82,10 @@ struct Shard {
   bool th_started = false;
   std::mutex mu;
   std::condition_variable cv_job, cv_done;
-  std::deque<Frame *> jobs;
+  std::deque<Frame *> jobs;     /* waiting for room in the context's ring             */
+  std::deque<Frame *> ring;     /* in the context's ring, oldest first (helper mode)  */
+  bool helper_mode = false;     /* the helper thread owns the context's submit / wait */
+  int ring_room = 2;            /* stream.inflight                                     */
   bool quit = false;
   bool broken = false;
   char errmsg[200] = "";
@@ -97,37 +104,83 @@ bool device_failure (int rc)
   return rc == MIBAYER_ERR_HIP || rc == MIBAYER_ERR_NOMEM;
 }
 
+/* everything the helper still holds is re-done elsewhere (mu held) */
+void helper_give_up (Shard *sh, const char *why)
+{
+  sh->broken = true;
+  snprintf (sh->errmsg, sizeof sh->errmsg, "%s", why ? why : "");
+  for (Frame *f : sh->ring)
+    f->state = F_REDO;
+  sh->ring.clear ();
+  for (Frame *f : sh->jobs)
+    f->state = F_REDO;
+  sh->jobs.clear ();
+  sh->cv_done.notify_all ();
+}
+
+/* Helper mode: this thread is the only caller of the context's submit / wait.
+ * It keeps the ring as full as the queue allows (a submit from pageable memory
+ * blocks while the runtime stages the upload -- that is the point of being on a
+ * thread of its own) and retires the oldest frame whenever nothing can be
+ * submitted. */
 void helper_main (Shard *sh)
 {
   std::unique_lock<std::mutex> lk (sh->mu);
   for (;;) {
-    sh->cv_job.wait (lk, [sh] { return sh->quit || !sh->jobs.empty (); });
-    if (sh->jobs.empty ())
-      return;                   /* quit */
-    Frame *f = sh->jobs.front ();
-    sh->jobs.pop_front ();
+    sh->cv_job.wait (lk, [sh] {
+      return sh->quit || !sh->jobs.empty () || !sh->ring.empty ();
+    });
+    if (sh->quit && sh->jobs.empty () && sh->ring.empty ())
+      return;
     if (sh->broken) {
-      f->state = F_REDO;
-      sh->cv_done.notify_all ();
+      helper_give_up (sh, sh->errmsg);
       continue;
     }
-    f->state = F_RUNNING;
-    lk.unlock ();
-    int rc = mibayer_internal_run_spare (sh->ctx, f->src, f->dst);
-    if (rc == MIBAYER_OK && sh->fault_due ())
-      rc = MIBAYER_ERR_HIP;
-    lk.lock ();
-    f->rc = rc;
-    if (rc == MIBAYER_OK) {
-      f->state = F_DONE;
-    } else {
-      f->state = F_FAILED;
-      if (device_failure (rc)) {
-        sh->broken = true;
-        snprintf (sh->errmsg, sizeof sh->errmsg, "%s", mibayer_last_hip_error ());
+    if (!sh->jobs.empty () && (int) sh->ring.size () < sh->ring_room) {
+      Frame *f = sh->jobs.front ();
+      sh->jobs.pop_front ();
+      f->state = F_RUNNING;
+      sh->ring.push_back (f);
+      lk.unlock ();
+      const int rc = mibayer_submit (sh->ctx, f->src, f->dst, f);
+      lk.lock ();
+      if (rc != MIBAYER_OK) {
+        f->rc = rc;
+        if (!sh->ring.empty () && sh->ring.back () == f)
+          sh->ring.pop_back ();
+        if (device_failure (rc)) {
+          f->state = F_REDO;
+          helper_give_up (sh, mibayer_last_hip_error ());
+        } else {
+          f->state = F_FAILED;
+          sh->cv_done.notify_all ();
+        }
+      }
+      continue;
+    }
+    if (!sh->ring.empty ()) {
+      Frame *f = sh->ring.front ();
+      lk.unlock ();
+      int rc = mibayer_wait (sh->ctx, NULL);
+      if (rc == MIBAYER_OK && sh->fault_due ())
+        rc = MIBAYER_ERR_HIP;
+      lk.lock ();
+      if (sh->ring.empty () || sh->ring.front () != f)
+        continue;               /* the shard was given up meanwhile */
+      if (rc == MIBAYER_OK) {
+        sh->ring.pop_front ();
+        f->state = F_DONE;
+        sh->cv_done.notify_all ();
+      } else if (device_failure (rc)) {
+        f->rc = rc;
+        helper_give_up (sh, mibayer_last_hip_error ());    /* f and everything behind it: F_REDO */
+      } else {
+        sh->ring.pop_front ();
+        f->rc = rc;
+        f->state = F_FAILED;
+        sh->cv_done.notify_all ();
       }
     }
-    sh->cv_done.notify_all ();
   }
 }
 
@@ -163,12 +216,16 @@ static void kill_shard (mibayer_pool *pool, int idx, int rc, const char *why)
   sh->alive = false;
   {
     std::lock_guard<std::mutex> lk (sh->mu);
+    if (!why || !why[0])
+      why = sh->errmsg;
     sh->broken = true;
+    for (Frame *f : sh->ring)
+      f->state = F_REDO;
+    sh->ring.clear ();
     for (Frame *f : sh->jobs)
       f->state = F_REDO;
     sh->jobs.clear ();
-    if (!why || !why[0])
-      why = sh->errmsg;
+    sh->cv_job.notify_all ();
   }
   for (Frame &f : pool->fifo)
     if (f.shard == idx && f.state == F_DIRECT)
@@ -216,6 +273,26 @@ static void queue_to_helper (Shard *sh, Frame *f)
   sh->cv_job.notify_one ();
 }
 
+/* The first pageable frame of a shard: from now on its helper thread is the only
+ * one that touches the context's submit / wait ring.  Frames the streaming
+ * thread had submitted itself and that are still in that ring are handed over,
+ * in order, so the helper retires them first. */
+static void enter_helper_mode (mibayer_pool *pool, int idx)
+{
+  Shard *sh = pool->shards[(size_t) idx];
+  if (sh->helper_mode)
+    return;
+  start_helper (sh);
+  std::lock_guard<std::mutex> lk (sh->mu);
+  sh->helper_mode = true;
+  for (Frame &f : pool->fifo)
+    if (f.shard == idx && f.state == F_DIRECT) {
+      f.state = F_RUNNING;
+      sh->ring.push_back (&f);
+    }
+  sh->cv_job.notify_one ();
+}
+
 extern "C" int mibayer_pool_create (const mibayer_pool_cfg *cfg,
     mibayer_pool **out)
 {
@@ -257,7 +334,11 @@ extern "C" int mibayer_pool_create (const mibayer_pool_cfg *cfg,
     if (mibayer_get_cfg (pool->shards[0]->ctx, &resolved) == MIBAYER_OK
         && resolved.inflight > 0)
       pool->per_shard = resolved.inflight;
+    for (Shard *sh : pool->shards)
+      sh->ring_room = pool->per_shard;
   }
+  /* one shard: a helper would only add a hand-off */
+  pool->use_helpers = pool->shards.size () > 1;
   if (const char *e = getenv ("MIBAYER_POOL_HELPERS"))
     pool->use_helpers = atoi (e) != 0;
   if (const char *e = getenv ("MIBAYER_INJECT_FAULT")) {
@@ -369,10 +450,11 @@ extern "C" int mibayer_pool_submit (mibayer_pool *pool, const uint8_t *src,
     if (sh->inflight >= pool->per_shard)
       return MIBAYER_ERR_BUSY;
     Frame f = { src, dst, tag, (int) idx, (int) idx, F_DIRECT, MIBAYER_OK };
-    const bool pageable = pool->use_helpers
+    if (pool->use_helpers && !sh->helper_mode
         && (mibayer_internal_is_pageable (src)
-            || mibayer_internal_is_pageable (dst));
-    if (pageable) {
+            || mibayer_internal_is_pageable (dst)))
+      enter_helper_mode (pool, (int) idx);
+    if (sh->helper_mode) {
       pool->fifo.push_back (f);
       queue_to_helper (sh, &pool->fifo.back ());
     } else {
@@ -445,8 +527,8 @@ extern "C" int mibayer_pool_wait (mibayer_pool *pool, void **tag)
     pool->redo_rr = (idx + 1) % n;
     Shard *to = pool->shards[idx];
     f.shard = (int) idx;
-    if (to->th_started) {
-      /* its helper thread owns the spare slot */
+    if (to->helper_mode) {
+      /* its helper thread owns the context: an ordinary job for it */
       queue_to_helper (to, &f);
       continue;
     }

@@ -218,11 +218,11 @@ int mibayer_time_device (mibayer_ctx *ctx, const void *d_src,
 
 /* Measured launch-plan selection for the device-resident path.  MI355X boxes
  * differ in which block->tile order streams best (DESIGN.md "XCD map"): this
- * call times the candidate plans (two tile shapes x {band 1, one chunk per
- * XCD, identity order}) on the caller's own buffers with HIP events on the
+ * call times the candidate plans (the three production tile shapes x {band 1,
+ * one chunk per XCD, identity order}) on the caller's own buffers with HIP events on the
  * context's compute stream -- a common time-based warm-up (>= 60 ms of
  * launches), then five interleaved rounds of a few launches per candidate, the
- * MEDIAN round counts (about 350 launches in all) -- and keeps the fastest
+ * MEDIAN round counts (about 400 launches in all) -- and keeps the fastest
  * for every later launch of this context.  The
  * kernel is idempotent, so d_dst holds the correct output afterwards.
  * Synchronous.  `report` (may be NULL) receives a one-line summary. */
