@@ -171,11 +171,12 @@ def test_multi_frame_stream_1080p(plugin, gpu_pkg, oracle, tmp_path):
     assert md5(got[0].tobytes()) == "f14f6ad248ef0bac0f28546db6d14813"
 
 
-def _tee_pipeline(tmp, props, nbuf, w=640, h=480, order="bggr", fmt="RGBx", debug=None):
+def _tee_pipeline(tmp, props, nbuf, w=640, h=480, order="bggr", fmt="RGBx", debug=None, extra_env=None):
     inp, outp = str(tmp / "in.raw"), str(tmp / "out.raw")
     env_extra = {"GST_DEBUG": debug, "GST_DEBUG_NO_COLOR": "1"} if debug else {}
     env = gst_env(tmp)
     env.update(env_extra)
+    env.update(extra_env or {})
     pipeline = ("videotestsrc num-buffers=%d pattern=snow ! video/x-bayer,format=%s,width=%d,height=%d,framerate=30/1 "
                 "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! bayer2rgb %s "
                 "! video/x-raw,format=%s ! filesink location=%s" % (nbuf, order, w, h, inp, props, fmt, outp))
@@ -200,6 +201,34 @@ def test_queued_mode_keeps_order_and_drains_on_eos(plugin, gpu_pkg, oracle, tmp_
     for i in range(n):
         assert np.array_equal(got[i], want[i]), (props, i)
     assert len({md5(f.tobytes()) for f in src}) == n        # snow: every frame differs, so order is checked
+
+
+@pytest.mark.gpu
+@needs_gst
+@pytest.mark.parametrize("props", ["inflight=2 devices=0,0,0,0", "inflight=2 devices=0,0,0,0 pinned-pool=false",
+                                   "inflight=3 devices=0,0 hipgraph=true"])
+def test_a_failed_gpu_is_dropped_and_the_pipeline_carries_on(plugin, gpu_pkg, oracle, tmp_path, props):
+    """SURVEY.md section 5 "a failed device is dropped from the round-robin set", at element level on real hardware:
+    logical shard 1 of the pool reports a device error after three frames (MIBAYER_INJECT_FAULT).  The pipeline reaches
+    EOS, every frame is there, in order, bit-exact (the dead shard's frames were converted again on the others), and
+    the element posted a WARNING -- not an error -- naming the dropped device.  If the last shard goes too, it is an
+    ERROR."""
+    n = 29
+    src, got, err = _tee_pipeline(tmp_path, props, n, debug="3",
+                                  extra_env={"MIBAYER_INJECT_FAULT": "1:3"})
+    want = oracle.bayer2rgb_batch(src, 640, "bggr", 0, 1, 2, nthreads=2)
+    for i in range(n):
+        assert np.array_equal(got[i], want[i]), (props, i)
+    assert "dropped from the rotation" in err and "WARN" in err, err[-1500:]
+    # every shard fails: now the stream errors out
+    ndev = props.split("devices=")[1].split()[0].count(",") + 1
+    faults = ",".join("%d:%d" % (k, 2 + k) for k in range(ndev))
+    env = gst_env(tmp_path)
+    env["MIBAYER_INJECT_FAULT"] = faults
+    res = subprocess.run([GST_LAUNCH, "-q"] + ("videotestsrc num-buffers=40 ! video/x-bayer,format=bggr,width=640,"
+                                               "height=480 ! bayer2rgb %s ! fakesink" % props).split(),
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode != 0 and "GPU conversion failed" in res.stderr + res.stdout
 
 
 @pytest.mark.gpu
