@@ -108,6 +108,7 @@ ABI = {
     "mibayer_pool_inject_fault": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_longlong]),
     "mibayer_process_device": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
                                               ctypes.c_int, _vp]),
+    "mibayer_process_device_list": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int, _vp]),
     "mibayer_ctx_stream": (_vp, [_vp]),
     "mibayer_sync": (ctypes.c_int, [_vp]),
     "mibayer_time_device": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t,
@@ -359,6 +360,13 @@ class Context:
         _check(lib().mibayer_process_device(
             self._h, _vp(d_src), src_frame_bytes or self.src_bytes, _vp(d_dst),
             dst_frame_bytes or self.dst_bytes, nframes, _vp(s)), "mibayer_process_device")
+
+    def process_device_list(self, d_srcs, d_dsts, stream="ctx"):
+        """One launch (per 16 frames) over frames that are separate device allocations."""
+        s = self.stream if stream == "ctx" else (stream or 0)
+        n = len(d_srcs)
+        a, b = (_vp * n)(*d_srcs), (_vp * n)(*d_dsts)
+        _check(lib().mibayer_process_device_list(self._h, a, b, n, _vp(s)), "mibayer_process_device_list")
 
     def sync(self):
         _check(lib().mibayer_sync(self._h), "mibayer_sync")

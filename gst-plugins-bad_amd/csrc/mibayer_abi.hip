@@ -339,6 +339,7 @@ static void fill_params (const mibayer_ctx *c, KParams &p, Geometry &g,
     p.sel[k] = c->sel[k];
   p.swap_rows = c->swap_rows;
   p.start_sleep = c->start_sleep > 0 ? c->start_sleep : 0;      /* auto: plan_launch */
+  p.nlist = 0;
 }
 
 typedef void (*KernelFn) (KParams);
@@ -350,7 +351,7 @@ constexpr int kStartSleepChunk = 24;    /* x s_sleep(1) = 64 clocks each */
 static int plan_launch (const mibayer_ctx *c, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     KParams &p, KernelFn &kern, unsigned &grid, Geometry *geom = nullptr,
-    long long tile_row0 = 0, long long ntile_rows = -1)
+    long long tile_row0 = 0, long long ntile_rows = -1, int pointers_aligned16 = -1)
 {
   Geometry g;
   fill_params (c, p, g, d_src, src_frame_bytes, d_dst, dst_frame_bytes,
@@ -367,10 +368,14 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
   if (g.tile_rows * g.tiles_x > 0x7fffffffLL)
     return MIBAYER_ERR_GEOMETRY;
   const mibayer_cfg &f = c->cfg;
+  /* pointers_aligned16 >= 0: a list launch, whose caller has looked at every
+   * frame pointer itself (frame strides do not apply) */
   const bool fast = (f.width % 16 == 0) && (f.src_stride % 16 == 0)
-      && (f.dst_stride % 16 == 0) && aligned16 (d_src) && aligned16 (d_dst)
-      && (nframes == 1 || (src_frame_bytes % 16 == 0
-              && dst_frame_bytes % 16 == 0));
+      && (f.dst_stride % 16 == 0)
+      && (pointers_aligned16 >= 0 ? pointers_aligned16 != 0
+          : (aligned16 (d_src) && aligned16 (d_dst)
+              && (nframes == 1 || (src_frame_bytes % 16 == 0
+                      && dst_frame_bytes % 16 == 0))));
   kern = fast ? c->var->fast : c->var->generic;
   /* The variant's default band map is dropped for the identity order in two cases
    * (profiles/r01_sweep_narrow_frames.log, r01_sweep_tile_multiple_widths.log):
@@ -1356,6 +1361,62 @@ extern "C" int mibayer_process_device (mibayer_ctx *c, const void *d_src,
   Range r ("mibayer:process_device");
   return launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes,
       (hipStream_t) hip_stream);
+}
+
+/* One launch over frames that are separate device allocations (a GstBuffer
+ * each): hipbayer2rgb's batch mode.  A 4K frame is ~7 us of kernel, about what
+ * a launch costs to issue, so a device-resident pipeline that converts frame by
+ * frame is bound by launch latency (5.8 k fps = 48 Gpix/s, against 1.3 Tpix/s
+ * for one launch over 64 resident frames); a list launch amortises it over up
+ * to kMaxList frames without asking the caller to make them contiguous. */
+extern "C" int mibayer_process_device_list (mibayer_ctx *c,
+    const void *const *d_srcs, void *const *d_dsts, int nframes,
+    void *hip_stream)
+{
+  if (!c || !d_srcs || !d_dsts || nframes < 0)
+    return MIBAYER_ERR_ARG;
+  for (int f = 0; f < nframes; f++)
+    if (!d_srcs[f] || !d_dsts[f] || (((uintptr_t) d_srcs[f]) & 3)
+        || (((uintptr_t) d_dsts[f]) & 3))
+      return MIBAYER_ERR_ARG;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  Range r ("mibayer:process_device_list");
+  if (c->inverse) {             /* no table in the rgb2bayer kernel: frame by frame */
+    for (int f = 0; f < nframes; f++) {
+      const int rc = launch (c, d_srcs[f], c->src_bytes, d_dsts[f],
+          c->dst_bytes, 1, (hipStream_t) hip_stream);
+      if (rc != MIBAYER_OK)
+        return rc;
+    }
+    return MIBAYER_OK;
+  }
+  for (int f0 = 0; f0 < nframes; f0 += kMaxList) {
+    const int n = nframes - f0 < kMaxList ? nframes - f0 : kMaxList;
+    bool all16 = true;
+    for (int f = 0; f < n; f++)
+      all16 = all16 && aligned16 (d_srcs[f0 + f]) && aligned16 (d_dsts[f0 + f]);
+    KParams p;
+    KernelFn kern;
+    unsigned grid;
+    /* planned as a batch of n frames; the 16-byte path needs every pointer aligned */
+    const int rc = plan_launch (c, d_srcs[f0], c->src_bytes, d_dsts[f0],
+        c->dst_bytes, n, p, kern, grid, nullptr, 0, -1, all16 ? 1 : 0);
+    if (rc != MIBAYER_OK)
+      return rc;
+    p.src = nullptr;
+    p.dst = nullptr;
+    p.nlist = n;
+    for (int f = 0; f < n; f++) {
+      p.src_list[f] = (const uint8_t *) d_srcs[f0 + f];
+      p.dst_list[f] = (uint8_t *) d_dsts[f0 + f];
+    }
+    hipLaunchKernelGGL (kern, dim3 (grid), dim3 (c->var->threads), 0,
+        (hipStream_t) hip_stream, p);
+    HIP_TRY (hipGetLastError ());
+  }
+  return MIBAYER_OK;
 }
 
 extern "C" void *mibayer_ctx_stream (mibayer_ctx *c)

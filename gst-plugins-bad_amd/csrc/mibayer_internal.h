@@ -121,6 +121,8 @@ inline TileMap make_tile_map (int tiles_x, int tiles_y, long long tile_rows,
   return m;
 }
 
+constexpr int kMaxList = 16;    /* frames of one list launch (mibayer_process_device_list) */
+
 /* Kernel arguments (passed by value -> SGPRs). */
 struct KParams {
   const uint8_t *src;
@@ -137,7 +139,23 @@ struct KParams {
   int start_sleep;              /* s_sleep(1) iterations before a workgroup's first load */
   uint32_t sel[4];              /* v_perm_b32 selectors of output pixel 0..3   */
   int swap_rows;                /* 1 for grbg / gbrg                           */
+  /* list launch: frame f is read at src_list[f] and written at dst_list[f] (frames that are
+   * separate allocations, e.g. one GstBuffer each) instead of src / dst + f * frame bytes */
+  int nlist;
+  const uint8_t *src_list[kMaxList];
+  uint8_t *dst_list[kMaxList];
 };
+
+/* frame index is wave-uniform: the table look-up is a scalar load from the kernel arguments */
+__device__ __forceinline__ const uint8_t *frame_src (const KParams &p, uint32_t frame)
+{
+  return p.nlist ? p.src_list[frame] : p.src + frame * p.src_frame_bytes;
+}
+
+__device__ __forceinline__ uint8_t *frame_dst (const KParams &p, uint32_t frame)
+{
+  return p.nlist ? p.dst_list[frame] : p.dst + frame * p.dst_frame_bytes;
+}
 
 struct Variant {
   const char *name;

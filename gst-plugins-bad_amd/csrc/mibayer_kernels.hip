@@ -262,8 +262,8 @@ bayer2rgb_lds_kernel (KParams p)
     __builtin_amdgcn_s_sleep (1);
   const uint32_t frame = fastdiv (tile.row, p.map.tiles_y);
   const int ty = (int) (tile.row - frame * p.map.tiles_y.d);
-  const uint8_t *src = p.src + frame * p.src_frame_bytes;
-  uint8_t *dst = p.dst + frame * p.dst_frame_bytes;
+  const uint8_t *src = frame_src (p, frame);
+  uint8_t *dst = frame_dst (p, frame);
   const int tile_x = (int) tile.tx * TW;
   const int tile_y = ty * TR;
   const int tid = threadIdx.x;
@@ -436,8 +436,8 @@ bayer2rgb_direct_kernel (KParams p)
   const uint32_t frame = fastdiv (tile.row, p.map.tiles_y);
   const int ty = (int) (tile.row - frame * p.map.tiles_y.d);
   const int tx = (int) tile.tx;
-  const uint8_t *src = p.src + frame * p.src_frame_bytes;
-  uint8_t *dst = p.dst + frame * p.dst_frame_bytes;
+  const uint8_t *src = frame_src (p, frame);
+  uint8_t *dst = frame_dst (p, frame);
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
   const int lane = tid & 63;
@@ -558,8 +558,8 @@ bayer2rgb_persist_kernel (KParams p)
     const int ty = (int) (id.row - frame * p.map.tiles_y.d);
     const int tx = (int) id.tx;
     Tile t;
-    t.src = p.src + frame * p.src_frame_bytes;
-    t.dst = p.dst + frame * p.dst_frame_bytes;
+    t.src = frame_src (p, frame);
+    t.dst = frame_dst (p, frame);
     t.tile_x = tx * TW;
     t.tile_y = ty * TR;
     return t;

@@ -38,7 +38,8 @@ enum
 {
   PROP_0,
   PROP_DEVICE_ID,
-  PROP_ASYNC
+  PROP_ASYNC,
+  PROP_BATCH
 };
 
 /* bytes of one frame for either media type; same rules as bayer2rgb's
@@ -563,7 +564,19 @@ typedef struct
   gint device_id;
   mibayer_ctx *ctx;
   gint ctx_device;              /* the device the context was created on */
+  /* batch mode (property "batch" > 1): input / output buffer pairs waiting for ONE launch over all of
+   * them, and converted outputs waiting to be handed to the base class one by one */
+  gint batch;
+  GQueue waiting;               /* Hb2rPair* */
+  GQueue ready;                 /* GstBuffer* */
 } GstMiHipBayer2RGB;
+
+typedef struct
+{
+  GstBuffer *in, *out;
+} Hb2rPair;
+
+#define HB2R_MAX_BATCH 16       /* frames of one list launch (mibayer_process_device_list) */
 
 typedef struct
 {
@@ -595,6 +608,8 @@ hb2r_set_property (GObject * object, guint prop_id, const GValue * value,
 {
   if (prop_id == PROP_DEVICE_ID)
     ((GstMiHipBayer2RGB *) object)->device_id = g_value_get_int (value);
+  else if (prop_id == PROP_BATCH)
+    ((GstMiHipBayer2RGB *) object)->batch = g_value_get_int (value);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
 }
@@ -605,13 +620,31 @@ hb2r_get_property (GObject * object, guint prop_id, GValue * value,
 {
   if (prop_id == PROP_DEVICE_ID)
     g_value_set_int (value, ((GstMiHipBayer2RGB *) object)->device_id);
+  else if (prop_id == PROP_BATCH)
+    g_value_set_int (value, ((GstMiHipBayer2RGB *) object)->batch);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
 }
 
 static void
+hb2r_drop_queued (GstMiHipBayer2RGB * self)
+{
+  Hb2rPair *pair;
+  GstBuffer *buf;
+
+  while ((pair = g_queue_pop_head (&self->waiting)) != NULL) {
+    gst_buffer_unref (pair->in);
+    gst_buffer_unref (pair->out);
+    g_free (pair);
+  }
+  while ((buf = g_queue_pop_head (&self->ready)) != NULL)
+    gst_buffer_unref (buf);
+}
+
+static void
 hb2r_finalize (GObject * object)
 {
+  hb2r_drop_queued ((GstMiHipBayer2RGB *) object);
   hb2r_drop_ctx ((GstMiHipBayer2RGB *) object);
   G_OBJECT_CLASS (gst_mi_hip_bayer2rgb_parent_class)->finalize (object);
 }
@@ -740,61 +773,74 @@ hb2r_decide_allocation (GstBaseTransform * trans, GstQuery * query)
       (trans, query);
 }
 
-static GstFlowReturn
-hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
+/* The C ABI takes bare device pointers: a frame that lives on another GPU, or a
+ * buffer smaller than the negotiated frame, would fault on the device.  Maps both
+ * memories for device access (no host wait: the caller orders its launch after
+ * their last-access events). */
+static gboolean
+hb2r_map_pair (GstMiHipBayer2RGB * self, GstBuffer * inbuf, GstBuffer * outbuf,
+    GstMemory ** in_mem, GstMemory ** out_mem, GstMapInfo * in_map,
+    GstMapInfo * out_map)
 {
-  GstMiHipBayer2RGB *self = (GstMiHipBayer2RGB *) trans;
-  GstMemory *in_mem = buffer_hip_memory (inbuf);
-  GstMemory *out_mem = buffer_hip_memory (outbuf);
-  GstMapInfo in_map, out_map;
-  GstFlowReturn ret = GST_FLOW_OK;
-  gpointer stream;
-  int rc;
-
-  if (!in_mem || !out_mem || !self->ctx) {
+  *in_mem = buffer_hip_memory (inbuf);
+  *out_mem = buffer_hip_memory (outbuf);
+  if (!*in_mem || !*out_mem || !self->ctx) {
     GST_ELEMENT_ERROR (self, CORE, NEGOTIATION,
         ("hipbayer2rgb needs HIP device memory on both pads"), (NULL));
-    return GST_FLOW_ERROR;
+    return FALSE;
   }
-  /* the C ABI takes bare device pointers: a frame that lives on another GPU, or
-   * a buffer smaller than the negotiated frame, would fault on the device */
-  if (((GstMiHipMemory *) in_mem)->device != self->ctx_device
-      || ((GstMiHipMemory *) out_mem)->device != self->ctx_device) {
+  if (((GstMiHipMemory *) * in_mem)->device != self->ctx_device
+      || ((GstMiHipMemory *) * out_mem)->device != self->ctx_device) {
     GST_ELEMENT_ERROR (self, CORE, NEGOTIATION,
         ("hipbayer2rgb: buffers live on another GPU than device-id=%d",
             self->ctx_device),
         ("input memory on HIP device %d, output memory on %d; set the same "
             "device-id on hipupload and hipbayer2rgb",
-            ((GstMiHipMemory *) in_mem)->device,
-            ((GstMiHipMemory *) out_mem)->device));
-    return GST_FLOW_ERROR;
+            ((GstMiHipMemory *) * in_mem)->device,
+            ((GstMiHipMemory *) * out_mem)->device));
+    return FALSE;
   }
+  if (!gst_memory_map (*in_mem, in_map,
+          GST_MAP_READ | GST_MAP_HIP | GST_MAP_HIP_ASYNC))
+    return FALSE;
+  if (!gst_memory_map (*out_mem, out_map,
+          GST_MAP_WRITE | GST_MAP_HIP | GST_MAP_HIP_ASYNC)) {
+    gst_memory_unmap (*in_mem, in_map);
+    return FALSE;
+  }
+  if (in_map->size < (gsize) GST_ROUND_UP_4 (self->width) * self->height
+      || out_map->size < (gsize) 4 * self->width * self->height) {
+    GST_ELEMENT_ERROR (self, STREAM, FORMAT,
+        ("hipbayer2rgb: device buffer smaller than a %dx%d frame", self->width,
+            self->height),
+        ("input %" G_GSIZE_FORMAT " bytes (need %" G_GSIZE_FORMAT "), output %"
+            G_GSIZE_FORMAT " bytes (need %" G_GSIZE_FORMAT ")", in_map->size,
+            (gsize) GST_ROUND_UP_4 (self->width) * self->height, out_map->size,
+            (gsize) 4 * self->width * self->height));
+    gst_memory_unmap (*out_mem, out_map);
+    gst_memory_unmap (*in_mem, in_map);
+    return FALSE;
+  }
+  return TRUE;
+}
+
+static GstFlowReturn
+hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
+{
+  GstMiHipBayer2RGB *self = (GstMiHipBayer2RGB *) trans;
+  GstMemory *in_mem, *out_mem;
+  GstMapInfo in_map, out_map;
+  GstFlowReturn ret = GST_FLOW_OK;
+  gpointer stream;
+  int rc;
+
+  if (!hb2r_map_pair (self, inbuf, outbuf, &in_mem, &out_mem, &in_map, &out_map))
+    return GST_FLOW_ERROR;
   /* Stream-ordered, no host round trip: the launch is ordered after whatever
    * was last queued on the two memories, and both are marked with an event
    * after it.  The next user either orders its own stream after that event or
    * -- any plain map, hipdownload, a CPU map -- waits for it on the host. */
   stream = mibayer_ctx_stream (self->ctx);
-  if (!gst_memory_map (in_mem, &in_map,
-          GST_MAP_READ | GST_MAP_HIP | GST_MAP_HIP_ASYNC))
-    return GST_FLOW_ERROR;
-  if (!gst_memory_map (out_mem, &out_map,
-          GST_MAP_WRITE | GST_MAP_HIP | GST_MAP_HIP_ASYNC)) {
-    gst_memory_unmap (in_mem, &in_map);
-    return GST_FLOW_ERROR;
-  }
-  if (in_map.size < (gsize) GST_ROUND_UP_4 (self->width) * self->height
-      || out_map.size < (gsize) 4 * self->width * self->height) {
-    GST_ELEMENT_ERROR (self, STREAM, FORMAT,
-        ("hipbayer2rgb: device buffer smaller than a %dx%d frame", self->width,
-            self->height),
-        ("input %" G_GSIZE_FORMAT " bytes (need %" G_GSIZE_FORMAT "), output %"
-            G_GSIZE_FORMAT " bytes (need %" G_GSIZE_FORMAT ")", in_map.size,
-            (gsize) GST_ROUND_UP_4 (self->width) * self->height, out_map.size,
-            (gsize) 4 * self->width * self->height));
-    gst_memory_unmap (out_mem, &out_map);
-    gst_memory_unmap (in_mem, &in_map);
-    return GST_FLOW_ERROR;
-  }
   if (!gst_mi_hip_memory_order_after ((GstMiHipMemory *) in_mem, stream)
       || !gst_mi_hip_memory_order_after ((GstMiHipMemory *) out_mem, stream)) {
     /* could not order on the device: fall back to waiting on the host */
@@ -820,9 +866,155 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
   return ret;
 }
 
+/* ---- batch mode: one launch over up to `batch` queued frames ------------------ */
+/* A 4K frame is ~7 us of kernel -- about what one launch costs to issue -- so a
+ * device-resident pipeline that converts buffer by buffer is bound by launch
+ * latency, not by HBM.  With batch=N the element parks N input buffers (each
+ * with its output buffer already allocated), converts them with ONE list launch
+ * (mibayer_process_device_list: every frame is its own allocation) and hands
+ * the outputs on in order.  The price is latency: up to N-1 frames wait; events
+ * that must not overtake buffers (caps, segment, gap, EOS) convert and push what
+ * is waiting first, a flush drops it.  Same stream-ordered hand-over as the
+ * frame-by-frame mode: the launch is ordered after every memory's last access
+ * and every memory is marked after it. */
+static GstFlowReturn
+hb2r_convert_waiting (GstMiHipBayer2RGB * self)
+{
+  const void *srcs[HB2R_MAX_BATCH];
+  void *dsts[HB2R_MAX_BATCH];
+  GstMemory *in_mem[HB2R_MAX_BATCH], *out_mem[HB2R_MAX_BATCH];
+  GstMapInfo in_map[HB2R_MAX_BATCH], out_map[HB2R_MAX_BATCH];
+  Hb2rPair *pairs[HB2R_MAX_BATCH];
+  GstFlowReturn ret = GST_FLOW_OK;
+  gpointer stream;
+  gboolean marked = TRUE;
+  guint n = 0, i;
+  int rc;
+
+  while (n < HB2R_MAX_BATCH && !g_queue_is_empty (&self->waiting)) {
+    Hb2rPair *pair = g_queue_pop_head (&self->waiting);
+
+    if (ret == GST_FLOW_OK && hb2r_map_pair (self, pair->in, pair->out,
+            &in_mem[n], &out_mem[n], &in_map[n], &out_map[n])) {
+      pairs[n++] = pair;
+    } else {
+      ret = GST_FLOW_ERROR;
+      gst_buffer_unref (pair->in);
+      gst_buffer_unref (pair->out);
+      g_free (pair);
+    }
+  }
+  if (n == 0)
+    return ret;
+  stream = mibayer_ctx_stream (self->ctx);
+  for (i = 0; i < n; i++) {
+    if (!gst_mi_hip_memory_order_after ((GstMiHipMemory *) in_mem[i], stream)
+        || !gst_mi_hip_memory_order_after ((GstMiHipMemory *) out_mem[i],
+            stream)) {
+      gst_mi_hip_memory_wait ((GstMiHipMemory *) in_mem[i]);
+      gst_mi_hip_memory_wait ((GstMiHipMemory *) out_mem[i]);
+    }
+    srcs[i] = in_map[i].data;
+    dsts[i] = out_map[i].data;
+  }
+  rc = ret == GST_FLOW_OK
+      ? mibayer_process_device_list (self->ctx, srcs, dsts, (int) n, stream)
+      : MIBAYER_OK;
+  for (i = 0; i < n && rc == MIBAYER_OK; i++)
+    marked = gst_mi_hip_memory_mark_access ((GstMiHipMemory *) in_mem[i], stream)
+        && gst_mi_hip_memory_mark_access ((GstMiHipMemory *) out_mem[i], stream)
+        && marked;
+  if (rc == MIBAYER_OK && !marked)
+    rc = mibayer_sync (self->ctx);      /* no event: finish before anyone looks */
+  if (rc != MIBAYER_OK) {
+    GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
+        ("hipbayer2rgb: GPU conversion failed"),
+        ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
+    ret = GST_FLOW_ERROR;
+  }
+  for (i = 0; i < n; i++) {
+    gst_memory_unmap (out_mem[i], &out_map[i]);
+    gst_memory_unmap (in_mem[i], &in_map[i]);
+    gst_buffer_unref (pairs[i]->in);
+    if (ret == GST_FLOW_OK)
+      g_queue_push_tail (&self->ready, pairs[i]->out);
+    else
+      gst_buffer_unref (pairs[i]->out);
+    g_free (pairs[i]);
+  }
+  return ret;
+}
+
+static GstFlowReturn
+hb2r_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
+{
+  GstMiHipBayer2RGB *self = (GstMiHipBayer2RGB *) trans;
+  GstBaseTransformClass *klass = GST_BASE_TRANSFORM_GET_CLASS (trans);
+  GstBuffer *inbuf;
+  GstFlowReturn ret = GST_FLOW_OK;
+
+  if (self->batch <= 1 && g_queue_is_empty (&self->waiting)
+      && g_queue_is_empty (&self->ready))
+    return GST_BASE_TRANSFORM_CLASS (gst_mi_hip_bayer2rgb_parent_class)->generate_output
+        (trans, outbuf);
+
+  *outbuf = NULL;
+  inbuf = trans->queued_buf;
+  trans->queued_buf = NULL;
+  if (inbuf != NULL) {
+    GstBuffer *out = NULL;
+    Hb2rPair *pair;
+
+    ret = klass->prepare_output_buffer (trans, inbuf, &out);
+    if (ret != GST_FLOW_OK || out == NULL) {
+      gst_buffer_unref (inbuf);
+      return ret == GST_FLOW_OK ? GST_FLOW_ERROR : ret;
+    }
+    pair = g_new0 (Hb2rPair, 1);
+    pair->in = inbuf;
+    pair->out = out;
+    g_queue_push_tail (&self->waiting, pair);
+    if ((gint) g_queue_get_length (&self->waiting)
+        >= MIN (MAX (self->batch, 1), HB2R_MAX_BATCH))
+      ret = hb2r_convert_waiting (self);
+  }
+  /* the base class calls again for as long as a buffer comes out */
+  if (ret == GST_FLOW_OK)
+    *outbuf = g_queue_pop_head (&self->ready);
+  return ret;
+}
+
+static gboolean
+hb2r_sink_event (GstBaseTransform * trans, GstEvent * event)
+{
+  GstMiHipBayer2RGB *self = (GstMiHipBayer2RGB *) trans;
+  GstBuffer *buf;
+
+  switch (GST_EVENT_TYPE (event)) {
+    case GST_EVENT_CAPS:
+    case GST_EVENT_SEGMENT:
+    case GST_EVENT_GAP:
+    case GST_EVENT_EOS:
+      /* waiting frames precede the event */
+      while (!g_queue_is_empty (&self->waiting)
+          && hb2r_convert_waiting (self) == GST_FLOW_OK);
+      while ((buf = g_queue_pop_head (&self->ready)) != NULL)
+        gst_pad_push (GST_BASE_TRANSFORM_SRC_PAD (trans), buf);
+      break;
+    case GST_EVENT_FLUSH_STOP:
+      hb2r_drop_queued (self);
+      break;
+    default:
+      break;
+  }
+  return GST_BASE_TRANSFORM_CLASS (gst_mi_hip_bayer2rgb_parent_class)->sink_event
+      (trans, event);
+}
+
 static gboolean
 hb2r_stop (GstBaseTransform * trans)
 {
+  hb2r_drop_queued ((GstMiHipBayer2RGB *) trans);
   hb2r_drop_ctx ((GstMiHipBayer2RGB *) trans);
   return TRUE;
 }
@@ -840,6 +1032,12 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
   g_object_class_install_property (object_class, PROP_DEVICE_ID,
       g_param_spec_int ("device-id", "Device ID", "HIP ordinal of the MI355X",
           0, G_MAXINT, 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (object_class, PROP_BATCH,
+      g_param_spec_int ("batch", "Frames per launch",
+          "Convert this many queued frames with ONE kernel launch (each frame "
+          "stays its own buffer); 1 = a launch per frame, no added latency.  A "
+          "launch per 4K frame costs about as much as the kernel runs",
+          1, HB2R_MAX_BATCH, 1, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   xfer_add_templates (element_class, HB2R_SINK_CAPS, HB2R_SRC_CAPS);
   gst_element_class_set_static_metadata (element_class,
       "Bayer to RGB decoder (HIP device memory)", "Filter/Converter/Video",
@@ -851,6 +1049,8 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
   transform_class->decide_allocation =
       GST_DEBUG_FUNCPTR (hb2r_decide_allocation);
   transform_class->transform = GST_DEBUG_FUNCPTR (hb2r_transform);
+  transform_class->generate_output = GST_DEBUG_FUNCPTR (hb2r_generate_output);
+  transform_class->sink_event = GST_DEBUG_FUNCPTR (hb2r_sink_event);
   transform_class->stop = GST_DEBUG_FUNCPTR (hb2r_stop);
 }
 
@@ -861,6 +1061,9 @@ gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
   self->device_id = 0;
   self->ctx = NULL;
   self->ctx_device = 0;
+  self->batch = 1;
+  g_queue_init (&self->waiting);
+  g_queue_init (&self->ready);
 }
 
 /* ======================================================================== */

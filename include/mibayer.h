@@ -204,6 +204,13 @@ int mibayer_pool_inject_fault (mibayer_pool *pool, int shard,
 int mibayer_process_device (mibayer_ctx *ctx, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     void *hip_stream);
+/* The same for frames that are SEPARATE device allocations (one GstBuffer each):
+ * frame f is read at d_srcs[f] and written at d_dsts[f]; up to 16 frames go into
+ * one kernel launch (more are split).  For device-resident pipelines, where a
+ * launch per 4K frame costs as much as the kernel runs (gst/gstmihipelements.c,
+ * hipbayer2rgb batch=N). */
+int mibayer_process_device_list (mibayer_ctx *ctx, const void *const *d_srcs,
+    void *const *d_dsts, int nframes, void *hip_stream);
 /* the context's compute stream (a hipStream_t), created non-blocking */
 void *mibayer_ctx_stream (mibayer_ctx *ctx);
 /* waits for the context's own streams */

@@ -399,6 +399,19 @@ mibayer_process_device (mibayer_ctx * c, const void *d_src,
   return MIBAYER_OK;
 }
 
+int
+mibayer_process_device_list (mibayer_ctx * c, const void *const *d_srcs, void *const *d_dsts, int nframes,
+    void *hip_stream)
+{
+  int f, rc = MIBAYER_OK;
+
+  if (!c || !d_srcs || !d_dsts || nframes < 0)
+    return MIBAYER_ERR_ARG;
+  for (f = 0; f < nframes && rc == MIBAYER_OK; f++)
+    rc = mibayer_process_device (c, d_srcs[f], 0, d_dsts[f], 0, 1, hip_stream);
+  return rc;
+}
+
 void *
 mibayer_dev_alloc (int device, size_t bytes)
 {

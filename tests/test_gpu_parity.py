@@ -570,6 +570,45 @@ def test_config5_4k_stream_pinned_double_buffered_ring(gpu_pkg, oracle, mechanis
         L.mibayer_host_free(p)
 
 
+def test_list_launch_over_separately_allocated_frames(gpu_pkg, oracle):
+    """mibayer_process_device_list: one launch per 16 frames that are separate device allocations (hipbayer2rgb
+    batch=N).  21 frames (split 16 + 5), every Bayer order; then with one pointer only 4-byte aligned (the generic
+    kernel takes the launch) and for a width that always needs the generic kernel."""
+    for (w, h, n, pat, fmt, misalign) in ((1920, 1080, 21, "rggb", "BGRx", 0), (1920, 1080, 5, "gbrg", "xRGB", 4),
+                                          (642, 50, 7, "grbg", "RGBx", 0), (3840, 2160, 3, "bggr", "xBGR", 0)):
+        stride = (w + 3) & ~3
+        src = oracle.fill_synthetic(w, h, n, seed=63, stride=stride)
+        r, g, b = gpu_pkg.FORMATS[fmt]
+        with gpu_pkg.Context(w, h, pat, fmt) as ctx:
+            d_srcs = [ctx.device_alloc(ctx.src_bytes + 64) for _ in range(n)]
+            d_dsts = [ctx.device_alloc(ctx.dst_bytes + 64) for _ in range(n)]
+            offs = [misalign if f == n // 2 else 0 for f in range(n)]
+            for f in range(n):
+                ctx.to_device(d_srcs[f] + offs[f], src[f])
+            ctx.process_device_list([p + o for p, o in zip(d_srcs, offs)], [p + o for p, o in zip(d_dsts, offs)])
+            ctx.sync()
+            for f in range(n):
+                got = ctx.from_device(d_dsts[f] + offs[f], ctx.dst_bytes).reshape(h, 4 * w)
+                assert np.array_equal(got, oracle.bayer2rgb(src[f], w, pat, r, g, b)), (w, h, pat, f)
+            for p in d_srcs + d_dsts:
+                ctx.device_free(p)
+    # the inverse direction goes frame by frame through the same entry point
+    w, h, n = 640, 480, 3
+    rgb = np.random.default_rng(64).integers(0, 256, (n, h, 4 * w), dtype=np.uint8)
+    with gpu_pkg.Context(w, h, "rggb", (1, 2, 3), flags=gpu_pkg.FLAG_RGB2BAYER) as ctx:
+        d_srcs = [ctx.device_alloc(ctx.src_bytes) for _ in range(n)]
+        d_dsts = [ctx.device_alloc(ctx.dst_bytes) for _ in range(n)]
+        for f in range(n):
+            ctx.to_device(d_srcs[f], rgb[f])
+        ctx.process_device_list(d_srcs, d_dsts)
+        ctx.sync()
+        for f in range(n):
+            got = ctx.from_device(d_dsts[f], ctx.dst_bytes).reshape(h, w)
+            assert np.array_equal(got, oracle.rgb2bayer(rgb[f], w, "rggb", 1, 2, 3)[:, :w])
+        for p in d_srcs + d_dsts:
+            ctx.device_free(p)
+
+
 def test_hipgraph_host_path_with_changing_pointers(gpu_pkg, oracle):
     """Graph mode patches the two host pointers into the instantiated graph per frame: pageable and pinned,
     fresh and recycled pointers must all give the oracle's bytes."""

@@ -298,3 +298,27 @@ def test_asynchronous_upload_keeps_the_host_buffer_until_the_copy_is_done(rig, t
     kv = run(rig, "states", "videotestsrc num-buffers=12 ! video/x-bayer,format=rggb,width=64,height=48 ! %s ! "
              "hipbayer2rgb ! queue ! hipdownload ! fakesink" % upload, 3)
     assert kv["cycles_ok"] == "3"
+
+
+@pytest.mark.parametrize("batch", [2, 4, 16])
+def test_hipbayer2rgb_batch_mode_keeps_order_and_drains(rig, tmp_path, batch):
+    """batch=N parks N buffer pairs and converts them with one list launch: every frame still leaves once and in
+    order, the tail that does not fill a batch is converted at EOS, and a flush drops what is parked."""
+    w, h, n = 258, 37, 14
+    inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
+    frames(n, 260 * h, first=40).tofile(inp)
+    for launch in ("hipupload ! hipbayer2rgb batch=%d ! hipdownload" % batch,
+                   "hipupload async=true ! hipbayer2rgb batch=%d" % batch):
+        kv = run(rig, "convert", launch, B2R % ("gbrg", w, h), inp, 260 * h, outp)
+        assert kv["pushed"] == str(n) and kv["pulled"] == str(n), launch
+        seq, fill = stamps(outp, n, 4 * w * h)
+        assert fill == list(range(40, 40 + n)) and seq == list(range(n)), launch
+    kv = run(rig, "flush", "hipupload ! hipbayer2rgb batch=%d ! hipdownload" % batch, B2R % ("gbrg", w, h), inp,
+             260 * h, outp, 3)
+    dropped = 3 % batch if batch <= 3 else 3        # what was parked when the flush came
+    assert kv["pulled"] == str(n - dropped)
+    _, fill = stamps(outp, n - dropped, 4 * w * h)
+    assert fill == [40 + i for i in range(n) if not (3 - dropped <= i < 3)]
+    kv = run(rig, "states", "videotestsrc num-buffers=11 ! video/x-bayer,format=rggb,width=64,height=48 ! hipupload ! "
+             "hipbayer2rgb batch=%d ! queue ! hipdownload ! fakesink" % batch, 2)
+    assert kv["cycles_ok"] == "2"

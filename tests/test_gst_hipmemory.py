@@ -49,6 +49,26 @@ def test_upload_convert_download_pipeline(plugin, gpu_pkg, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("elements", ["hipupload async=true ! hipbayer2rgb", "hipupload ! hipbayer2rgb batch=4",
+                                      "hipupload async=true ! hipbayer2rgb batch=16 ! queue"])
+def test_async_upload_and_batched_conversion_are_bit_exact(plugin, gpu_pkg, oracle, tmp_path, elements):
+    """The asynchronous uploader (host buffers released when their DMA has finished) and the batched converter (one
+    list launch over N separately allocated frames; 23 frames = full batches plus a tail converted at EOS), alone and
+    together, with every device memory recycled several times: same frames, same order, same bytes."""
+    w, h, n = 1280, 720, 23
+    inp, outp = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
+    res = launch(tmp_path,
+                 "videotestsrc num-buffers=%d pattern=snow ! video/x-bayer,format=grbg,width=%d,height=%d,framerate=30/1 "
+                 "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! %s "
+                 "! hipdownload ! video/x-raw,format=xBGR ! filesink location=%s" % (n, w, h, inp, elements, outp))
+    assert res.returncode == 0, res.stderr[-2000:]
+    src = np.fromfile(inp, np.uint8).reshape(n, h, w)
+    got = np.fromfile(outp, np.uint8).reshape(n, h, 4 * w)
+    want = oracle.bayer2rgb_batch(src, w, "grbg", 3, 2, 1, nthreads=4)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
 def test_stream_ordered_handover_survives_buffer_recycling(plugin, gpu_pkg, oracle, tmp_path):
     """hipbayer2rgb does not wait for its kernel: it marks both memories with a "last access" event.  With 24 frames
     through pools of a few buffers, a `queue` between the elements (the converter runs ahead of the downloader) and

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""What hipbayer2rgb batch=N buys: 64 device-resident 4K frames, each its own allocation, converted
+  (a) with one launch per frame (hipbayer2rgb batch=1),  (b) with list launches of 2 / 4 / 8 / 16 frames
+  (mibayer_process_device_list),  (c) for reference, as one contiguous 64-frame batch (mibayer_process_device).
+HIP events on the context's compute stream.   Usage (GPU box): python tools/list_launch_bench.py"""
+import ctypes
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+pkg = entry.load_package()
+L = pkg.lib()
+W, H, N, REPS = 3840, 2160, 64, 20
+vp = ctypes.c_void_p
+with pkg.Context(W, H, "rggb", "BGRx") as ctx:
+    srcs = [ctx.device_alloc(ctx.src_bytes) for _ in range(N)]
+    dsts = [ctx.device_alloc(ctx.dst_bytes) for _ in range(N)]
+    for p in srcs:
+        ctx.fill_synthetic(p, 1, seed=2)
+    big_src, big_dst = ctx.device_alloc(N * ctx.src_bytes), ctx.device_alloc(N * ctx.dst_bytes)
+    ctx.fill_synthetic(big_src, N, seed=2)
+    ctx.sync()
+    ev0, ev1 = L.mibayer_dev_event_create(0), L.mibayer_dev_event_create(0)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(REPS):
+            fn()
+        ctx.sync()
+        return (time.perf_counter() - t0) / REPS
+
+    def per_frame():
+        for s, d in zip(srcs, dsts):
+            ctx.process_device(s, d, 1)
+
+    def lists(k):
+        def fn():
+            for i in range(0, N, k):
+                ctx.process_device_list(srcs[i:i + k], dsts[i:i + k])
+        return fn
+
+    print("# 64 device-resident 4K frames per pass, wall time per pass incl. launch issue (python ctypes caller), %d passes" % REPS)
+    for label, fn in [("one launch per frame (batch=1)", per_frame)] + \
+                     [("list launches of %2d separately allocated frames" % k, lists(k)) for k in (2, 4, 8, 16)] + \
+                     [("one launch over a contiguous 64-frame batch", lambda: ctx.process_device(big_src, big_dst, N))]:
+        t = timed(fn)
+        print("%-56s %8.3f ms  %8.1f fps  %9.1f Mpix/s  %6.1f GB/s (%4.1f %% of 8 TB/s)" % (
+            label, t * 1e3, N / t, N * W * H / t / 1e6, 5.0 * N * W * H / t / 1e9, 5.0 * N * W * H / t / 1e9 / 80), flush=True)
