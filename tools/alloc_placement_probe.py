@@ -17,6 +17,9 @@ import __graft_entry__ as entry  # noqa: E402
 pkg = entry.load_package()
 W, H, N = 3840, 2160, 64
 NPAIRS = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+# "frag": before the pairs are allocated, 96 x 256 MiB of junk are allocated and every other block is freed again, so
+# the pairs are assembled from holes all over the 288 GB instead of one fresh run of physical pages
+FRAG = len(sys.argv) > 2 and sys.argv[2] == "frag"
 PLANS = [("4x2/band1", 1, "1"), ("4x2/chunk", 1, "-1"), ("1x8/chunk", 3, "-1"), ("1x8/identity", 3, "0")]
 ctxs = {}
 for name, variant, band in PLANS:
@@ -25,6 +28,11 @@ for name, variant, band in PLANS:
 del os.environ["MIBAYER_XCD_BAND"]
 c0 = ctxs[PLANS[0][0]]
 SHIFT = 64 << 20            # room to slide the destination inside its allocation
+if FRAG:
+    junk = [c0.device_alloc(256 << 20) for _ in range(96)]
+    for j in junk[1::2]:
+        c0.device_free(j)
+    print("# fragmented first: 96 x 256 MiB allocated, every other block freed")
 pairs = []
 for k in range(NPAIRS):
     d_src = c0.device_alloc(N * c0.src_bytes)
