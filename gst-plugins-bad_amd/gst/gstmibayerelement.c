@@ -812,9 +812,15 @@ element_generate_output (GstBaseTransform * base, GstBuffer ** outbuf)
   /* the base class calls again for as long as a buffer comes out */
   g_mutex_lock (&self->flow_lock);
   *outbuf = g_queue_pop_head (&self->ready);
-  if (*outbuf == NULL && self->capacity > 0
-      && (gint) g_queue_get_length (&self->pending) >= self->capacity)
+  /* The first frame after a start or a flush is not held back: sinks preroll on
+   * it, and holding it until the pool is full can deadlock against upstream
+   * queues that fill up while another branch's sink sits prerolled. */
+  if (*outbuf == NULL && !g_queue_is_empty (&self->pending)
+      && (!self->prerolled || (self->capacity > 0
+              && (gint) g_queue_get_length (&self->pending) >= self->capacity)))
     ret = element_collect_locked (self, outbuf, &owned, &rc);
+  if (*outbuf != NULL)
+    self->prerolled = TRUE;
   g_mutex_unlock (&self->flow_lock);
   element_post_notes (self);
   if (rc != MIBAYER_OK)
@@ -847,6 +853,7 @@ element_sink_event (GstBaseTransform * base, GstEvent * event)
       /* serialised: whatever the streaming thread still managed to queue */
       element_drain (self, FALSE);
       g_atomic_int_set (&self->flushing, 0);
+      self->prerolled = FALSE;
       break;
     default:
       break;
@@ -903,6 +910,7 @@ element_start (GstBaseTransform * base)
   self->act.pinned_pool = self->pinned_pool;
   GST_OBJECT_UNLOCK (self);
   g_atomic_int_set (&self->flushing, 0);
+  self->prerolled = FALSE;
   return TRUE;
 }
 
@@ -996,6 +1004,7 @@ gst_mi_bayer_element_instance_setup (GstMiBayerElement * self)
   self->pool_stride = 0;
   self->capacity = 0;
   self->flushing = 0;
+  self->prerolled = FALSE;
   self->failure_note = NULL;
   g_mutex_init (&self->flow_lock);
   g_queue_init (&self->pending);

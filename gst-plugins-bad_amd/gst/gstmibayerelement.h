@@ -67,6 +67,7 @@ struct _GstMiBayerElement
   GMutex flow_lock;             /* pool / pending / ready: the streaming thread vs. FLUSH_START, which
                                    arrives on another thread */
   volatile gint flushing;       /* between FLUSH_START and FLUSH_STOP: nothing is submitted or pushed */
+  gboolean prerolled;           /* a frame has left since start / flush; the first one is never held back */
   gchar *failure_note;          /* a device was dropped: posted as ONE element warning (flow_lock) */
 };
 

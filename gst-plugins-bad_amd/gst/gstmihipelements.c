@@ -567,6 +567,7 @@ typedef struct
   /* batch mode (property "batch" > 1): input / output buffer pairs waiting for ONE launch over all of
    * them, and converted outputs waiting to be handed to the base class one by one */
   gint batch;
+  gboolean prerolled;           /* a frame has left since start / flush: batching may begin */
   GQueue waiting;               /* Hb2rPair* */
   GQueue ready;                 /* GstBuffer* */
 } GstMiHipBayer2RGB;
@@ -974,13 +975,20 @@ hb2r_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
     pair->in = inbuf;
     pair->out = out;
     g_queue_push_tail (&self->waiting, pair);
+    /* The first frame after a start or a flush goes out alone: sinks preroll on
+     * it, and a pipeline does not reach PLAYING before they have -- parking it
+     * until N-1 more arrive can deadlock against upstream queues that fill up
+     * while another branch's sink sits prerolled (tee ! queue ! ...). */
     if ((gint) g_queue_get_length (&self->waiting)
-        >= MIN (MAX (self->batch, 1), HB2R_MAX_BATCH))
+        >= (self->prerolled ? MIN (MAX (self->batch, 1), HB2R_MAX_BATCH) : 1))
       ret = hb2r_convert_waiting (self);
   }
   /* the base class calls again for as long as a buffer comes out */
-  if (ret == GST_FLOW_OK)
+  if (ret == GST_FLOW_OK) {
     *outbuf = g_queue_pop_head (&self->ready);
+    if (*outbuf != NULL)
+      self->prerolled = TRUE;
+  }
   return ret;
 }
 
@@ -1003,6 +1011,7 @@ hb2r_sink_event (GstBaseTransform * trans, GstEvent * event)
       break;
     case GST_EVENT_FLUSH_STOP:
       hb2r_drop_queued (self);
+      self->prerolled = FALSE;
       break;
     default:
       break;
@@ -1016,6 +1025,7 @@ hb2r_stop (GstBaseTransform * trans)
 {
   hb2r_drop_queued ((GstMiHipBayer2RGB *) trans);
   hb2r_drop_ctx ((GstMiHipBayer2RGB *) trans);
+  ((GstMiHipBayer2RGB *) trans)->prerolled = FALSE;
   return TRUE;
 }
 
@@ -1036,7 +1046,8 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
       g_param_spec_int ("batch", "Frames per launch",
           "Convert this many queued frames with ONE kernel launch (each frame "
           "stays its own buffer); 1 = a launch per frame, no added latency.  A "
-          "launch per 4K frame costs about as much as the kernel runs",
+          "launch per 4K frame costs about as much as the kernel runs.  The "
+          "first frame after a start or flush is never held back (preroll)",
           1, HB2R_MAX_BATCH, 1, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   xfer_add_templates (element_class, HB2R_SINK_CAPS, HB2R_SRC_CAPS);
   gst_element_class_set_static_metadata (element_class,
@@ -1062,6 +1073,7 @@ gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
   self->ctx = NULL;
   self->ctx_device = 0;
   self->batch = 1;
+  self->prerolled = FALSE;
   g_queue_init (&self->waiting);
   g_queue_init (&self->ready);
 }

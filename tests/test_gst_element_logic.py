@@ -121,12 +121,12 @@ def test_flush_drops_exactly_the_frames_in_flight(rig, tmp_path):
     inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
     frames(n, w * h).tofile(inp)
     kv = run(rig, "flush", "bayer2rgb inflight=4", B2R % ("bggr", w, h), inp, w * h, outp, 3)
-    assert kv["before_flush_pulled"] == "0"           # capacity 4: nothing had come out after 3 buffers
+    assert kv["before_flush_pulled"] == "0"           # frame 0 left right after its push (preroll); 1 and 2 are held
     assert kv["released_at_flush_start"] == "1"       # dropped at FLUSH_START already, not only at FLUSH_STOP
-    assert kv["pushed"] == str(n) and kv["pulled"] == str(n - 3)
-    seq, fill = stamps(outp, n - 3, 4 * w * h)
-    assert fill == list(range(3, n))                  # frames 0..2 were dropped, nothing else
-    assert seq == list(range(3, n))                   # same GPU pool before and after the flush
+    assert kv["pushed"] == str(n) and kv["pulled"] == str(n - 2)
+    seq, fill = stamps(outp, n - 2, 4 * w * h)
+    assert fill == [0] + list(range(3, n))            # frames 1 and 2 were dropped, nothing else
+    assert seq == [0] + list(range(3, n))             # same GPU pool before and after the flush
 
 
 @pytest.mark.parametrize("launch", ["bayer2rgb", "bayer2rgb inflight=3"])
@@ -315,7 +315,7 @@ def test_hipbayer2rgb_batch_mode_keeps_order_and_drains(rig, tmp_path, batch):
         assert fill == list(range(40, 40 + n)) and seq == list(range(n)), launch
     kv = run(rig, "flush", "hipupload ! hipbayer2rgb batch=%d ! hipdownload" % batch, B2R % ("gbrg", w, h), inp,
              260 * h, outp, 3)
-    dropped = 3 % batch if batch <= 3 else 3        # what was parked when the flush came
+    dropped = 2 % batch     # parked when the flush came: frame 0 left alone (preroll), frames 1-2 filled a batch or not
     assert kv["pulled"] == str(n - dropped)
     _, fill = stamps(outp, n - dropped, 4 * w * h)
     assert fill == [40 + i for i in range(n) if not (3 - dropped <= i < 3)]

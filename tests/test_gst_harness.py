@@ -74,18 +74,19 @@ def test_harness_caps_change_mid_stream(plugin, gpu_pkg, oracle, harness, tmp_pa
 
 
 def test_harness_flush_drops_frames_in_flight(plugin, gpu_pkg, oracle, harness, tmp_path):
-    """Queued mode, capacity 4: after 3 buffers nothing has come out; FLUSH_START/STOP must drop those 3;
-    the 5 buffers pushed afterwards all come out (the last ones at EOS), and nothing else."""
+    """Queued mode, capacity 4: the first buffer leaves at once (sinks preroll on it), the next two are held;
+    FLUSH_START/STOP must drop exactly those two; after the flush the first buffer again leaves at once and the
+    rest come out as the pool fills / at EOS, and nothing else."""
     w, h, n = 64, 48, 8
     src = oracle.fill_synthetic(w, h, n, seed=72)
     inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
     src.tofile(inp)
     kv = run(harness, tmp_path, "flush", "bayer2rgb inflight=4", CAPS % ("bggr", w, h), inp, w * h, outp, 3)
-    assert kv["before_flush_pulled"] == "0"
-    assert kv["pushed"] == "8" and kv["pulled"] == "5"
-    got = np.fromfile(outp, np.uint8).reshape(5, h, 4 * w)
-    for i in range(5):
-        assert np.array_equal(got[i], oracle.bayer2rgb(src[3 + i], w, "bggr", 0, 1, 2)), i
+    assert kv["before_flush_pulled"] == "0"           # frame 0 had already been pulled right after its push
+    assert kv["pushed"] == "8" and kv["pulled"] == "6"
+    got = np.fromfile(outp, np.uint8).reshape(6, h, 4 * w)
+    for k, i in enumerate([0, 3, 4, 5, 6, 7]):
+        assert np.array_equal(got[k], oracle.bayer2rgb(src[i], w, "bggr", 0, 1, 2)), i
 
 
 def test_state_cycles_one_pipeline_instance(plugin, gpu_pkg, harness, tmp_path):
