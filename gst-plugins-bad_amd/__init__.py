@@ -174,7 +174,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.mibayer_abi_version() != 1:
+        if L.mibayer_abi_version() != 2:
             raise MibayerErrorNoLib("libmibayer.so ABI version mismatch")
         _lib = L
     return _lib

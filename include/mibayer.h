@@ -37,7 +37,12 @@
 extern "C" {
 #endif
 
-#define MIBAYER_ABI_VERSION 1
+/* 2: additive over 1 -- pool failover / fault injection / helper threads,
+ * mibayer_process_device_list, mibayer_host_alloc_near + NUMA queries,
+ * mibayer_dev_stream_* / mibayer_dev_upload_async / mibayer_dev_event_query;
+ * MIBAYER_FLAG_HIPGRAPH now captures the compute-queue segment of a frame.
+ * Every v1 entry point keeps its signature and meaning. */
+#define MIBAYER_ABI_VERSION 2
 
 /* Bayer order; numbering identical to the reference's anonymous enum
  * GST_BAYER_2_RGB_FORMAT_*, gstbayer2rgb.c:95-101. */
