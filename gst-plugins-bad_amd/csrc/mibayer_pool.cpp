@@ -108,7 +108,8 @@ bool device_failure (int rc)
 void helper_give_up (Shard *sh, const char *why)
 {
   sh->broken = true;
-  snprintf (sh->errmsg, sizeof sh->errmsg, "%s", why ? why : "");
+  if (why != sh->errmsg)
+    snprintf (sh->errmsg, sizeof sh->errmsg, "%s", why ? why : "");
   for (Frame *f : sh->ring)
     f->state = F_REDO;
   sh->ring.clear ();
@@ -214,10 +215,11 @@ static void kill_shard (mibayer_pool *pool, int idx, int rc, const char *why)
   if (!sh->alive)
     return;
   sh->alive = false;
+  char reason[200];
   {
     std::lock_guard<std::mutex> lk (sh->mu);
-    if (!why || !why[0])
-      why = sh->errmsg;
+    snprintf (reason, sizeof reason, "%s", (why && why[0]) ? why : sh->errmsg);
+    why = reason;
     sh->broken = true;
     for (Frame *f : sh->ring)
       f->state = F_REDO;
