@@ -122,6 +122,7 @@ ABI = {
     "mibayer_host_alloc_near": (_vp, [ctypes.c_int, ctypes.c_size_t]),
     "mibayer_device_numa_node": (ctypes.c_int, [ctypes.c_int]),
     "mibayer_host_numa_node": (ctypes.c_int, [_vp]),
+    "mibayer_host_is_pinned": (ctypes.c_int, [_vp]),
     "mibayer_device_alloc": (_vp, [_vp, ctypes.c_size_t]),
     "mibayer_device_free": (None, [_vp, _vp]),
     "mibayer_copy_to_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),

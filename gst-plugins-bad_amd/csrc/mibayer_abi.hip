@@ -1324,6 +1324,19 @@ extern "C" int mibayer_internal_is_pageable (const void *p)
   return attr.type == hipMemoryTypeUnregistered ? 1 : 0;
 }
 
+extern "C" int mibayer_host_is_pinned (const void *p)
+{
+  if (!p || device_count_cached () <= 0)
+    return 0;
+  hipPointerAttribute_t attr;
+  memset (&attr, 0, sizeof attr);
+  if (hipPointerGetAttributes (&attr, p) != hipSuccess) {
+    (void) hipGetLastError ();
+    return 0;
+  }
+  return attr.type == hipMemoryTypeHost ? 1 : 0;
+}
+
 extern "C" void mibayer_internal_abandon (mibayer_ctx *c)
 {
   if (!c)

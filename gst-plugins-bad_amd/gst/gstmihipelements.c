@@ -240,6 +240,15 @@ xfer_upload_async (GstMiHipXfer * self, GstBuffer * inbuf, GstMemory * dev_mem)
     g_free (p);
     return FALSE;
   }
+  /* From pageable memory (a source that ignored the proposed pinned pool, e.g.
+   * fakesrc, filesrc) hipMemcpyAsync blocks for the whole copy anyway -- 159 us per
+   * 4K mosaic in the HIP API trace, profiles/r02_async_upload_hip_api_trace.log --
+   * and the deferred release only adds calls: take the plain blocking copy. */
+  if (!mibayer_host_is_pinned (p->map.data)) {
+    gst_buffer_unmap (inbuf, &p->map);
+    g_free (p);
+    return FALSE;
+  }
   if (!gst_memory_map (dev_mem, &dev_map,
           GST_MAP_WRITE | GST_MAP_HIP | GST_MAP_HIP_ASYNC)) {
     gst_buffer_unmap (inbuf, &p->map);
@@ -423,8 +432,7 @@ xfer_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
   if (to_device && self->async) {
     if (xfer_upload_async (self, inbuf, dev_mem))
       return GST_FLOW_OK;
-    GST_WARNING_OBJECT (self, "asynchronous upload unavailable (%s): "
-        "copying synchronously", mibayer_last_hip_error ());
+    GST_LOG_OBJECT (self, "pageable input or no copy queue: blocking copy");
   }
   if (!gst_buffer_map (host_buf, &host_map,
           to_device ? GST_MAP_READ : GST_MAP_WRITE))

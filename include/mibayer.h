@@ -256,6 +256,10 @@ void mibayer_host_free (void *p);
  * feeds GPU k should not sit behind the socket link.  Falls back to
  * mibayer_host_alloc() when the node is unknown.  Free with mibayer_host_free(). */
 void *mibayer_host_alloc_near (int device, size_t bytes);
+/* 1 when p points into pinned / registered host memory (an asynchronous copy
+ * from / to it really is asynchronous), 0 for ordinary pageable memory, where
+ * hipMemcpyAsync blocks the caller while the runtime stages the data */
+int mibayer_host_is_pinned (const void *p);
 /* NUMA node next to a device (-1 = unknown) / holding the first page of p */
 int mibayer_device_numa_node (int device);
 int mibayer_host_numa_node (const void *p);

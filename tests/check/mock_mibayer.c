@@ -90,6 +90,15 @@ mibayer_host_alloc_near (int device, size_t bytes)
   return mibayer_host_alloc (bytes);
 }
 
+/* MOCK_MIBAYER_PAGEABLE=1 makes every host buffer count as pageable */
+int
+mibayer_host_is_pinned (const void *p)
+{
+  const char *e = getenv ("MOCK_MIBAYER_PAGEABLE");
+
+  return p != NULL && !(e && atoi (e) != 0);
+}
+
 void
 mibayer_host_free (void *p)
 {
