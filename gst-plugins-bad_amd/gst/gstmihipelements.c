@@ -476,9 +476,9 @@ gst_mi_hip_xfer_class_init (GstMiHipXferClass * klass)
           "hipupload: queue the host-to-device copy and return; the host buffer "
           "is released when the copy has completed, downstream GPU work is "
           "ordered after it; lets upstream fill the next frame while this one "
-          "crosses PCIe, at the price of a few more calls per frame -- off by "
-          "default: with a producer that is never the bottleneck the blocking "
-          "copy measured faster (no effect on hipdownload)", FALSE,
+          "crosses PCIe.  Applies to pinned input (the pool this element "
+          "proposes upstream); input in pageable memory is copied blocking, as "
+          "the runtime would do anyway (no effect on hipdownload)", TRUE,
           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   transform_class->sink_event = GST_DEBUG_FUNCPTR (xfer_sink_event);
   transform_class->stop = GST_DEBUG_FUNCPTR (xfer_stop);
@@ -496,7 +496,7 @@ static void
 gst_mi_hip_xfer_init (GstMiHipXfer * self)
 {
   self->device_id = 0;
-  self->async = FALSE;
+  self->async = TRUE;
   self->stream = NULL;
   self->stream_device = 0;
   g_queue_init (&self->pending);

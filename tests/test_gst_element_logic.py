@@ -281,7 +281,7 @@ def test_both_plugins_in_one_process_keep_their_pinned_pools(rig):
         assert kv["cycles_ok"] == "2"
 
 
-@pytest.mark.parametrize("upload", ["hipupload async=true", "hipupload"])
+@pytest.mark.parametrize("upload", ["hipupload", "hipupload async=false"])
 def test_asynchronous_upload_keeps_the_host_buffer_until_the_copy_is_done(rig, tmp_path, upload):
     """hipupload queues its DMA and returns: the double executes an asynchronous copy only when something ordered after
     it completes, and reads the HOST buffer at that moment -- an input buffer handed back before its copy was done is
