@@ -830,10 +830,14 @@ rgb2bayer_kernel (R2BParams p)
  * and with PX == 8 a lane owns 32 contiguous input bytes and stores 8 bytes
  * (512 B per wave-store instead of 256).  Items are decoded with two
  * multiply-shift divisions (row = item / dwords-per-row, frame = row / height). */
-template <int K, int PX, int LD, bool VEC16>
+/* VEC = bytes per load instruction the source rows allow: 16 (width % 4 == 0 and
+ * 16-byte aligned rows), 8 (even widths: rows are 8-byte aligned, two 8-byte loads
+ * per full item) or 4 (anything else, and the partial last item of a row) */
+template <int K, int PX, int LD, int VEC>
 __global__ void __launch_bounds__ (256)
 rgb2bayer_flat_kernel (R2BParams p)
 {
+  constexpr bool VEC16 = VEC == 16;
   constexpr int IPG = PX / 4;           /* items per group */
   const TileId tile = block_to_tile (blockIdx.x, p.map);       /* tiles_x == 1: .row = logical block */
   if (!tile.valid)
@@ -873,10 +877,25 @@ rgb2bayer_flat_kernel (R2BParams p)
         } else {
           const uint32_t *q = (const uint32_t *) s + 4 * h;
           const int x0 = (int) (xd + h) * 4;
-          if (x0 + 0 < p.width) px[k][h].x = q[0];
-          if (x0 + 1 < p.width) px[k][h].y = q[1];
-          if (x0 + 2 < p.width) px[k][h].z = q[2];
-          if (x0 + 3 < p.width) px[k][h].w = q[3];
+          if (VEC == 8 && x0 + 3 < p.width) {
+            u32x2 a, b;
+            if constexpr (LD == 1) {
+              a = __builtin_nontemporal_load ((const u32x2 *) q);
+              b = __builtin_nontemporal_load ((const u32x2 *) q + 1);
+            } else {
+              a = ((const u32x2 *) q)[0];
+              b = ((const u32x2 *) q)[1];
+            }
+            px[k][h].x = a.x;
+            px[k][h].y = a.y;
+            px[k][h].z = b.x;
+            px[k][h].w = b.y;
+          } else {
+            if (x0 + 0 < p.width) px[k][h].x = q[0];
+            if (x0 + 1 < p.width) px[k][h].y = q[1];
+            if (x0 + 2 < p.width) px[k][h].z = q[2];
+            if (x0 + 3 < p.width) px[k][h].w = q[3];
+          }
         }
       }
     }
@@ -910,10 +929,10 @@ rgb2bayer_flat_kernel (R2BParams p)
 
 typedef void (*R2BFn) (R2BParams);
 
-template <bool VEC16>
+template <int VEC>
 static R2BFn flat_kernel_for (int k, int px, int ld)
 {
-#define R2B_FLAT(K, PX, LD) if (k == K && px == PX && ld == LD) return rgb2bayer_flat_kernel<K, PX, LD, VEC16>
+#define R2B_FLAT(K, PX, LD) if (k == K && px == PX && ld == LD) return rgb2bayer_flat_kernel<K, PX, LD, VEC>
   R2B_FLAT (1, 4, 0); R2B_FLAT (1, 4, 1); R2B_FLAT (1, 8, 0); R2B_FLAT (1, 8, 1);
   R2B_FLAT (2, 4, 0); R2B_FLAT (2, 4, 1); R2B_FLAT (2, 8, 0); R2B_FLAT (2, 8, 1);
   R2B_FLAT (3, 4, 0); R2B_FLAT (3, 4, 1); R2B_FLAT (3, 8, 0); R2B_FLAT (3, 8, 1);
@@ -953,8 +972,12 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
     if (px == 8 && ((p.out_dwords & 1) || (p.dst_stride & 7) || (p.dst_frame_bytes & 7)
             || !aligned_to (p.dst, 8) || !vec16))
       px = 4;
-    R2BFn fn = vec16 ? flat_kernel_for<true> (q.flat_k, px, q.flat_ld ? 1 : 0)
-        : flat_kernel_for<false> (q.flat_k, px, q.flat_ld ? 1 : 0);
+    /* even widths: rows of 4*W bytes are 8-byte aligned when the frames are */
+    const bool vec8 = !vec16 && (p.src_stride % 8 == 0) && aligned_to (p.src, 8)
+        && (p.src_frame_bytes % 8 == 0);
+    R2BFn fn = vec16 ? flat_kernel_for<16> (q.flat_k, px, q.flat_ld ? 1 : 0)
+        : vec8 ? flat_kernel_for<8> (q.flat_k, px, q.flat_ld ? 1 : 0)
+        : flat_kernel_for<4> (q.flat_k, px, q.flat_ld ? 1 : 0);
     if (fn) {
       q.item0 = (uint32_t) (row0 * p.out_dwords);
       q.item_end = (uint32_t) item_end;
