@@ -830,9 +830,10 @@ rgb2bayer_kernel (R2BParams p)
  * and with PX == 8 a lane owns 32 contiguous input bytes and stores 8 bytes
  * (512 B per wave-store instead of 256).  Items are decoded with two
  * multiply-shift divisions (row = item / dwords-per-row, frame = row / height). */
-/* VEC = bytes per load instruction the source rows allow: 16 (width % 4 == 0 and
- * 16-byte aligned rows), 8 (even widths: rows are 8-byte aligned, two 8-byte loads
- * per full item) or 4 (anything else, and the partial last item of a row) */
+/* VEC = 16: width % 4 == 0 and 16-byte aligned frames -- every item is full and loaded
+ * unconditionally.  VEC = 4: any other geometry -- full items still take one 16-byte load (at
+ * dword alignment, which is all a gfx950 global load needs), the partial last item of a row is
+ * read dword by dword */
 template <int K, int PX, int LD, int VEC>
 __global__ void __launch_bounds__ (256)
 rgb2bayer_flat_kernel (R2BParams p)
@@ -877,19 +878,14 @@ rgb2bayer_flat_kernel (R2BParams p)
         } else {
           const uint32_t *q = (const uint32_t *) s + 4 * h;
           const int x0 = (int) (xd + h) * 4;
-          if (VEC == 8 && x0 + 3 < p.width) {
-            u32x2 a, b;
-            if constexpr (LD == 1) {
-              a = __builtin_nontemporal_load ((const u32x2 *) q);
-              b = __builtin_nontemporal_load ((const u32x2 *) q + 1);
-            } else {
-              a = ((const u32x2 *) q)[0];
-              b = ((const u32x2 *) q)[1];
-            }
-            px[k][h].x = a.x;
-            px[k][h].y = a.y;
-            px[k][h].z = b.x;
-            px[k][h].w = b.y;
+          if (x0 + 3 < p.width) {
+            /* a full item: one 16-byte load at the alignment the rows have (gfx950 global
+             * loads need no more than dword alignment) */
+            typedef uint32_t u32x4_a4 __attribute__ ((ext_vector_type (4), aligned (4)));
+            if constexpr (LD == 1)
+              px[k][h] = __builtin_nontemporal_load ((const u32x4_a4 *) q);
+            else
+              px[k][h] = *(const u32x4_a4 *) q;
           } else {
             if (x0 + 0 < p.width) px[k][h].x = q[0];
             if (x0 + 1 < p.width) px[k][h].y = q[1];
@@ -972,11 +968,7 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
     if (px == 8 && ((p.out_dwords & 1) || (p.dst_stride & 7) || (p.dst_frame_bytes & 7)
             || !aligned_to (p.dst, 8) || !vec16))
       px = 4;
-    /* even widths: rows of 4*W bytes are 8-byte aligned when the frames are */
-    const bool vec8 = !vec16 && (p.src_stride % 8 == 0) && aligned_to (p.src, 8)
-        && (p.src_frame_bytes % 8 == 0);
     R2BFn fn = vec16 ? flat_kernel_for<16> (q.flat_k, px, q.flat_ld ? 1 : 0)
-        : vec8 ? flat_kernel_for<8> (q.flat_k, px, q.flat_ld ? 1 : 0)
         : flat_kernel_for<4> (q.flat_k, px, q.flat_ld ? 1 : 0);
     if (fn) {
       q.item0 = (uint32_t) (row0 * p.out_dwords);
