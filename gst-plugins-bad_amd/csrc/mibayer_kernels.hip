@@ -45,6 +45,11 @@ namespace mibayer {
 
 typedef uint32_t u32x4 __attribute__ ((ext_vector_type (4)));
 typedef uint32_t u32x2 __attribute__ ((ext_vector_type (2)));
+/* the same at dword alignment: all a gfx950 global load / store needs.  The generic paths (rows
+ * that are not 16-byte aligned: width % 16 != 0, padded strides, odd pointers) move 16 bytes per
+ * instruction through these instead of dword by dword */
+typedef uint32_t u32x4_a4 __attribute__ ((ext_vector_type (4), aligned (4)));
+typedef uint32_t u32x2_a4 __attribute__ ((ext_vector_type (2), aligned (4)));
 
 /* ------------------------------------------------------------------------- */
 /* packed-byte primitives                                                     */
@@ -210,12 +215,21 @@ __device__ __forceinline__ void store_pixels (uint8_t *p, u32x4 px,
     else
       *(u32x4 *) p = px;
   } else {
-    uint32_t *q = (uint32_t *) p;
-    q[0] = px.x;
-    q[1] = px.y;
+    /* rows start at dword alignment only: same 16-byte store, at that alignment; the lane that
+     * holds the last two columns of a width % 4 == 2 frame writes two pixels */
     if (lastmode != 2) {
-      q[2] = px.z;
-      q[3] = px.w;
+      if constexpr (ST == 1)
+        __builtin_nontemporal_store (px, (u32x4_a4 *) p);
+      else
+        *(u32x4_a4 *) p = px;
+    } else {
+      u32x2 two;
+      two.x = px.x;
+      two.y = px.y;
+      if constexpr (ST == 1)
+        __builtin_nontemporal_store (two, (u32x2_a4 *) p);
+      else
+        *(u32x2_a4 *) p = two;
     }
   }
 }
@@ -323,29 +337,40 @@ bayer2rgb_lds_kernel (KParams p)
         *(u32x4 *) &lds[r * PITCH + MAIN + c] = v[i];
     }
   } else {
-    constexpr int TPR = TW / 4;           /* 4 B each */
+    /* generic geometry: the same 16-byte chunks, loaded at dword alignment; the chunk that
+     * straddles the end of a row (width % 16 != 0) is read dword by dword up to ROUND_UP_4(width),
+     * which the source stride always covers */
+    constexpr int TPR = TW / 16;
     constexpr int RPP = NTHREADS / TPR;
     constexpr int NPASS = (NROWS + RPP - 1) / RPP;
-    const int c = (tid % TPR) * 4;
+    const int c = (tid % TPR) * 16;
     const int rr = tid / TPR;
-    uint32_t v[NPASS];
+    const int avail = p.wlimit4 - (tile_x + c);         /* readable bytes from this chunk on */
+    u32x4 v[NPASS];
 #pragma unroll
     for (int i = 0; i < NPASS; i++) {
       const int r = i * RPP + rr;
       const int y = tile_y - 1 + r;
-      v[i] = 0u;
-      if (r < NROWS && y <= p.height && tile_x + c < p.wlimit4) {
+      v[i] = (u32x4) (0u);
+      if (r < NROWS && y <= p.height && avail > 0) {
         const uint8_t *g = src
             + (size_t) map_row (y, p.height, p.dn_last) * p.src_stride
             + tile_x + c;
-        v[i] = *(const uint32_t *) g;
+        if (avail >= 16) {
+          v[i] = *(const u32x4_a4 *) g;
+        } else {
+          const uint32_t *q = (const uint32_t *) g;
+          v[i].x = q[0];
+          if (avail > 4) v[i].y = q[1];
+          if (avail > 8) v[i].z = q[2];
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < NPASS; i++) {
       const int r = i * RPP + rr;
       if (r < NROWS)
-        *(uint32_t *) &lds[r * PITCH + MAIN + c] = v[i];
+        *(u32x4 *) &lds[r * PITCH + MAIN + c] = v[i];
     }
   }
   /* halo dwords: column tile_x-4 and tile_x+TW of every staged row */
