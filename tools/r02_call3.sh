@@ -22,4 +22,4 @@ echo "== rgb2bayer counters"; bash tools/r2b_counters.sh 2>&1 | tee $O/r2b_count
 echo "== pool bench, shared per-device queues (default)"; timeout 600 python tools/pool_pageable_bench.py 4 200 2>&1 | tee $O/pool_shared.log
 echo "== pool bench, private queues per context"; MIBAYER_SHARED_QUEUES=0 timeout 600 python tools/pool_pageable_bench.py 4 200 2>&1 | tee $O/pool_private.log
 echo "== stream mode"; timeout 600 python bench.py --mode stream 2>/dev/null | tail -1 | tee $O/stream.json | cut -c1-900
-echo "== gst pipeline bench"; timeout 900 bash tools/gst_pipeline_bench.sh 400 2>&1 | tee $O/gst_pipeline_bench.log
+echo "== gst pipeline bench"; timeout 900 bash tools/gst_pipeline_bench.sh 2000 2>&1 | tee $O/gst_pipeline_bench.log
