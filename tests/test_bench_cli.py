@@ -27,3 +27,36 @@ def test_without_a_gpu_the_benchmark_refuses(pkg):
     assert res.returncode != 0
     assert "no MI355X visible" in (res.stderr + res.stdout)
     assert "{" not in res.stdout           # no JSON line is fabricated
+
+
+def test_profiled_traffic_is_labelled_with_its_box_and_build():
+    """`roofline.traffic` is null unless the run itself was profiled; the committed PMC figure travels as
+    `traffic_profiled` with the plan, the box serial and the build hash it was measured on (VERDICT r01 weak #2)."""
+    import json
+    h = bench.build_hash()
+    assert len(h) == 12 and int(h, 16) >= 0
+    with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+        t = json.load(f)
+    assert {"plans", "box_serial", "build", "algorithmic_bytes_per_launch"} <= set(t)
+    for band, plan in ((1, "band1"), (544, "chunk"), (0, "identity")):
+        tp = bench.profiled_traffic(band)
+        assert tp["plan"] == plan and tp["bytes"] == t["plans"][plan]["hbm_bytes_per_launch"]
+        assert tp["box_serial"] == t["box_serial"] and tp["build"] == t["build"]
+        assert tp["build_matches_this_run"] == (t["build"] == h)
+        assert 1.0 <= tp["bytes"] / t["algorithmic_bytes_per_launch"] < 1.2
+
+
+def test_cpu_baseline_has_the_simd_leg_and_uses_every_core(monkeypatch):
+    """SURVEY 8(d) / BASELINE.md section 4: an ORC-equivalent SIMD leg on one core and an all-cores leg whose thread
+    count is the host's core count (VERDICT r01 missing #1), next to the scalar port and the reference's C path."""
+    monkeypatch.setattr(bench, "WIDTH", 256)
+    monkeypatch.setattr(bench, "HEIGHT", 64)
+    cb = bench.cpu_baseline(budget_s=0.5, sample_frames=4)
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Mpix/s"
+    assert cb["simd_1core"]["best"] in ("sse2", "avx2") and cb["value"] == cb["simd_1core"][cb["simd_1core"]["best"]]["value"]
+    assert cb["scalar_1core"]["cores"] == 1 and cb["scalar_1core"]["value"] > 0
+    ncores = len(os.sched_getaffinity(0))
+    assert cb["all_cores"]["cores"] == ncores == cb["all_cores"]["host_cores"]
+    assert cb["all_cores"]["jobs"] >= min(2 * ncores, 4 * 64)       # at least two jobs per core (bounded by the rows)
+    if cb["reference_c_path"] is not None:
+        assert cb["reference_c_path"]["kind"] == "reference" and cb["reference_c_path"]["cores"] == 1
