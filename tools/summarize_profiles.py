@@ -78,7 +78,7 @@ if stats:
         lines.append("Timed region only (the 20 bayer2rgb dispatches before the final parity launch = the 20 timed steps, kernel `%s`): "
                      "**avg %.0f ns**, min %d, max %d." % (timed[-1]["Kernel_Name"][:60], sum(d) / len(d), min(d), max(d)))
         lines.append("")
-    lines.append("(calls include the launches of `mibayer_autotune` -- two tile shapes x three block orders, five rounds -- and the ~150 ms time-based pre-warm; "
+    lines.append("(calls include the launches of `mibayer_autotune` -- three tile shapes x three block orders, five rounds -- and the ~150 ms time-based pre-warm; "
                  "profiled runs clock ~2 % lower than unprofiled ones, MI355X_MICROARCH.md \"DVFS\")")
     lines.append("")
 
