@@ -1324,6 +1324,48 @@ extern "C" int mibayer_internal_is_pageable (const void *p)
   return attr.type == hipMemoryTypeUnregistered ? 1 : 0;
 }
 
+extern "C" void mibayer_internal_private_queues (mibayer_ctx *c)
+{
+  if (!c || !c->shared_queues)
+    return;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return;
+  hipStream_t q[3] = { nullptr, nullptr, nullptr };
+  bool bad = false;
+  for (hipStream_t &st : q)
+    bad |= hip_failed (hipStreamCreateWithFlags (&st, hipStreamNonBlocking),
+        "hipStreamCreate");
+  if (bad) {                    /* keep the shared ones */
+    for (hipStream_t st : q)
+      if (st)
+        (void) hipStreamDestroy (st);
+    (void) hipGetLastError ();
+    return;
+  }
+  /* what this context has in flight on the shared queues completes there: a
+   * slot is reused only after its own download event has been waited for, and
+   * that event was recorded on the queue the download ran on */
+  {
+    std::lock_guard<std::mutex> lk (g_queues_mu);
+    DeviceQueues &dq = g_queues[c->device];
+    if (--dq.refs == 0) {
+      (void) hipStreamSynchronize (dq.h2d);
+      (void) hipStreamSynchronize (dq.compute);
+      (void) hipStreamSynchronize (dq.d2h);
+      (void) hipStreamDestroy (dq.h2d);
+      (void) hipStreamDestroy (dq.compute);
+      (void) hipStreamDestroy (dq.d2h);
+      dq = DeviceQueues ();
+    }
+  }
+  c->s_h2d = q[0];
+  c->s_compute = q[1];
+  c->s_d2h = q[2];
+  c->shared_queues = false;
+  /* graphs captured for the old compute queue replay on any queue; nothing to rebuild */
+}
+
 extern "C" int mibayer_host_is_pinned (const void *p)
 {
   if (!p || device_count_cached () <= 0)

@@ -31,6 +31,16 @@ int mibayer_internal_run_spare (mibayer_ctx *ctx, const uint8_t *src,
  * registered / device memory. */
 int mibayer_internal_is_pageable (const void *p);
 
+/* Give the context host-path queues of its own instead of its device's shared
+ * set (csrc/mibayer_abi.hip, DeviceQueues).  Shared queues keep PINNED copies of
+ * several contexts back to back on the one DMA engine per direction; a context
+ * whose frames are PAGEABLE is driven by a helper thread whose copies block
+ * while the runtime stages them, and several such threads stage concurrently
+ * only if each has its own queue (4 shards, pageable: 1483 fps on shared queues,
+ * 1627 fps on private ones; pinned: 1587 vs 870 -- profiles/r02_pool_queues.log).
+ * Frames already queued finish where they are; safe at any time. */
+void mibayer_internal_private_queues (mibayer_ctx *ctx);
+
 /* Best-effort quiesce of a context whose device reported an error: waits for
  * whatever still completes, never fails. */
 void mibayer_internal_abandon (mibayer_ctx *ctx);

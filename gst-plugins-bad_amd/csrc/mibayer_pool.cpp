@@ -284,6 +284,8 @@ static void enter_helper_mode (mibayer_pool *pool, int idx)
   Shard *sh = pool->shards[(size_t) idx];
   if (sh->helper_mode)
     return;
+  /* its blocking copies must not queue behind the other shards' (mibayer_hooks.h) */
+  mibayer_internal_private_queues (sh->ctx);
   start_helper (sh);
   std::lock_guard<std::mutex> lk (sh->mu);
   sh->helper_mode = true;

@@ -235,6 +235,12 @@ mibayer_internal_is_pageable (const void *p)
 }
 
 void
+mibayer_internal_private_queues (mibayer_ctx * c)
+{
+  (void) c;                     /* the double has no queues */
+}
+
+void
 mibayer_internal_abandon (mibayer_ctx * c)
 {
   if (c)
