@@ -12,10 +12,17 @@ for p in \
   "videotestsrc num-buffers=40 ! $B ! bayer2rgb inflight=2 devices=0,0 hipgraph=true ! fakesink" \
   "videotestsrc num-buffers=40 ! video/x-raw,format=ARGB,width=640,height=480 ! rgb2bayer inflight=2 ! bayer2rgb ! fakesink" \
   "videotestsrc num-buffers=40 ! $B ! hipupload ! hipbayer2rgb ! hipdownload ! fakesink" \
-  "videotestsrc num-buffers=40 ! $B ! hipupload ! hipbayer2rgb ! fakesink"; do
+  "videotestsrc num-buffers=40 ! $B ! hipupload ! hipbayer2rgb ! fakesink" \
+  "videotestsrc num-buffers=40 ! $B ! hipupload async=true ! hipbayer2rgb batch=4 ! hipdownload ! fakesink" \
+  "videotestsrc num-buffers=40 ! $B ! hipupload async=false ! hipbayer2rgb batch=16 ! fakesink" \
+  "FAULT videotestsrc num-buffers=40 ! $B ! bayer2rgb inflight=2 devices=0,0,0 ! fakesink" \
+  "videotestsrc num-buffers=40 ! $B ! bayer2rgb inflight=2 devices=0,0,0 pinned-pool=false ! fakesink"; do
+  fault=""
+  case "$p" in FAULT*) p=${p#FAULT }; fault="1:3";; esac
+  export MIBAYER_INJECT_FAULT=$fault
   out=$(GST_TRACERS=leaks GST_DEBUG=GST_TRACER:7 GST_DEBUG_NO_COLOR=1 /opt/conda/bin/gst-launch-1.0 -q $p 2>&1)
   rc=$?
   alive=$(echo "$out" | grep -c "object-alive, type-name=(string)[A-Za-z]")
-  echo "rc=$rc alive=$alive :: $p"
+  echo "rc=$rc alive=$alive ${fault:+(shard 1 fails after 3 frames) }:: $p"
   echo "$out" | grep "object-alive, type-name=(string)[A-Za-z]" | head -5
 done

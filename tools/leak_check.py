@@ -51,6 +51,34 @@ def one_round(i):
         o = np.empty((h, 4 * w), np.uint8)
         pool.submit(src, o, tag=1)
         pool.wait()
+    # round 2: failover (a shard dies and its frames are redone), helper threads (pageable buffers), private
+    # queues, NUMA-local pinned memory, list launches, copy queue + asynchronous upload
+    with pkg.Pool([0, 0, 0], w, h, "bggr", "RGBx", inflight=2) as pool:
+        pool.inject_fault(1, 1)
+        outs = [np.empty((h, 4 * w), np.uint8) for _ in range(6)]
+        for k, o in enumerate(outs):
+            if pool.pending() >= L.mibayer_pool_capacity(pool._h):
+                pool.wait()
+            pool.submit(src, o, tag=k + 1)
+        while pool.pending():
+            pool.wait()
+        pool.take_failure()
+    pn = L.mibayer_host_alloc_near(0, 4 * w * h)
+    L.mibayer_host_free(pn)
+    with pkg.Context(w, h, "rggb", "BGRx") as ctx:
+        ds = [ctx.device_alloc(ctx.src_bytes) for _ in range(3)]
+        dd = [ctx.device_alloc(ctx.dst_bytes) for _ in range(3)]
+        ctx.process_device_list(ds, dd)
+        ctx.sync()
+        st = L.mibayer_dev_stream_create(0)
+        e2 = L.mibayer_dev_event_create(0)
+        L.mibayer_dev_upload_async(0, ctypes.c_void_p(ds[0]), ctypes.c_void_p(src.ctypes.data), src.nbytes, ctypes.c_void_p(st))
+        L.mibayer_dev_event_record(0, ctypes.c_void_p(e2), ctypes.c_void_p(st))
+        L.mibayer_dev_event_wait(0, ctypes.c_void_p(e2))
+        L.mibayer_dev_event_destroy(0, ctypes.c_void_p(e2))
+        L.mibayer_dev_stream_destroy(0, ctypes.c_void_p(st))
+        for q in ds + dd:
+            ctx.device_free(q)
     ev = L.mibayer_dev_event_create(0)
     L.mibayer_dev_event_record(0, ev, None)
     L.mibayer_dev_event_wait(0, ev)
