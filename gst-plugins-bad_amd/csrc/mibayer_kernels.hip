@@ -730,6 +730,10 @@ static const Variant kVariants[] = {
   LDS_VARIANT ("lds_4x2_r4_dpp_nt_ldnt", 4, 2, 4, 0, 9, true),
   /* direct global -> LDS row loads (no staging registers, no ds_write pass) */
   LDS_VARIANT ("lds_4x2_r4_dpp_nt_glds", 4, 2, 4, 0, 17, true),
+  /* 20-21: plain (write-back) stores in the wide shapes: for output rows that start off a 64-byte sector
+   * (width % 16 != 0) the L2 then completes the partial sectors two waves share before they go out */
+  LDS_VARIANT ("lds_4x2_r4_dpp", 4, 2, 4, 0, 0, true),
+  LDS_VARIANT ("lds_2x4_r4_dpp", 2, 4, 4, 0, 0, true),
 };
 
 int variant_count ()
