@@ -207,6 +207,7 @@ struct mibayer_ctx {
                                            set by MIBAYER_XCD_BAND or mibayer_autotune() */
   int num_cus = 256;                    /* hipDeviceProp_t.multiProcessorCount */
   int persist_wgs_per_cu = 4;           /* MIBAYER_PERSIST_WGS (tuning), persistent arms */
+  bool rows_off_sector = false;         /* dst_stride % 64 != 0: see plain_store_twin () */
   int graph_mode = 0;                   /* MIBAYER_FLAG_HIPGRAPH: 0 = the compute-queue segment of a frame as
                                            a graph per slot (default), 1 = the whole upload -> kernel ->
                                            download chain as a graph per slot on the slot's own queue
@@ -635,6 +636,13 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   c->dst_bytes = (size_t) f.dst_stride * f.height;
   c->inverse = (f.flags & MIBAYER_FLAG_RGB2BAYER) != 0;
   c->var = &variant (resolve_variant (f.variant, f.width));
+  /* output rows off the 64-byte sector grid: write-back stores + one chunk of the batch per XCD
+   * (plain_store_twin, mibayer_kernels.hip); rows that fit one tile keep their identity-order plan */
+  c->rows_off_sector = !c->inverse && (f.dst_stride % 64) != 0;
+  if (c->rows_off_sector && f.variant == 0 && f.width > c->var->tile_w) {
+    c->var = &variant (plain_store_twin (resolve_variant (0, f.width)));
+    c->band_override = -1;
+  }
   if (const char *e = getenv ("MIBAYER_XCD_BAND"))
     c->band_override = atoi (e);
   if (const char *e = getenv ("MIBAYER_START_SLEEP"))
@@ -1544,10 +1552,13 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
   const Variant *shapes[3] = { c->var, nullptr, nullptr };
   int nshapes = 1;
   if (c->cfg.variant == 0) {
-    /* the other production shapes (1024x8, 512x16, 256x32 px tiles) */
-    for (int v = 3; v >= 1; v--)
-      if (c->var != &variant (v))
-        shapes[nshapes++] = &variant (v);
+    /* the other production shapes (1024x8, 512x16, 256x32 px tiles), with plain
+     * stores where the output rows sit off the sector grid */
+    for (int v = 3; v >= 1; v--) {
+      const Variant *cand = &variant (c->rows_off_sector ? plain_store_twin (v) : v);
+      if (c->var != cand)
+        shapes[nshapes++] = cand;
+    }
   }
   const bool band_forced = getenv ("MIBAYER_XCD_BAND") != NULL;
   const int bands[3] = { 1, -1, 0 };

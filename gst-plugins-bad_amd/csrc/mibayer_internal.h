@@ -173,6 +173,9 @@ struct Variant {
 int variant_count ();
 const Variant &variant (int id);
 int resolve_variant (int id, int width);        /* 0 ("auto") -> a concrete id */
+/* the plain-store (write-back) arm of a production shape (ids 1-3), for output rows that start off a
+ * 64-byte sector; any other id is returned unchanged */
+int plain_store_twin (int id);
 
 /* rgb2bayer (reference gst/bayer/gstrgb2bayer.c:230-278) */
 struct R2BParams {

@@ -746,6 +746,23 @@ const Variant &variant (int id)
   return kVariants[id];
 }
 
+/* Output rows that do not start on a 64-byte sector (4 * width, or a padded stride, not a multiple of
+ * 64: 4056-px sensors, any width % 16 != 0): every wave-store of a row then ends in a partial sector that the
+ * neighbouring wave -- or the neighbouring workgroup -- completes.  Streaming (nt) stores push those halves out
+ * one by one; plain write-back stores let the L2 put them together first, provided both halves reach the SAME
+ * L2, i.e. under the chunk-per-XCD order: 4056x3040 76.0 -> 78.9 %, 3838x2160 72.5 -> 78.5 %, 1366x768
+ * 68.1 -> 73.3 % of peak (profiles/r02_generic_path.log); for sector-aligned rows nt + band 1 stays ahead
+ * (80.8 vs 79.3 %). */
+int plain_store_twin (int id)
+{
+  switch (id) {
+    case 1: return 20;          /* lds_4x2_r4_dpp */
+    case 2: return 21;          /* lds_2x4_r4_dpp */
+    case 3: return 4;           /* lds_1x8_r4_dpp */
+    default: return id;
+  }
+}
+
 /* variant 0.  Rows that fit into ONE tile take the narrowest production tile that covers them (256 / 512 / 1024 px),
  * run in identity order without the start delay: 81-84 % of HBM peak for 320 ... 1024-px rows, against 50-79 % for
  * the other shapes (a second, mostly empty tile per row is what hurts: 640 px in 512-px tiles 59 %;
