@@ -88,3 +88,22 @@ def test_helpers_can_be_switched_off(driver):
     # MIBAYER_POOL_HELPERS=0: pageable frames take the direct path on the calling thread (A/B knob)
     kv, _ = run(driver, 4, 2, 40, True, "1:2", "ok", env={"MIBAYER_POOL_HELPERS": "0"})
     assert kv["delivered"] == "40" and kv["alive"] == "3"
+
+
+def test_randomised_scenarios(driver):
+    """Seeded random pools: 1-8 shards, 1-3 frames in flight each, 5-90 frames, pinned or pageable, a random subset of
+    the shards failing at random points.  Every scenario either delivers every frame once, in order, from its own source
+    (exit 0), or -- only if EVERY shard was given a fault -- may end with the stream dead (exit 21); no sanitizer report."""
+    import random
+    rng = random.Random(20260927)
+    for _ in range(40):
+        shards, inflight, frames, pageable = rng.randint(1, 8), rng.randint(1, 3), rng.randint(5, 90), rng.randint(0, 1)
+        which = rng.sample(range(shards), rng.randint(0, shards))
+        faults = ",".join("%d:%d" % (s, rng.randint(0, 12)) for s in which) or "-"
+        res = subprocess.run([driver, str(shards), str(inflight), str(frames), str(pageable), faults, "ok"],
+                             capture_output=True, text=True, timeout=120)
+        out = res.stdout + res.stderr
+        assert "Sanitizer" not in out, out[-3000:]
+        assert res.returncode in (0, 21), (res.returncode, shards, inflight, frames, pageable, faults, out[-1000:])
+        if res.returncode == 21:
+            assert len(which) == shards, (shards, faults, out[-500:])
