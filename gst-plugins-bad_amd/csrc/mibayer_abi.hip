@@ -1664,7 +1664,8 @@ extern "C" void *mibayer_host_alloc (size_t bytes)
   void *p = NULL;
   if (device_count_cached () <= 0)
     return NULL;
-  if (hip_failed (hipHostMalloc (&p, bytes ? bytes : 1, hipHostMallocDefault),
+  /* portable: a pool buffer may be read / written by any GPU of a `devices=` list */
+  if (hip_failed (hipHostMalloc (&p, bytes ? bytes : 1, hipHostMallocPortable),
           "hipHostMalloc"))
     return NULL;
   return p;
@@ -1722,7 +1723,8 @@ extern "C" void *mibayer_host_alloc_near (int device, size_t bytes)
       (unsigned long) (8 * sizeof mask)) == 0;
   void *p = NULL;
   const bool bad = hip_failed (hipHostMalloc (&p, bytes ? bytes : 1,
-          bound ? hipHostMallocNumaUser : hipHostMallocDefault), "hipHostMalloc");
+          (bound ? hipHostMallocNumaUser : 0u) | hipHostMallocPortable),
+      "hipHostMalloc");
   if (bound)
     (void) syscall (SYS_set_mempolicy, kMpolDefault, NULL, 0ul);
   if (bad) {
