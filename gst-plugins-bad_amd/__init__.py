@@ -134,6 +134,7 @@ ABI = {
     "mibayer_dev_stream_create": (_vp, [ctypes.c_int]),
     "mibayer_dev_stream_destroy": (None, [ctypes.c_int, _vp]),
     "mibayer_dev_upload_async": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp]),
+    "mibayer_dev_download_async": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp]),
     "mibayer_dev_event_query": (ctypes.c_int, [ctypes.c_int, _vp]),
     "mibayer_dev_event_create": (_vp, [ctypes.c_int]),
     "mibayer_dev_event_destroy": (None, [ctypes.c_int, _vp]),

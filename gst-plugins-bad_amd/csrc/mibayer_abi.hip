@@ -1885,6 +1885,22 @@ extern "C" int mibayer_dev_upload_async (int device, void *d_dst,
   return MIBAYER_OK;
 }
 
+extern "C" int mibayer_dev_download_async (int device, void *dst,
+    const void *d_src, size_t bytes, void *hip_stream)
+{
+  if (!dst || !d_src || !hip_stream)
+    return MIBAYER_ERR_ARG;
+  if (device < 0 || device >= device_count_cached ())
+    return MIBAYER_ERR_NO_DEVICE;
+  DeviceGuard guard (device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  Range r ("mibayer:d2h(async download)");
+  HIP_TRY (hipMemcpyAsync (dst, d_src, bytes, hipMemcpyDeviceToHost,
+          (hipStream_t) hip_stream));
+  return MIBAYER_OK;
+}
+
 extern "C" int mibayer_dev_event_query (int device, void *event)
 {
   if (!event)

@@ -107,12 +107,14 @@ buffer_hip_memory (GstBuffer * buf)
 /* hipupload / hipdownload                                                   */
 /* ======================================================================== */
 
-/* hipupload: one host buffer whose DMA into device memory is still in flight */
+/* one host buffer whose DMA is still in flight: hipupload's input (kept until the copy has read
+ * it), hipdownload's output (pushed once the copy has written it) */
 typedef struct
 {
   GstBuffer *host_buf;          /* our reference keeps the memory (and its pool slot) alive */
   GstMapInfo map;
   gpointer event;               /* recorded on the copy queue right after the copy */
+  GstBuffer *dev_buf;           /* hipdownload: the device buffer being read (released with the entry) */
 } PendingUpload;
 
 #define MAX_PENDING_UPLOADS 4
@@ -121,7 +123,8 @@ typedef struct
 {
   GstBaseTransform parent;
   gint device_id;
-  gboolean async;               /* hipupload: do not wait for the DMA (property "async") */
+  gboolean async;               /* do not wait for the DMA (property "async") */
+  gboolean prerolled;           /* hipdownload: a frame has left since start / flush */
   /* hipupload, async: the copy queue and the host buffers it still reads */
   gpointer stream;
   gint stream_device;
@@ -182,6 +185,8 @@ pending_upload_free (GstMiHipXfer * self, PendingUpload * p)
 {
   gst_buffer_unmap (p->host_buf, &p->map);
   gst_buffer_unref (p->host_buf);
+  if (p->dev_buf)
+    gst_buffer_unref (p->dev_buf);
   if (p->event)
     mibayer_dev_event_destroy (self->stream_device, p->event);
   g_free (p);
@@ -288,17 +293,194 @@ xfer_upload_async (GstMiHipXfer * self, GstBuffer * inbuf, GstMemory * dev_mem)
   return TRUE;
 }
 
+/* ---- asynchronous download: the queued mode of hipdownload ---------------------- */
+/* The synchronous downloader holds the streaming thread for the whole 4 B/pixel
+ * copy (0.63 ms per 4K frame), during which nothing upstream on that thread --
+ * the next upload, the next launch -- is queued: `hipupload ! hipbayer2rgb !
+ * hipdownload` runs at 1285 fps where the same three stages overlapped inside
+ * `bayer2rgb inflight=2` reach 1604.  Asynchronously, the copy is queued on the
+ * element's copy queue (ordered after the device memory's last access, and the
+ * memory is marked so that it is not recycled under the copy), the output buffer
+ * waits in `pending` with its own event, and generate_output hands on the
+ * oldest output once its copy has finished -- immediately if it has, at the
+ * latest when more than MAX_PENDING_UPLOADS are waiting; events that must not
+ * overtake buffers push what is waiting first, a flush drops it.  Pageable
+ * output memory (a downstream pool that is not pinned) takes the blocking copy:
+ * hipMemcpyAsync would block anyway.  The first frame after a start / flush is
+ * not held back (preroll). */
+
+/* the oldest output whose copy is done (or, wait == TRUE, the oldest one) */
+static GstBuffer *
+xfer_pop_download (GstMiHipXfer * self, gboolean wait)
+{
+  PendingUpload *p = g_queue_peek_head (&self->pending);
+  GstBuffer *out;
+
+  if (p == NULL)
+    return NULL;
+  if (p->event != NULL) {
+    if (wait)
+      mibayer_dev_event_wait (self->stream_device, p->event);
+    else if (mibayer_dev_event_query (self->stream_device, p->event) == 0)
+      return NULL;
+  }
+  g_queue_pop_head (&self->pending);
+  out = gst_buffer_ref (p->host_buf);
+  pending_upload_free (self, p);        /* unmaps; drops our references */
+  return out;
+}
+
+static gboolean
+xfer_download_async (GstMiHipXfer * self, GstBuffer * inbuf, GstBuffer * outbuf)
+{
+  GstMemory *dev_mem = buffer_hip_memory (inbuf);
+  GstMiHipMemory *m = (GstMiHipMemory *) dev_mem;
+  PendingUpload *p;
+  GstMapInfo dev_map;
+  gsize n;
+
+  if (dev_mem == NULL)
+    return FALSE;
+  if (self->stream != NULL && self->stream_device != m->device)
+    return FALSE;               /* frames in flight on another device: blocking copy */
+  if (self->stream == NULL) {
+    self->stream = mibayer_dev_stream_create (m->device);
+    self->stream_device = m->device;
+    if (self->stream == NULL)
+      return FALSE;
+  }
+  p = g_new0 (PendingUpload, 1);
+  if (!gst_buffer_map (outbuf, &p->map, GST_MAP_WRITE)) {
+    g_free (p);
+    return FALSE;
+  }
+  if (!mibayer_host_is_pinned (p->map.data)
+      || !gst_memory_map (dev_mem, &dev_map,
+          GST_MAP_READ | GST_MAP_HIP | GST_MAP_HIP_ASYNC)) {
+    gst_buffer_unmap (outbuf, &p->map);
+    g_free (p);
+    return FALSE;
+  }
+  n = MIN (p->map.size, dev_map.size);
+  if (!gst_mi_hip_memory_order_after (m, self->stream))
+    gst_mi_hip_memory_wait (m);
+  p->event = mibayer_dev_event_create (m->device);
+  if (p->event == NULL
+      || mibayer_dev_download_async (m->device, p->map.data, dev_map.data, n,
+          self->stream) != MIBAYER_OK
+      || !gst_mi_hip_memory_mark_access (m, self->stream)
+      || mibayer_dev_event_record (m->device, p->event,
+          self->stream) != MIBAYER_OK) {
+    /* whatever was queued must not outlive this call */
+    mibayer_dev_stream_destroy (m->device, self->stream);       /* synchronises */
+    self->stream = NULL;
+    gst_memory_unmap (dev_mem, &dev_map);
+    gst_buffer_unmap (outbuf, &p->map);
+    if (p->event)
+      mibayer_dev_event_destroy (m->device, p->event);
+    g_free (p);
+    return FALSE;
+  }
+  gst_memory_unmap (dev_mem, &dev_map);
+  p->host_buf = outbuf;         /* takes the caller's reference */
+  p->dev_buf = gst_buffer_ref (inbuf);
+  g_queue_push_tail (&self->pending, p);
+  return TRUE;
+}
+
+static GstFlowReturn xfer_transform (GstBaseTransform * trans,
+    GstBuffer * inbuf, GstBuffer * outbuf);
+
+static GstFlowReturn
+xfer_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
+{
+  GstMiHipXfer *self = GST_MI_HIP_XFER (trans);
+  GstBaseTransformClass *klass = GST_BASE_TRANSFORM_GET_CLASS (trans);
+  GstBuffer *inbuf;
+
+  if (GST_MI_HIP_XFER_GET_CLASS (trans)->to_device
+      || (!self->async && g_queue_is_empty (&self->pending)))
+    return GST_BASE_TRANSFORM_CLASS (gst_mi_hip_xfer_parent_class)->generate_output
+        (trans, outbuf);
+
+  *outbuf = NULL;
+  inbuf = trans->queued_buf;
+  trans->queued_buf = NULL;
+  if (inbuf != NULL) {
+    GstBuffer *out = NULL;
+    GstFlowReturn ret = klass->prepare_output_buffer (trans, inbuf, &out);
+
+    if (ret != GST_FLOW_OK || out == NULL) {
+      gst_buffer_unref (inbuf);
+      return ret == GST_FLOW_OK ? GST_FLOW_ERROR : ret;
+    }
+    if (!self->async || !xfer_download_async (self, inbuf, out)) {
+      /* blocking copy; what is already waiting leaves first, in order */
+      GQueue done = G_QUEUE_INIT;
+      GstBuffer *b;
+
+      while ((b = xfer_pop_download (self, TRUE)) != NULL)
+        g_queue_push_tail (&done, b);
+      ret = xfer_transform (trans, inbuf, out);
+      gst_buffer_unref (inbuf);
+      if (ret != GST_FLOW_OK) {
+        gst_buffer_unref (out);
+        while ((b = g_queue_pop_head (&done)) != NULL)
+          gst_buffer_unref (b);
+        return ret;
+      }
+      g_queue_push_tail (&done, out);
+      *outbuf = g_queue_pop_head (&done);
+      while ((b = g_queue_pop_head (&done)) != NULL) {  /* rare: keep the order */
+        PendingUpload *q = g_new0 (PendingUpload, 1);
+
+        q->host_buf = b;
+        if (!gst_buffer_map (b, &q->map, GST_MAP_READ)) {
+          gst_buffer_unref (b);
+          g_free (q);
+          continue;
+        }
+        g_queue_push_tail (&self->pending, q);  /* no event: ready at once */
+      }
+      self->prerolled = TRUE;
+      return GST_FLOW_OK;
+    }
+    gst_buffer_unref (inbuf);           /* the pending entry holds its own ref */
+  }
+  /* the base class calls again for as long as a buffer comes out */
+  *outbuf = xfer_pop_download (self, !self->prerolled
+      || g_queue_get_length (&self->pending) > MAX_PENDING_UPLOADS);
+  if (*outbuf != NULL)
+    self->prerolled = TRUE;
+  return GST_FLOW_OK;
+}
+
 static gboolean
 xfer_sink_event (GstBaseTransform * trans, GstEvent * event)
 {
   GstMiHipXfer *self = GST_MI_HIP_XFER (trans);
+  const gboolean to_device = GST_MI_HIP_XFER_GET_CLASS (trans)->to_device;
+  GstBuffer *buf;
 
   switch (GST_EVENT_TYPE (event)) {
     case GST_EVENT_EOS:
-    case GST_EVENT_FLUSH_STOP:
     case GST_EVENT_CAPS:
-      /* serialised with the streaming thread: hand every host buffer back */
-      xfer_reap_uploads (self, TRUE, 0);
+    case GST_EVENT_SEGMENT:
+    case GST_EVENT_GAP:
+      /* serialised with the streaming thread.  hipupload: hand every host buffer
+       * back; hipdownload: what is waiting precedes the event */
+      if (to_device) {
+        if (GST_EVENT_TYPE (event) == GST_EVENT_EOS
+            || GST_EVENT_TYPE (event) == GST_EVENT_CAPS)
+          xfer_reap_uploads (self, TRUE, 0);
+      } else {
+        while ((buf = xfer_pop_download (self, TRUE)) != NULL)
+          gst_pad_push (GST_BASE_TRANSFORM_SRC_PAD (trans), buf);
+      }
+      break;
+    case GST_EVENT_FLUSH_STOP:
+      xfer_reap_uploads (self, TRUE, 0);        /* either direction: drop */
+      self->prerolled = FALSE;
       break;
     default:
       break;
@@ -311,6 +493,7 @@ static gboolean
 xfer_stop (GstBaseTransform * trans)
 {
   xfer_drop_stream (GST_MI_HIP_XFER (trans));
+  GST_MI_HIP_XFER (trans)->prerolled = FALSE;
   return TRUE;
 }
 
@@ -399,10 +582,11 @@ xfer_decide_allocation (GstBaseTransform * trans, GstQuery * query)
           (guint) size, 2);
     } else if (gst_query_get_n_allocation_pools (query) == 0) {
       pool = configured_pool (gst_mi_host_pool_new (self->device_id), caps,
-          (guint) size, 2);
+          (guint) size, MAX_PENDING_UPLOADS + 2);
     }
     if (pool) {
-      gst_query_add_allocation_pool (query, pool, (guint) size, 2, 0);
+      gst_query_add_allocation_pool (query, pool, (guint) size,
+          to_device ? 2 : MAX_PENDING_UPLOADS + 2, 0);
       gst_object_unref (pool);
     }
   }
@@ -472,15 +656,17 @@ gst_mi_hip_xfer_class_init (GstMiHipXferClass * klass)
       g_param_spec_int ("device-id", "Device ID", "HIP ordinal of the MI355X",
           0, G_MAXINT, 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_ASYNC,
-      g_param_spec_boolean ("async", "Asynchronous upload",
-          "hipupload: queue the host-to-device copy and return; the host buffer "
-          "is released when the copy has completed, downstream GPU work is "
-          "ordered after it; lets upstream fill the next frame while this one "
-          "crosses PCIe.  Applies to pinned input (the pool this element "
-          "proposes upstream); input in pageable memory is copied blocking, as "
-          "the runtime would do anyway (no effect on hipdownload)", TRUE,
+      g_param_spec_boolean ("async", "Asynchronous copy",
+          "Queue the copy and return.  hipupload: the host buffer is released "
+          "when the copy has completed, downstream GPU work is ordered after "
+          "it.  hipdownload: the output buffer is pushed when its copy has "
+          "completed (up to 4 frames wait; the first frame after a start or "
+          "flush is not held back).  Applies to pinned host memory (the pools "
+          "these elements propose / use); pageable memory is copied blocking, "
+          "as the runtime would do anyway", TRUE,
           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   transform_class->sink_event = GST_DEBUG_FUNCPTR (xfer_sink_event);
+  transform_class->generate_output = GST_DEBUG_FUNCPTR (xfer_generate_output);
   transform_class->stop = GST_DEBUG_FUNCPTR (xfer_stop);
   transform_class->passthrough_on_same_caps = FALSE;
   transform_class->transform_caps = GST_DEBUG_FUNCPTR (xfer_transform_caps);
@@ -497,6 +683,7 @@ gst_mi_hip_xfer_init (GstMiHipXfer * self)
 {
   self->device_id = 0;
   self->async = TRUE;
+  self->prerolled = FALSE;
   self->stream = NULL;
   self->stream_device = 0;
   g_queue_init (&self->pending);

@@ -291,6 +291,10 @@ void *mibayer_dev_stream_create (int device);
 void mibayer_dev_stream_destroy (int device, void *hip_stream);
 int mibayer_dev_upload_async (int device, void *d_dst, const void *src,
     size_t bytes, void *hip_stream);
+/* the other direction (hipdownload's queued mode): `dst` is complete once an
+ * event recorded on the stream after the call has fired */
+int mibayer_dev_download_async (int device, void *dst, const void *d_src,
+    size_t bytes, void *hip_stream);
 /* 1 = the work recorded in the event has completed, 0 = not yet, < 0 = error */
 int mibayer_dev_event_query (int device, void *event);
 

@@ -494,6 +494,14 @@ mibayer_dev_upload_async (int device, void *d_dst, const void *src, size_t bytes
   return MIBAYER_OK;
 }
 
+/* the other direction: the host buffer is WRITTEN when something ordered after the copy completes -- an output
+ * buffer pushed downstream (or unmapped) before that is a sanitizer report or a wrong stamp */
+int
+mibayer_dev_download_async (int device, void *dst, const void *d_src, size_t bytes, void *hip_stream)
+{
+  return mibayer_dev_upload_async (device, dst, d_src, bytes, hip_stream);
+}
+
 int
 mibayer_dev_event_query (int device, void *event)
 {

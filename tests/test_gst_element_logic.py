@@ -313,8 +313,8 @@ def test_hipbayer2rgb_batch_mode_keeps_order_and_drains(rig, tmp_path, batch):
         assert kv["pushed"] == str(n) and kv["pulled"] == str(n), launch
         seq, fill = stamps(outp, n, 4 * w * h)
         assert fill == list(range(40, 40 + n)) and seq == list(range(n)), launch
-    kv = run(rig, "flush", "hipupload ! hipbayer2rgb batch=%d ! hipdownload" % batch, B2R % ("gbrg", w, h), inp,
-             260 * h, outp, 3)
+    kv = run(rig, "flush", "hipupload ! hipbayer2rgb batch=%d ! hipdownload async=false" % batch, B2R % ("gbrg", w, h),
+             inp, 260 * h, outp, 3)
     dropped = 2 % batch     # parked when the flush came: frame 0 left alone (preroll), frames 1-2 filled a batch or not
     assert kv["pulled"] == str(n - dropped)
     _, fill = stamps(outp, n - dropped, 4 * w * h)
@@ -322,3 +322,31 @@ def test_hipbayer2rgb_batch_mode_keeps_order_and_drains(rig, tmp_path, batch):
     kv = run(rig, "states", "videotestsrc num-buffers=11 ! video/x-bayer,format=rggb,width=64,height=48 ! hipupload ! "
              "hipbayer2rgb batch=%d ! queue ! hipdownload ! fakesink" % batch, 2)
     assert kv["cycles_ok"] == "2"
+
+
+@pytest.mark.parametrize("download", ["hipdownload", "hipdownload async=false"])
+def test_asynchronous_download_pushes_a_frame_only_when_its_copy_is_done(rig, tmp_path, download):
+    """hipdownload queues its device-to-host copy and hands the output on once the copy's event has fired.  The double
+    executes an asynchronous copy only when something ordered after it completes and answers the first query of
+    every event with "not yet": an output pushed early carries the wrong stamp, one unmapped or released early is a
+    sanitizer report.  Every frame leaves once and in order, the tail at EOS; a flush drops what is waiting and
+    nothing else; state cycles leave nothing behind."""
+    w, h, n = 258, 37, 15
+    inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
+    frames(n, 260 * h, first=90).tofile(inp)
+    for head in ("hipupload ! hipbayer2rgb", "hipupload async=false ! hipbayer2rgb batch=4"):
+        kv = run(rig, "convert", "%s ! %s" % (head, download), B2R % ("gbrg", w, h), inp, 260 * h, outp)
+        assert kv["pushed"] == str(n) and kv["pulled"] == str(n), (head, download)
+        seq, fill = stamps(outp, n, 4 * w * h)
+        assert fill == list(range(90, 90 + n)) and seq == list(range(n)), (head, download)
+    kv = run(rig, "flush", "hipupload ! hipbayer2rgb ! %s" % download, B2R % ("gbrg", w, h), inp, 260 * h, outp, 4)
+    pulled = int(kv["pulled"])
+    assert n - 4 <= pulled <= n                    # at most the frames pushed before the flush are gone
+    _, fill = stamps(outp, pulled, 4 * w * h)
+    assert fill == sorted(fill) and len(set(fill)) == pulled          # in order, no duplicates
+    assert fill[-(n - 4):] == list(range(94, 90 + n))                 # everything after the flush arrived
+    if "async=false" in download:
+        assert pulled == n                          # the blocking downloader holds nothing back
+    kv = run(rig, "states", "videotestsrc num-buffers=13 ! video/x-bayer,format=rggb,width=64,height=48 ! hipupload ! "
+             "hipbayer2rgb batch=2 ! %s ! fakesink" % download, 3)
+    assert kv["cycles_ok"] == "3"

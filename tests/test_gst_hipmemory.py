@@ -50,7 +50,8 @@ def test_upload_convert_download_pipeline(plugin, gpu_pkg, oracle, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("elements", ["hipupload async=true ! hipbayer2rgb", "hipupload ! hipbayer2rgb batch=4",
-                                      "hipupload async=true ! hipbayer2rgb batch=16 ! queue"])
+                                      "hipupload async=true ! hipbayer2rgb batch=16 ! queue",
+                                      "hipupload async=false ! hipbayer2rgb ! queue max-size-buffers=3"])
 def test_async_upload_and_batched_conversion_are_bit_exact(plugin, gpu_pkg, oracle, tmp_path, elements):
     """The asynchronous uploader (host buffers released when their DMA has finished) and the batched converter (one
     list launch over N separately allocated frames; 23 frames = full batches plus a tail converted at EOS), alone and
@@ -66,6 +67,14 @@ def test_async_upload_and_batched_conversion_are_bit_exact(plugin, gpu_pkg, orac
     got = np.fromfile(outp, np.uint8).reshape(n, h, 4 * w)
     want = oracle.bayer2rgb_batch(src, w, "grbg", 3, 2, 1, nthreads=4)
     assert np.array_equal(got, want)
+    # the same through the blocking downloader (hipdownload is asynchronous by default: outputs wait for their copy)
+    out2 = str(tmp_path / "out2.raw")
+    res = launch(tmp_path,
+                 "videotestsrc num-buffers=%d pattern=snow ! video/x-bayer,format=grbg,width=%d,height=%d,framerate=30/1 "
+                 "! %s ! hipdownload async=false ! video/x-raw,format=xBGR ! filesink location=%s"
+                 % (n, w, h, elements, out2))
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert np.array_equal(np.fromfile(out2, np.uint8).reshape(n, h, 4 * w), want)
 
 
 @pytest.mark.gpu

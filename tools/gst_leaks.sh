@@ -15,6 +15,7 @@ for p in \
   "videotestsrc num-buffers=40 ! $B ! hipupload ! hipbayer2rgb ! fakesink" \
   "videotestsrc num-buffers=40 ! $B ! hipupload async=true ! hipbayer2rgb batch=4 ! hipdownload ! fakesink" \
   "videotestsrc num-buffers=40 ! $B ! hipupload async=false ! hipbayer2rgb batch=16 ! fakesink" \
+  "videotestsrc num-buffers=40 ! $B ! hipupload ! hipbayer2rgb ! hipdownload async=false ! fakesink" \
   "FAULT videotestsrc num-buffers=40 ! $B ! bayer2rgb inflight=2 devices=0,0,0 ! fakesink" \
   "videotestsrc num-buffers=40 ! $B ! bayer2rgb inflight=2 devices=0,0,0 pinned-pool=false ! fakesink"; do
   fault=""

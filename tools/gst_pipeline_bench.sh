@@ -26,6 +26,8 @@ a=$(run 20 "hipupload async=false ! hipbayer2rgb" "$DEV"); b=$(run $((10*N+20)) 
 line "hipupload async=false ! hipbayer2rgb" $a $b $((10*N))
 a=$(run 20 "hipupload ! hipbayer2rgb ! hipdownload"); b=$(run $((N+20)) "hipupload ! hipbayer2rgb ! hipdownload")
 line "hipupload ! hipbayer2rgb ! hipdownload" $a $b
+a=$(run 20 "hipupload ! hipbayer2rgb ! hipdownload async=false"); b=$(run $((N+20)) "hipupload ! hipbayer2rgb ! hipdownload async=false")
+line "hipupload ! hipbayer2rgb ! hipdownload async=false" $a $b
 # the inverse element: 4 B/px in, 1 B/px out
 run_inv () {
   local t0=$(date +%s.%N)
