@@ -104,13 +104,18 @@ def cpu_baseline(budget_s=12.0, sample_frames=32):
     src = oracle.fill_synthetic(WIDTH, HEIGHT, sample_frames, SEED)
     dst = np.empty((sample_frames, HEIGHT, 4 * WIDTH), np.uint8)
     r, g, b = oracle.LAYOUTS[FORMAT]
-    oracle.bayer2rgb_batch_bands(src, WIDTH, "rggb", r, g, b, 1, min(ncores, sample_frames), "own", dst)  # page-in
+    # all cores: frames x row bands, at least two jobs per core
+    nbands_all = max(1, -(-2 * ncores // sample_frames))
+    # page-in with the job -> thread map of the all-cores leg: every output page is first touched (and so placed,
+    # on a multi-socket host) by the thread that writes it later
+    oracle.bayer2rgb_batch_bands(src, WIDTH, "rggb", r, g, b, nbands_all, ncores, "own", dst)
 
-    def run(mode, nthreads, nbands, budget):
+    def run(mode, nthreads, nbands, budget, repeat=1):
         reps, t0 = 0, time.perf_counter()
         while True:
-            oracle.bayer2rgb_batch_bands(src, WIDTH, ORDERS[reps % 4], r, g, b, nbands, nthreads, mode, dst)
-            reps += 1
+            oracle.bayer2rgb_batch_bands(src, WIDTH, ORDERS[reps % 4], r, g, b, nbands, nthreads, mode, dst,
+                                         repeat=repeat)
+            reps += repeat
             el = time.perf_counter() - t0
             if el >= budget:
                 return WIDTH * HEIGHT * sample_frames * reps / el / 1e6, reps, el
@@ -123,9 +128,13 @@ def cpu_baseline(budget_s=12.0, sample_frames=32):
         simd[isa] = {"value": round(v, 1), "passes": reps, "seconds": round(el, 2)}
     best_isa = max(simd, key=lambda k: simd[k]["value"])
     vs, repss, els = run("own", 1, 1, share)
-    # all cores: frames x row bands, at least two jobs per core
-    nbands = max(1, -(-2 * ncores // sample_frames))
-    vn, repsn, eln = run(best_isa, ncores, nbands, share * 1.5)
+    # every core: one quick pass sizes `repeat` so that a call lasts ~0.25 s and creating / joining `ncores` threads
+    # is not what is being timed
+    nbands = nbands_all
+    t0 = time.perf_counter()
+    oracle.bayer2rgb_batch_bands(src, WIDTH, "rggb", r, g, b, nbands, ncores, best_isa, dst)
+    one = max(time.perf_counter() - t0, 1e-4)
+    vn, repsn, eln = run(best_isa, ncores, nbands, share * 1.5, repeat=max(1, min(200, int(0.25 / one))))
     ref = None
     if oracle.have_ref_rows():
         # the reference's own compiled row kernels (gstbayerorc-dist.c, -DDISABLE_ORC = its C backup path)
@@ -148,7 +157,8 @@ def cpu_baseline(budget_s=12.0, sample_frames=32):
         "all_cores": {"value": round(vn, 1), "cores": ncores, "host_cores": ncores, "passes": repsn,
                       "isa": best_isa, "jobs": sample_frames * nbands,
                       "note": "pthreads, %d frames x %d row bands = %d jobs round-robin over %d threads (every "
-                              "host core)" % (sample_frames, nbands, sample_frames * nbands, ncores)},
+                              "host core), several passes per thread creation, output pages first touched by the "
+                              "thread that writes them" % (sample_frames, nbands, sample_frames * nbands, ncores)},
         "reference_c_path": ref,
     }
 

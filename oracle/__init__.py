@@ -45,6 +45,9 @@ def lib():
         L.oracle_bayer2rgb_batch_bands.argtypes = [
             _u8p, ctypes.c_size_t, ctypes.c_int, _u8p, ctypes.c_size_t, ctypes.c_int,
         ] + [ctypes.c_int] * 10
+        L.oracle_bayer2rgb_batch_bands_repeat.argtypes = [
+            _u8p, ctypes.c_size_t, ctypes.c_int, _u8p, ctypes.c_size_t, ctypes.c_int,
+        ] + [ctypes.c_int] * 11
         L.oracle_fill_synthetic.argtypes = [
             _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
             ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32]
@@ -146,8 +149,10 @@ def bayer2rgb_mode(src, width, pattern, r_off, g_off, b_off, mode="own", y0=0, y
     return dst
 
 
-def bayer2rgb_batch_bands(src, width, pattern, r_off, g_off, b_off, nbands=1, nthreads=1, mode="own", dst=None):
-    """src: (N, H, src_stride) uint8 -> (N, H, 4*width) uint8; N x nbands jobs over nthreads pthreads."""
+def bayer2rgb_batch_bands(src, width, pattern, r_off, g_off, b_off, nbands=1, nthreads=1, mode="own", dst=None,
+                          repeat=1):
+    """src: (N, H, src_stride) uint8 -> (N, H, 4*width) uint8; N x nbands jobs over nthreads pthreads; `repeat` > 1
+    converts the batch that many times inside the worker threads (timing: amortises thread creation)."""
     if isinstance(pattern, str):
         pattern = PATTERNS[pattern]
     src = np.ascontiguousarray(src, dtype=np.uint8)
@@ -156,9 +161,9 @@ def bayer2rgb_batch_bands(src, width, pattern, r_off, g_off, b_off, nbands=1, nt
         dst = np.empty((N, H, 4 * width), np.uint8)
     if mode == "ref":
         load_ref_rows()
-    rc = lib().oracle_bayer2rgb_batch_bands(
+    rc = lib().oracle_bayer2rgb_batch_bands_repeat(
         _p(dst), H * 4 * width, 4 * width, _p(src), H * sstride, sstride,
-        width, H, pattern, r_off, g_off, b_off, N, nbands, nthreads, ROWS[mode])
+        width, H, pattern, r_off, g_off, b_off, N, nbands, nthreads, ROWS[mode], repeat)
     if rc != 0:
         raise ValueError("oracle rejected geometry/layout/mode (rc=%d)" % rc)
     return dst

@@ -388,7 +388,7 @@ struct batch_job
   const uint8_t *src;
   size_t src_frame_bytes;
   int src_stride;
-  int w, h, pattern, r, g, b, nframes, nbands, nthreads, tid, mode, rc;
+  int w, h, pattern, r, g, b, nframes, nbands, nthreads, tid, mode, rc, repeat;
 };
 
 static void *
@@ -396,6 +396,8 @@ batch_worker (void *arg)
 {
   struct batch_job *jb = (struct batch_job *) arg;
   long job, njobs = (long) jb->nframes * jb->nbands;
+  int rep;
+  for (rep = 0; rep < jb->repeat; rep++)
   for (job = jb->tid; job < njobs; job += jb->nthreads) {
     const int f = (int) (job / jb->nbands), band = (int) (job % jb->nbands);
     const int y0 = (int) ((long) jb->h * band / jb->nbands);
@@ -412,11 +414,40 @@ batch_worker (void *arg)
 
 /* nframes x nbands independent jobs (frame f, rows h*b/nbands .. h*(b+1)/nbands),
  * job k on thread k mod nthreads */
+static int batch_bands_repeat (uint8_t *dst, size_t dst_frame_bytes,
+    int dst_stride, const uint8_t *src, size_t src_frame_bytes, int src_stride,
+    int width, int height, int pattern, int r_off, int g_off, int b_off,
+    int nframes, int nbands, int nthreads, int mode, int repeat);
+
 int
 oracle_bayer2rgb_batch_bands (uint8_t *dst, size_t dst_frame_bytes,
     int dst_stride, const uint8_t *src, size_t src_frame_bytes, int src_stride,
     int width, int height, int pattern, int r_off, int g_off, int b_off,
     int nframes, int nbands, int nthreads, int mode)
+{
+  return batch_bands_repeat (dst, dst_frame_bytes, dst_stride, src,
+      src_frame_bytes, src_stride, width, height, pattern, r_off, g_off, b_off,
+      nframes, nbands, nthreads, mode, 1);
+}
+
+/* the same conversion `repeat` times over inside the worker threads: for timing on many cores, where
+ * creating and joining a few hundred threads per pass would otherwise be a large part of a pass */
+int
+oracle_bayer2rgb_batch_bands_repeat (uint8_t *dst, size_t dst_frame_bytes,
+    int dst_stride, const uint8_t *src, size_t src_frame_bytes, int src_stride,
+    int width, int height, int pattern, int r_off, int g_off, int b_off,
+    int nframes, int nbands, int nthreads, int mode, int repeat)
+{
+  return batch_bands_repeat (dst, dst_frame_bytes, dst_stride, src,
+      src_frame_bytes, src_stride, width, height, pattern, r_off, g_off, b_off,
+      nframes, nbands, nthreads, mode, repeat < 1 ? 1 : repeat);
+}
+
+static int
+batch_bands_repeat (uint8_t *dst, size_t dst_frame_bytes,
+    int dst_stride, const uint8_t *src, size_t src_frame_bytes, int src_stride,
+    int width, int height, int pattern, int r_off, int g_off, int b_off,
+    int nframes, int nbands, int nthreads, int mode, int repeat)
 {
   int t, rc = 0;
   long njobs;
@@ -439,7 +470,7 @@ oracle_bayer2rgb_batch_bands (uint8_t *dst, size_t dst_frame_bytes,
   for (t = 0; t < nthreads; t++) {
     struct batch_job jb = { dst, dst_frame_bytes, dst_stride, src,
       src_frame_bytes, src_stride, width, height, pattern, r_off, g_off,
-      b_off, nframes, nbands, nthreads, t, mode, 0
+      b_off, nframes, nbands, nthreads, t, mode, 0, repeat
     };
     jobs[t] = jb;
     if (t > 0 && pthread_create (&th[t], NULL, batch_worker, &jobs[t]) != 0) {

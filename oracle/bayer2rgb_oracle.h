@@ -86,6 +86,12 @@ int oracle_bayer2rgb_batch_bands (uint8_t *dst, size_t dst_frame_bytes,
     int width, int height, int pattern, int r_off, int g_off, int b_off,
     int nframes, int nbands, int nthreads, int mode);
 
+/* the same, `repeat` passes inside the worker threads (timing on many cores) */
+int oracle_bayer2rgb_batch_bands_repeat (uint8_t *dst, size_t dst_frame_bytes,
+    int dst_stride, const uint8_t *src, size_t src_frame_bytes, int src_stride,
+    int width, int height, int pattern, int r_off, int g_off, int b_off,
+    int nframes, int nbands, int nthreads, int mode, int repeat);
+
 /* Inverse element rgb2bayer, reference gst/bayer/gstrgb2bayer.c:254-268: output
  * byte (j,i) is byte r_off / g_off / b_off of input pixel (j,i) according to the
  * CFA site ((j&1)<<1)|(i&1); the reference hard-codes ARGB (r,g,b = 1,2,3).
