@@ -122,8 +122,8 @@ typedef struct
 typedef struct
 {
   GstBaseTransform parent;
-  gint device_id;
-  gboolean async;               /* do not wait for the DMA (property "async") */
+  gint device_id;               /* properties: g_atomic_int_* (set from any thread) */
+  gint async;                   /* do not wait for the DMA (property "async") */
   gboolean prerolled;           /* hipdownload: a frame has left since start / flush */
   /* hipupload, async: the copy queue and the host buffers it still reads */
   gpointer stream;
@@ -138,6 +138,8 @@ typedef struct
 } GstMiHipXferClass;
 
 #define GST_MI_HIP_XFER(obj) ((GstMiHipXfer *) (obj))
+#define XFER_ASYNC(self) (g_atomic_int_get (&(self)->async) != 0)
+#define XFER_DEVICE(self) (g_atomic_int_get (&(self)->device_id))
 #define GST_MI_HIP_XFER_GET_CLASS(obj) \
   ((GstMiHipXferClass *) G_OBJECT_GET_CLASS (obj))
 
@@ -147,10 +149,13 @@ static void
 xfer_set_property (GObject * object, guint prop_id, const GValue * value,
     GParamSpec * pspec)
 {
+  /* read by the streaming thread: plain aligned ints, set atomically */
   if (prop_id == PROP_DEVICE_ID)
-    GST_MI_HIP_XFER (object)->device_id = g_value_get_int (value);
+    g_atomic_int_set (&GST_MI_HIP_XFER (object)->device_id,
+        g_value_get_int (value));
   else if (prop_id == PROP_ASYNC)
-    GST_MI_HIP_XFER (object)->async = g_value_get_boolean (value);
+    g_atomic_int_set (&GST_MI_HIP_XFER (object)->async,
+        g_value_get_boolean (value));
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
 }
@@ -160,9 +165,11 @@ xfer_get_property (GObject * object, guint prop_id, GValue * value,
     GParamSpec * pspec)
 {
   if (prop_id == PROP_DEVICE_ID)
-    g_value_set_int (value, GST_MI_HIP_XFER (object)->device_id);
+    g_value_set_int (value,
+        g_atomic_int_get (&GST_MI_HIP_XFER (object)->device_id));
   else if (prop_id == PROP_ASYNC)
-    g_value_set_boolean (value, GST_MI_HIP_XFER (object)->async);
+    g_value_set_boolean (value,
+        g_atomic_int_get (&GST_MI_HIP_XFER (object)->async));
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
 }
@@ -399,7 +406,7 @@ xfer_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
   GstBuffer *inbuf;
 
   if (GST_MI_HIP_XFER_GET_CLASS (trans)->to_device
-      || (!self->async && g_queue_is_empty (&self->pending)))
+      || (!XFER_ASYNC (self) && g_queue_is_empty (&self->pending)))
     return GST_BASE_TRANSFORM_CLASS (gst_mi_hip_xfer_parent_class)->generate_output
         (trans, outbuf);
 
@@ -414,7 +421,7 @@ xfer_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
       gst_buffer_unref (inbuf);
       return ret == GST_FLOW_OK ? GST_FLOW_ERROR : ret;
     }
-    if (!self->async || !xfer_download_async (self, inbuf, out)) {
+    if (!XFER_ASYNC (self) || !xfer_download_async (self, inbuf, out)) {
       /* blocking copy; what is already waiting leaves first, in order */
       GQueue done = G_QUEUE_INIT;
       GstBuffer *b;
@@ -546,8 +553,8 @@ xfer_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query,
   gst_query_parse_allocation (query, &caps, NULL);
   if (caps && frame_size_from_caps (caps, &size)) {
     GstBufferPool *pool =
-        configured_pool (gst_mi_host_pool_new (GST_MI_HIP_XFER (trans)->
-            device_id), caps, (guint) size, MAX_PENDING_UPLOADS + 2);
+        configured_pool (gst_mi_host_pool_new (XFER_DEVICE (GST_MI_HIP_XFER
+                (trans))), caps, (guint) size, MAX_PENDING_UPLOADS + 2);
 
     if (pool) {
       /* asynchronous uploads hold up to MAX_PENDING_UPLOADS input buffers */
@@ -578,10 +585,10 @@ xfer_decide_allocation (GstBaseTransform * trans, GstQuery * query)
        * downstream proposed */
       while (gst_query_get_n_allocation_pools (query) > 0)
         gst_query_remove_nth_allocation_pool (query, 0);
-      pool = configured_pool (gst_mi_hip_pool_new (self->device_id), caps,
+      pool = configured_pool (gst_mi_hip_pool_new (XFER_DEVICE (self)), caps,
           (guint) size, 2);
     } else if (gst_query_get_n_allocation_pools (query) == 0) {
-      pool = configured_pool (gst_mi_host_pool_new (self->device_id), caps,
+      pool = configured_pool (gst_mi_host_pool_new (XFER_DEVICE (self)), caps,
           (guint) size, MAX_PENDING_UPLOADS + 2);
     }
     if (pool) {
@@ -613,7 +620,7 @@ xfer_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
             : "input"), (NULL));
     return GST_FLOW_ERROR;
   }
-  if (to_device && self->async) {
+  if (to_device && XFER_ASYNC (self)) {
     if (xfer_upload_async (self, inbuf, dev_mem))
       return GST_FLOW_OK;
     GST_LOG_OBJECT (self, "pageable input or no copy queue: blocking copy");
@@ -756,7 +763,7 @@ typedef struct
   GstBaseTransform parent;
   GstVideoInfo info;
   gint width, height, r_off, g_off, b_off, format;
-  gint device_id;
+  gint device_id;               /* properties device-id / batch: g_atomic_int_* */
   mibayer_ctx *ctx;
   gint ctx_device;              /* the device the context was created on */
   /* batch mode (property "batch" > 1): input / output buffer pairs waiting for ONE launch over all of
@@ -803,9 +810,11 @@ hb2r_set_property (GObject * object, guint prop_id, const GValue * value,
     GParamSpec * pspec)
 {
   if (prop_id == PROP_DEVICE_ID)
-    ((GstMiHipBayer2RGB *) object)->device_id = g_value_get_int (value);
+    g_atomic_int_set (&((GstMiHipBayer2RGB *) object)->device_id,
+        g_value_get_int (value));
   else if (prop_id == PROP_BATCH)
-    ((GstMiHipBayer2RGB *) object)->batch = g_value_get_int (value);
+    g_atomic_int_set (&((GstMiHipBayer2RGB *) object)->batch,
+        g_value_get_int (value));
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
 }
@@ -815,9 +824,11 @@ hb2r_get_property (GObject * object, guint prop_id, GValue * value,
     GParamSpec * pspec)
 {
   if (prop_id == PROP_DEVICE_ID)
-    g_value_set_int (value, ((GstMiHipBayer2RGB *) object)->device_id);
+    g_value_set_int (value,
+        g_atomic_int_get (&((GstMiHipBayer2RGB *) object)->device_id));
   else if (prop_id == PROP_BATCH)
-    g_value_set_int (value, ((GstMiHipBayer2RGB *) object)->batch);
+    g_value_set_int (value,
+        g_atomic_int_get (&((GstMiHipBayer2RGB *) object)->batch));
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
 }
@@ -932,7 +943,7 @@ hb2r_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
   cfg.r_off = self->r_off;
   cfg.g_off = self->g_off;
   cfg.b_off = self->b_off;
-  cfg.device = self->device_id;
+  cfg.device = g_atomic_int_get (&self->device_id);
   rc = mibayer_create (&cfg, &self->ctx);
   if (rc != MIBAYER_OK) {
     self->ctx = NULL;
@@ -958,8 +969,8 @@ hb2r_decide_allocation (GstBaseTransform * trans, GstQuery * query)
 
     while (gst_query_get_n_allocation_pools (query) > 0)
       gst_query_remove_nth_allocation_pool (query, 0);
-    pool = configured_pool (gst_mi_hip_pool_new (self->device_id), caps,
-        (guint) size, 2);
+    pool = configured_pool (gst_mi_hip_pool_new (g_atomic_int_get
+            (&self->device_id)), caps, (guint) size, 2);
     if (pool) {
       gst_query_add_allocation_pool (query, pool, (guint) size, 2, 0);
       gst_object_unref (pool);
@@ -1148,8 +1159,9 @@ hb2r_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
   GstBaseTransformClass *klass = GST_BASE_TRANSFORM_GET_CLASS (trans);
   GstBuffer *inbuf;
   GstFlowReturn ret = GST_FLOW_OK;
+  const gint batch = g_atomic_int_get (&self->batch);
 
-  if (self->batch <= 1 && g_queue_is_empty (&self->waiting)
+  if (batch <= 1 && g_queue_is_empty (&self->waiting)
       && g_queue_is_empty (&self->ready))
     return GST_BASE_TRANSFORM_CLASS (gst_mi_hip_bayer2rgb_parent_class)->generate_output
         (trans, outbuf);
@@ -1175,7 +1187,7 @@ hb2r_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
      * until N-1 more arrive can deadlock against upstream queues that fill up
      * while another branch's sink sits prerolled (tee ! queue ! ...). */
     if ((gint) g_queue_get_length (&self->waiting)
-        >= (self->prerolled ? MIN (MAX (self->batch, 1), HB2R_MAX_BATCH) : 1))
+        >= (self->prerolled ? MIN (MAX (batch, 1), HB2R_MAX_BATCH) : 1))
       ret = hb2r_convert_waiting (self);
   }
   /* the base class calls again for as long as a buffer comes out */
