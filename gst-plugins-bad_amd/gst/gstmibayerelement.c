@@ -880,7 +880,7 @@ element_query (GstBaseTransform * base, GstPadDirection direction,
     gst_query_parse_latency (query, &live, &min, &max);
     if (fps_n > 0 && fps_d > 0) {
       GstClockTime held =
-          gst_util_uint64_scale_int (GST_SECOND * (guint64) (self->inflight
+          gst_util_uint64_scale_int (GST_SECOND * (guint64) (self->act.inflight
               * element_ndevices (self)), fps_d, fps_n);
 
       min += held;
