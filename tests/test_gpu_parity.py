@@ -726,3 +726,70 @@ def test_device_launch_can_be_captured_in_a_hipgraph(gpu_pkg):
     res = subprocess.run([sys.executable, "-c", GRAPH_SCRIPT, ROOT], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, (res.stdout + res.stderr)[-2000:]
     assert "graph replay ok" in res.stdout
+
+
+@pytest.mark.parametrize("flags", [0, 1], ids=["streams", "hipgraph"])
+def test_contexts_on_several_threads_share_the_device_queues(gpu_pkg, oracle, flags):
+    """The reference's threading contract: several element instances run concurrently on
+    different streaming threads.  Here every context of a device shares that device's three queues
+    (csrc/mibayer_abi.hip, DeviceQueues), so: four threads, each with its own context (own geometry, order and layout),
+    stream frames through submit / wait at the same time while a fifth thread creates, uses and destroys short-lived
+    contexts (the queue set's reference count goes up and down under load).  Every frame of every thread is
+    bit-exact and in order."""
+    import threading
+    jobs = [(640, 480, "bggr", "RGBx", (0, 1, 2), 40), (1920, 1080, "rggb", "BGRx", (2, 1, 0), 24),
+            (1282, 722, "grbg", "xRGB", (1, 2, 3), 24), (3840, 2160, "gbrg", "xBGR", (3, 2, 1), 10)]
+    inputs = []
+    for k, (w, h, order, fmt, offs, n) in enumerate(jobs):
+        src = oracle.fill_synthetic(w, h, n, seed=70 + k)
+        want = oracle.bayer2rgb_batch(src, w, order, *offs, nthreads=4)
+        inputs.append((src, want))
+    errors, stop = [], threading.Event()
+
+    def stream(k):
+        try:
+            w, h, order, fmt, _, n = jobs[k]
+            src, want = inputs[k]
+            stride = (w + 3) & ~3
+            with gpu_pkg.Context(w, h, order, fmt, inflight=3, flags=flags) as c:
+                outs = [np.zeros((h, 4 * w), np.uint8) for _ in range(3)]
+                padded = [np.zeros((h, stride), np.uint8) for _ in range(3)]
+                done = 0
+                for i in range(n):
+                    if c.pending() == 3:
+                        t = c.wait()
+                        assert t == done + 1
+                        assert np.array_equal(outs[done % 3], want[done]), (k, done)
+                        done += 1
+                    padded[i % 3][:, :w] = src[i].reshape(h, -1)[:, :w]
+                    c.submit(padded[i % 3], outs[i % 3], tag=i + 1)
+                while c.pending():
+                    t = c.wait()
+                    assert t == done + 1
+                    assert np.array_equal(outs[done % 3], want[done]), (k, done)
+                    done += 1
+                assert done == n
+        except Exception as exc:            # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(exc)))
+
+    def churn():
+        try:
+            src, want = inputs[0]
+            w, h, order, fmt = jobs[0][:4]
+            while not stop.is_set():
+                with gpu_pkg.Context(w, h, order, fmt) as c:
+                    assert np.array_equal(c.process_host(src[0]), want[0])
+        except Exception as exc:            # noqa: BLE001
+            errors.append(("churn", repr(exc)))
+
+    threads = [threading.Thread(target=stream, args=(k,)) for k in range(len(jobs))]
+    extra = threading.Thread(target=churn)
+    extra.start()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    stop.set()
+    extra.join(60)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads) and not extra.is_alive()
