@@ -633,9 +633,9 @@ def test_hipgraph_host_path_with_changing_pointers(gpu_pkg, oracle):
 def test_randomised_geometries_strides_variants(gpu_pkg, oracle):
     """Seeded fuzz over the whole configuration space of the ABI: even widths 4..4100, heights 3..130, padded
     source and destination strides, all orders and formats, every kernel variant, host and device paths."""
-    rng = np.random.default_rng(20260926)
+    rng = np.random.default_rng(int(os.environ.get("MIBAYER_FUZZ_SEED", "20260926")))
     nvar = len(gpu_pkg.variant_names())
-    for case in range(60):
+    for case in range(int(os.environ.get("MIBAYER_FUZZ_CASES", "60"))):      # soak runs: tools/README.md
         w = int(rng.integers(2, 2051)) * 2
         h = int(rng.integers(3, 131))
         if case % 10 == 0:
