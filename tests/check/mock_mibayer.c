@@ -430,7 +430,7 @@ mibayer_process_device_list (mibayer_ctx * c, const void *const *d_srcs, void *c
 void *
 mibayer_dev_alloc (int device, size_t bytes)
 {
-  return device == 0 ? malloc (bytes ? bytes : 1) : NULL;
+  return (device >= 0 && device < mibayer_device_count ()) ? malloc (bytes ? bytes : 1) : NULL;
 }
 
 void

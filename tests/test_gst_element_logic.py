@@ -350,3 +350,18 @@ def test_asynchronous_download_pushes_a_frame_only_when_its_copy_is_done(rig, tm
     kv = run(rig, "states", "videotestsrc num-buffers=13 ! video/x-bayer,format=rggb,width=64,height=48 ! hipupload ! "
              "hipbayer2rgb batch=2 ! %s ! fakesink" % download, 3)
     assert kv["cycles_ok"] == "3"
+
+
+def test_hipbayer2rgb_refuses_frames_that_live_on_another_gpu(rig):
+    """The C ABI takes bare device pointers, so a frame uploaded to GPU 1 must not reach a context on GPU 0:
+    hipbayer2rgb compares the memory's device with its context's and posts a NEGOTIATION error instead of launching;
+    with matching ordinals the same pipeline runs."""
+    exe, env, _ = rig
+    desc = ("videotestsrc num-buffers=3 ! video/x-bayer,format=rggb,width=64,height=48 ! hipupload device-id=%d ! "
+            "hipbayer2rgb device-id=%d ! hipdownload ! fakesink")
+    two = dict(env, MOCK_MIBAYER_DEVICES="2")
+    res = subprocess.run([exe, "states", desc % (1, 0), "1"], capture_output=True, text=True, env=two, timeout=60)
+    out = res.stdout + res.stderr
+    assert res.returncode != 0 and "another GPU" in out and "AddressSanitizer" not in out, out[-2000:]
+    kv = run(rig, "states", desc % (1, 1), 1, extra_env={"MOCK_MIBAYER_DEVICES": "2"})
+    assert kv["cycles_ok"] == "1"
