@@ -51,6 +51,23 @@ int main (int argc, char **argv)
   hipEvent_t e0, e1;
   CK (hipEventCreate (&e0)); CK (hipEventCreate (&e1));
   const unsigned grid = 8 * 32 * 8;       /* 256 workgroups on the chosen XCD: 8 per CU */
+  if (argc > 3 && argv[3][0] == 't') {
+    /* time series: ONE region written over and over by XCD 0 -- is the ~3 % ripple of the table a function of the
+     * position (then this series is flat) or of time (then it shows here too)? */
+    printf ("# XCD 0 writing region 0, then region 5, 160 launches each, GB/s\n");
+    for (int r : { 0, 5 }) {
+      for (int i = 0; i < 160; i++) {
+        CK (hipEventRecord (e0));
+        stream_one_xcd<<<grid, 256>>> ((u32x4 *) (arena + region * r), region / 16, 0, 1, wrong, sink);
+        CK (hipEventRecord (e1));
+        CK (hipEventSynchronize (e1));
+        float ms; CK (hipEventElapsedTime (&ms, e0, e1));
+        printf (" %4.0f", region / (ms * 1e-3) / 1e9);
+      }
+      printf ("\n");
+    }
+    return 0;
+  }
   for (int write = 0; write < 2; write++) {
     printf ("# %s GB/s: rows = XCD, columns = 256 MiB region of the arena\n", write ? "write (nt)" : "read");
     for (int xcd = 0; xcd < 8; xcd++) {
