@@ -616,8 +616,18 @@ element_propose_allocation (GstBaseTransform * base, GstQuery * decide_query,
   min = (guint) (MAX (self->act.inflight, 1) * element_ndevices (self) + 2);
   pool = element_make_pinned_pool (self, caps, (guint) size, min);
   if (pool) {
+    mibayer_pool_cfg pc;
+    GstAllocationParams params;
+    GstAllocator *allocator;
+
     gst_query_add_allocation_pool (query, pool, (guint) size, min, 0);
     gst_object_unref (pool);
+    /* and the allocator behind it, for an upstream that builds its own pool */
+    allocator = gst_mi_host_allocator_new (element_parse_devices (self, &pc)
+        ? pc.devices[0] : self->act.device_id);
+    gst_allocation_params_init (&params);
+    gst_query_add_allocation_param (query, allocator, &params);
+    gst_object_unref (allocator);
     EL_DEBUG (self, "proposed a pinned input pool upstream");
   }
   return TRUE;

@@ -557,10 +557,18 @@ xfer_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query,
                 (trans))), caps, (guint) size, MAX_PENDING_UPLOADS + 2);
 
     if (pool) {
+      GstAllocationParams params;
+      GstAllocator *allocator =
+          gst_mi_host_allocator_new (XFER_DEVICE (GST_MI_HIP_XFER (trans)));
+
       /* asynchronous uploads hold up to MAX_PENDING_UPLOADS input buffers */
       gst_query_add_allocation_pool (query, pool, (guint) size,
           MAX_PENDING_UPLOADS + 2, 0);
       gst_object_unref (pool);
+      /* and the allocator behind it, for an upstream that builds its own pool */
+      gst_allocation_params_init (&params);
+      gst_query_add_allocation_param (query, allocator, &params);
+      gst_object_unref (allocator);
     }
   }
   return TRUE;

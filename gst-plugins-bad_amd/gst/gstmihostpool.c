@@ -1,6 +1,8 @@
 /* GstMiHostPool: buffer pool over hipHostMalloc-pinned memory.  See the header. */
 #include "gstmihostpool.h"
 
+#include <string.h>
+
 #include "mibayer.h"
 
 GST_DEBUG_CATEGORY_STATIC (gst_mi_host_pool_debug);
@@ -71,25 +73,61 @@ pinned_memory_free (gpointer data)
   mibayer_host_free (data);
 }
 
+/* `size` usable bytes of pinned memory with the prefix, padding and alignment
+ * of `params` (NULL = none), as one wrapped system memory */
+static GstMemory *
+pinned_memory_new (gint device, gsize size, const GstAllocationParams * params)
+{
+  const gsize align = params ? params->align : 0;       /* a mask: 2^n - 1 */
+  const gsize prefix = params ? params->prefix : 0;
+  const gsize padding = params ? params->padding : 0;
+  const GstMemoryFlags flags = params ? params->flags : 0;
+  const gsize maxsize = size + prefix + padding + align;
+  gsize offset = prefix, mis;
+  guint8 *data = device >= 0 ? mibayer_host_alloc_near (device, maxsize)
+      : mibayer_host_alloc (maxsize);
+
+  if (data == NULL)
+    return NULL;
+  /* hipHostMalloc memory starts on a page; the first byte after the prefix goes
+   * onto the requested boundary */
+  mis = ((gsize) (data + offset)) & align;
+  if (mis)
+    offset += align + 1 - mis;
+  if (offset && (flags & GST_MEMORY_FLAG_ZERO_PREFIXED))
+    memset (data, 0, offset);
+  if (maxsize > offset + size && (flags & GST_MEMORY_FLAG_ZERO_PADDED))
+    memset (data + offset + size, 0, maxsize - offset - size);
+  return gst_memory_new_wrapped (flags, data, maxsize, offset, size, data,
+      pinned_memory_free);
+}
+
 static GstFlowReturn
 gst_mi_host_pool_alloc_buffer (GstBufferPool * pool, GstBuffer ** buffer,
     GstBufferPoolAcquireParams * params)
 {
   GstMiHostPool *self = GST_MI_HOST_POOL (pool);
-  gpointer data = self->device >= 0
-      ? mibayer_host_alloc_near (self->device, self->size)
-      : mibayer_host_alloc (self->size);
-  GstBuffer *buf;
+  GstStructure *config = gst_buffer_pool_get_config (pool);
+  GstAllocationParams aparams;
+  GstAllocator *ignored = NULL;
+  GstMemory *mem;
 
-  if (data == NULL) {
+  /* whoever configured the pool may have asked for a prefix / padding /
+   * alignment (GstBaseSrc and GstBaseTransform copy the query's allocation
+   * params into the pool they were offered); the allocator itself is ours */
+  gst_allocation_params_init (&aparams);
+  if (config != NULL) {
+    (void) gst_buffer_pool_config_get_allocator (config, &ignored, &aparams);
+    gst_structure_free (config);
+  }
+  mem = pinned_memory_new (self->device, self->size, &aparams);
+  if (mem == NULL) {
     GST_ERROR_OBJECT (pool, "hipHostMalloc of %u bytes failed: %s",
         self->size, mibayer_last_hip_error ());
     return GST_FLOW_ERROR;
   }
-  buf = gst_buffer_new ();
-  gst_buffer_append_memory (buf, gst_memory_new_wrapped (0, data, self->size,
-          0, self->size, data, pinned_memory_free));
-  *buffer = buf;
+  *buffer = gst_buffer_new ();
+  gst_buffer_append_memory (*buffer, mem);
   return GST_FLOW_OK;
 }
 
@@ -119,4 +157,90 @@ gst_mi_host_pool_new (gint device)
   GST_MI_HOST_POOL (pool)->device = device;
   gst_object_ref_sink (pool);
   return pool;
+}
+
+/* ---- the same memory as a GstAllocator ---------------------------------------------- */
+
+typedef struct
+{
+  GstAllocator parent;
+  gint device;
+} GstMiHostAllocator;
+
+typedef struct
+{
+  GstAllocatorClass parent_class;
+} GstMiHostAllocatorClass;
+
+static GstMemory *
+gst_mi_host_allocator_alloc (GstAllocator * allocator, gsize size,
+    GstAllocationParams * params)
+{
+  GstMemory *mem =
+      pinned_memory_new (((GstMiHostAllocator *) allocator)->device, size,
+      params);
+
+  if (mem == NULL)
+    GST_ERROR_OBJECT (allocator, "hipHostMalloc of %" G_GSIZE_FORMAT
+        " bytes failed: %s", size, mibayer_last_hip_error ());
+  return mem;
+}
+
+/* the memories are wrapped system memory: the system allocator frees them
+ * (through pinned_memory_free), never this one */
+static void
+gst_mi_host_allocator_free (GstAllocator * allocator, GstMemory * memory)
+{
+  g_warn_if_reached ();
+}
+
+static void
+gst_mi_host_allocator_class_init (gpointer klass, gpointer data)
+{
+  GstAllocatorClass *allocator_class = GST_ALLOCATOR_CLASS (klass);
+
+  allocator_class->alloc = gst_mi_host_allocator_alloc;
+  allocator_class->free = gst_mi_host_allocator_free;
+}
+
+static void
+gst_mi_host_allocator_init (GTypeInstance * instance, gpointer klass)
+{
+  ((GstMiHostAllocator *) instance)->device = -1;
+}
+
+/* per-plugin type name, like the pool's */
+GType
+gst_mi_host_allocator_get_type (void)
+{
+  static gsize type_id = 0;
+
+  if (g_once_init_enter (&type_id)) {
+    gchar *name = g_strdup (MI_HOST_POOL_TYPE_NAME "Allocator");
+    GType t;
+    guint n = 1;
+
+    while (g_type_from_name (name) != 0) {
+      g_free (name);
+      name = g_strdup_printf ("%sAllocator%u", MI_HOST_POOL_TYPE_NAME, ++n);
+    }
+    t = g_type_register_static_simple (GST_TYPE_ALLOCATOR,
+        g_intern_string (name), sizeof (GstMiHostAllocatorClass),
+        gst_mi_host_allocator_class_init, sizeof (GstMiHostAllocator),
+        gst_mi_host_allocator_init, 0);
+    g_free (name);
+    g_once_init_leave (&type_id, t);
+  }
+  return type_id;
+}
+
+GstAllocator *
+gst_mi_host_allocator_new (gint device)
+{
+  GstMiHostAllocator *self =
+      g_object_new (gst_mi_host_allocator_get_type (), NULL);
+
+  self->device = device;
+  gst_object_ref_sink (self);
+  return GST_ALLOCATOR_CAST (self);
 }

@@ -3,6 +3,12 @@
  * asynchronous DMA.  The memory is ordinary CPU-addressable memory: any element
  * can map it like system memory.
  *
+ * GstMiHostAllocator -- the same memory as a GstAllocator, proposed in the
+ * ALLOCATION query next to the pool: an upstream element that builds a pool of
+ * its own (or allocates buffer by buffer) around the proposed allocator gets
+ * pinned memory too.  Both honour the prefix / padding / alignment of the
+ * GstAllocationParams they are given.
+ *
  * This file is compiled into BOTH plugins (`bayer` and `mihip`), and GStreamer
  * loads plugins RTLD_LOCAL: each copy registers its own GType, under its own
  * name (MI_HOST_POOL_TYPE_NAME, set per plugin by the Makefile) -- two
@@ -43,6 +49,12 @@ GType gst_mi_host_pool_get_type (void);
 /* `device`: the HIP ordinal that will read / write the buffers: they are pinned on
  * the NUMA node next to it (mibayer_host_alloc_near); -1 = no preference */
 GstBufferPool *gst_mi_host_pool_new (gint device);
+
+/* a GstAllocator of pinned host memory near `device` (-1 = no preference); the
+ * memories it returns are plain wrapped system memory (any element maps them),
+ * released with mibayer_host_free when the last reference goes */
+GType gst_mi_host_allocator_get_type (void);
+GstAllocator *gst_mi_host_allocator_new (gint device);
 
 G_END_DECLS
 #endif

@@ -16,6 +16,9 @@
  *        NULL -> PLAYING -> (EOS) -> NULL, <cycles> times, on ONE pipeline instance
  *   element_harness caps <launchline> <sinkcaps> <framebytes>
  *        CAPS event + one buffer; prints caps_accepted=0|1 flow=<name> (set_caps refusing a geometry = not-negotiated)
+ *   element_harness allocation <launchline> <sinkcaps>
+ *        ALLOCATION query to the element's sink pad; uses the proposed allocator and pool with a prefix / padding /
+ *        64-byte alignment; prints pools= params= alloc_ok= pool_ok=
  *
  * convert / flush also print warnings=<n> errors=<n> (element messages seen on a private bus) and, for flush,
  * released_at_flush_start=0|1: whether every input buffer pushed before the flush had been let go of by the element
@@ -291,6 +294,93 @@ run_states (const char *desc, int cycles)
   return 0;
 }
 
+/* allocation <launch> <caps>: what the element proposes upstream.  Sends an ALLOCATION query to its sink pad, then
+ * uses what came back the way an upstream element would: a memory from the proposed allocator with a prefix, a
+ * padding and a 64-byte alignment, and a buffer from the proposed pool configured with the same parameters. */
+static int
+check_memory (GstMemory * mem, gsize size, gsize prefix, gsize padding)
+{
+  GstMapInfo map;
+  gsize offset = 0, maxsize = 0;
+  int ok;
+
+  if (mem == NULL || gst_memory_get_sizes (mem, &offset, &maxsize) != size)
+    return 0;
+  ok = offset >= prefix && maxsize >= offset + size + padding;
+  if (!gst_memory_map (mem, &map, GST_MAP_WRITE))
+    return 0;
+  ok = ok && map.size == size && (((gsize) map.data) & 63) == 0;
+  memset (map.data, 0x5a, map.size);
+  ok = ok && map.data[-1] == 0 && map.data[size] == 0;  /* ZERO_PREFIXED / ZERO_PADDED */
+  gst_memory_unmap (mem, &map);
+  return ok;
+}
+
+static int
+run_allocation (char **argv)
+{
+  GstHarness *h = gst_harness_new_parse (argv[2]);
+  GstCaps *caps = gst_caps_from_string (argv[3]);
+  GstQuery *query;
+  GstAllocationParams params;
+  guint npools, nparams;
+  int alloc_ok = 0, pool_ok = 0;
+
+  if (!h || !caps)
+    return 2;
+  gst_harness_set_src_caps_str (h, argv[3]);
+  query = gst_query_new_allocation (caps, TRUE);
+  if (!gst_pad_peer_query (h->srcpad, query)) {
+    fprintf (stdout, "query=0\n");
+    return 0;
+  }
+  npools = gst_query_get_n_allocation_pools (query);
+  nparams = gst_query_get_n_allocation_params (query);
+  gst_allocation_params_init (&params);
+  params.align = 63;
+  params.prefix = 16;
+  params.padding = 8;
+  params.flags = GST_MEMORY_FLAG_ZERO_PREFIXED | GST_MEMORY_FLAG_ZERO_PADDED;
+  if (nparams > 0) {
+    GstAllocator *allocator = NULL;
+    GstMemory *mem;
+
+    gst_query_parse_nth_allocation_param (query, 0, &allocator, NULL);
+    if (allocator != NULL) {
+      mem = gst_allocator_alloc (allocator, 1000, &params);
+      alloc_ok = check_memory (mem, 1000, 16, 8);
+      if (mem)
+        gst_memory_unref (mem);
+      gst_object_unref (allocator);
+    }
+  }
+  if (npools > 0) {
+    GstBufferPool *pool = NULL;
+    guint size = 0, min = 0, max = 0;
+
+    gst_query_parse_nth_allocation_pool (query, 0, &pool, &size, &min, &max);
+    if (pool != NULL) {
+      GstStructure *config = gst_buffer_pool_get_config (pool);
+      GstBuffer *buf = NULL;
+
+      gst_buffer_pool_config_set_params (config, caps, size, min, max);
+      gst_buffer_pool_config_set_allocator (config, NULL, &params);
+      if (gst_buffer_pool_set_config (pool, config) && gst_buffer_pool_set_active (pool, TRUE)
+          && gst_buffer_pool_acquire_buffer (pool, &buf, NULL) == GST_FLOW_OK) {
+        pool_ok = gst_buffer_n_memory (buf) == 1 && check_memory (gst_buffer_peek_memory (buf, 0), size, 16, 8);
+        gst_buffer_unref (buf);
+      }
+      gst_buffer_pool_set_active (pool, FALSE);
+      gst_object_unref (pool);
+    }
+  }
+  fprintf (stdout, "query=1 pools=%u params=%u alloc_ok=%d pool_ok=%d\n", npools, nparams, alloc_ok, pool_ok);
+  gst_query_unref (query);
+  gst_caps_unref (caps);
+  gst_harness_teardown (h);
+  return 0;
+}
+
 int
 main (int argc, char **argv)
 {
@@ -303,6 +393,8 @@ main (int argc, char **argv)
     return run_renegotiate (argv);
   if (argc >= 5 && strcmp (argv[1], "caps") == 0)
     return run_caps (argv);
+  if (argc >= 4 && strcmp (argv[1], "allocation") == 0)
+    return run_allocation (argv);
   if (argc >= 4 && strcmp (argv[1], "states") == 0)
     return run_states (argv[2], atoi (argv[3]));
   fprintf (stderr, "usage: see the header of element_harness.c\n");

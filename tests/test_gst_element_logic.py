@@ -365,3 +365,16 @@ def test_hipbayer2rgb_refuses_frames_that_live_on_another_gpu(rig):
     assert res.returncode != 0 and "another GPU" in out and "AddressSanitizer" not in out, out[-2000:]
     kv = run(rig, "states", desc % (1, 1), 1, extra_env={"MOCK_MIBAYER_DEVICES": "2"})
     assert kv["cycles_ok"] == "1"
+
+
+def test_the_allocation_query_offers_a_pinned_pool_and_its_allocator(rig):
+    """SURVEY 8(f) rank 1 names both: a pinned GstBufferPool AND the GstAllocator behind it (an upstream element that
+    builds its own pool takes the allocator).  Both honour the prefix, padding, zero flags and alignment of the
+    GstAllocationParams they are used with (the double's "pinned" memory is malloc memory, 16-byte aligned, so the
+    64-byte alignment really has to be made)."""
+    for launch, caps in (("bayer2rgb", B2R % ("rggb", 64, 48)), ("rgb2bayer", R2B % (64, 48)),
+                         ("hipupload", B2R % ("rggb", 64, 48))):
+        kv = run(rig, "allocation", launch, caps)
+        assert kv == {"query": "1", "pools": "1", "params": "1", "alloc_ok": "1", "pool_ok": "1"}, (launch, kv)
+    kv = run(rig, "allocation", "bayer2rgb pinned-pool=false", B2R % ("rggb", 64, 48))
+    assert kv["pools"] == "0" and kv["params"] == "0"
