@@ -771,9 +771,11 @@ typedef struct
   GstBaseTransform parent;
   GstVideoInfo info;
   gint width, height, r_off, g_off, b_off, format;
-  gint device_id;               /* properties device-id / batch: g_atomic_int_* */
-  mibayer_ctx *ctx;
+  gint device_id;               /* properties device-id / batch: g_atomic_int_*; -1 = follow the frames */
+  mibayer_ctx *ctx;             /* created at the first buffer, on the device its memory lives on */
   gint ctx_device;              /* the device the context was created on */
+  GstBufferPool *out_pool;      /* output frames, on the same device */
+  gint out_pool_device;
   /* batch mode (property "batch" > 1): input / output buffer pairs waiting for ONE launch over all of
    * them, and converted outputs waiting to be handed to the base class one by one */
   gint batch;
@@ -810,6 +812,16 @@ hb2r_drop_ctx (GstMiHipBayer2RGB * self)
   if (self->ctx) {
     mibayer_destroy (self->ctx);
     self->ctx = NULL;
+  }
+}
+
+static void
+hb2r_drop_out_pool (GstMiHipBayer2RGB * self)
+{
+  if (self->out_pool) {
+    gst_buffer_pool_set_active (self->out_pool, FALSE);
+    gst_object_unref (self->out_pool);
+    self->out_pool = NULL;
   }
 }
 
@@ -861,6 +873,7 @@ hb2r_finalize (GObject * object)
 {
   hb2r_drop_queued ((GstMiHipBayer2RGB *) object);
   hb2r_drop_ctx ((GstMiHipBayer2RGB *) object);
+  hb2r_drop_out_pool ((GstMiHipBayer2RGB *) object);
   G_OBJECT_CLASS (gst_mi_hip_bayer2rgb_parent_class)->finalize (object);
 }
 
@@ -916,9 +929,7 @@ hb2r_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
   GstStructure *s = gst_caps_get_structure (incaps, 0);
   const gchar *order = gst_structure_get_string (s, "format");
   GstVideoInfo info;
-  mibayer_cfg cfg;
   gint i;
-  int rc;
 
   if (!gst_structure_get_int (s, "width", &self->width)
       || !gst_structure_get_int (s, "height", &self->height) || !order)
@@ -942,6 +953,48 @@ hb2r_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
     return FALSE;
   }
 
+  /* the context and the output pool are (re)built at the next buffer, on the device
+   * that buffer lives on: the frames decide where the conversion runs */
+  hb2r_drop_ctx (self);
+  hb2r_drop_out_pool (self);
+  return TRUE;
+}
+
+/* The element works where its input lives: `hipupload device-id=N` (or any other
+ * producer of HIPMemory) chooses the GPU, hipbayer2rgb follows -- its context and
+ * its output pool are created on the device of the first frame.  device-id >= 0
+ * pins the element instead: frames from another GPU are then an error, not a
+ * silent cross-device access (the C ABI takes bare device pointers). */
+static gboolean
+hb2r_device_of (GstMiHipBayer2RGB * self, GstBuffer * inbuf, gint * device)
+{
+  GstMemory *mem = buffer_hip_memory (inbuf);
+  const gint pinned = g_atomic_int_get (&self->device_id);
+
+  if (mem == NULL) {
+    GST_ELEMENT_ERROR (self, CORE, NEGOTIATION,
+        ("hipbayer2rgb needs HIP device memory on both pads"), (NULL));
+    return FALSE;
+  }
+  *device = ((GstMiHipMemory *) mem)->device;
+  if (pinned >= 0 && pinned != *device) {
+    GST_ELEMENT_ERROR (self, CORE, NEGOTIATION,
+        ("hipbayer2rgb: buffers live on another GPU than device-id=%d", pinned),
+        ("input memory on HIP device %d; leave device-id at -1 to follow the "
+            "frames, or set the same device-id on hipupload", *device));
+    return FALSE;
+  }
+  return TRUE;
+}
+
+static gboolean
+hb2r_ensure_ctx (GstMiHipBayer2RGB * self, gint device)
+{
+  mibayer_cfg cfg;
+  int rc;
+
+  if (self->ctx != NULL && self->ctx_device == device)
+    return TRUE;
   hb2r_drop_ctx (self);
   memset (&cfg, 0, sizeof cfg);
   cfg.struct_size = sizeof cfg;
@@ -951,41 +1004,59 @@ hb2r_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
   cfg.r_off = self->r_off;
   cfg.g_off = self->g_off;
   cfg.b_off = self->b_off;
-  cfg.device = g_atomic_int_get (&self->device_id);
+  cfg.device = device;
   rc = mibayer_create (&cfg, &self->ctx);
   if (rc != MIBAYER_OK) {
     self->ctx = NULL;
     GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
-        ("hipbayer2rgb: cannot create GPU context"),
+        ("hipbayer2rgb: cannot create GPU context on device %d", device),
         ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
     return FALSE;
   }
-  self->ctx_device = cfg.device;
+  self->ctx_device = device;
   return TRUE;
 }
 
-static gboolean
-hb2r_decide_allocation (GstBaseTransform * trans, GstQuery * query)
+/* output frames come from the element's own device-memory pool on the device of
+ * the input (downstream sees the memory's device in the memory itself) */
+static GstFlowReturn
+hb2r_prepare_output_buffer (GstBaseTransform * trans, GstBuffer * inbuf,
+    GstBuffer ** outbuf)
 {
   GstMiHipBayer2RGB *self = (GstMiHipBayer2RGB *) trans;
-  GstCaps *caps = NULL;
-  gsize size = 0;
+  GstBaseTransformClass *klass = GST_BASE_TRANSFORM_GET_CLASS (trans);
+  GstFlowReturn ret;
+  gint device;
 
-  gst_query_parse_allocation (query, &caps, NULL);
-  if (caps && hb2r_get_unit_size (trans, caps, &size)) {
-    GstBufferPool *pool;
+  *outbuf = NULL;
+  if (!hb2r_device_of (self, inbuf, &device))
+    return GST_FLOW_ERROR;
+  if (self->out_pool == NULL || self->out_pool_device != device) {
+    GstCaps *caps = gst_pad_get_current_caps (GST_BASE_TRANSFORM_SRC_PAD (trans));
 
-    while (gst_query_get_n_allocation_pools (query) > 0)
-      gst_query_remove_nth_allocation_pool (query, 0);
-    pool = configured_pool (gst_mi_hip_pool_new (g_atomic_int_get
-            (&self->device_id)), caps, (guint) size, 2);
-    if (pool) {
-      gst_query_add_allocation_pool (query, pool, (guint) size, 2, 0);
-      gst_object_unref (pool);
+    hb2r_drop_out_pool (self);
+    if (caps == NULL)
+      return GST_FLOW_NOT_NEGOTIATED;
+    self->out_pool = configured_pool (gst_mi_hip_pool_new (device), caps,
+        (guint) ((gsize) 4 * self->width * self->height), 2);
+    gst_caps_unref (caps);
+    if (self->out_pool == NULL
+        || !gst_buffer_pool_set_active (self->out_pool, TRUE)) {
+      hb2r_drop_out_pool (self);
+      GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
+          ("hipbayer2rgb: cannot set up a device-memory pool on device %d",
+              device), ("%s", mibayer_last_hip_error ()));
+      return GST_FLOW_ERROR;
     }
+    self->out_pool_device = device;
   }
-  return GST_BASE_TRANSFORM_CLASS (gst_mi_hip_bayer2rgb_parent_class)->decide_allocation
-      (trans, query);
+  ret = gst_buffer_pool_acquire_buffer (self->out_pool, outbuf, NULL);
+  if (ret != GST_FLOW_OK)
+    return ret;
+  if (klass->copy_metadata != NULL
+      && !klass->copy_metadata (trans, inbuf, *outbuf))
+    GST_WARNING_OBJECT (self, "could not copy the buffer metadata");
+  return GST_FLOW_OK;
 }
 
 /* The C ABI takes bare device pointers: a frame that lives on another GPU, or a
@@ -997,24 +1068,21 @@ hb2r_map_pair (GstMiHipBayer2RGB * self, GstBuffer * inbuf, GstBuffer * outbuf,
     GstMemory ** in_mem, GstMemory ** out_mem, GstMapInfo * in_map,
     GstMapInfo * out_map)
 {
+  gint device;
+
   *in_mem = buffer_hip_memory (inbuf);
   *out_mem = buffer_hip_memory (outbuf);
-  if (!*in_mem || !*out_mem || !self->ctx) {
+  if (!hb2r_device_of (self, inbuf, &device))
+    return FALSE;
+  if (!*out_mem || ((GstMiHipMemory *) * out_mem)->device != device) {
     GST_ELEMENT_ERROR (self, CORE, NEGOTIATION,
-        ("hipbayer2rgb needs HIP device memory on both pads"), (NULL));
+        ("hipbayer2rgb: input and output frames must live on one GPU"),
+        ("input memory on HIP device %d, output %s", device,
+            *out_mem ? "on another device" : "not in HIP device memory"));
     return FALSE;
   }
-  if (((GstMiHipMemory *) * in_mem)->device != self->ctx_device
-      || ((GstMiHipMemory *) * out_mem)->device != self->ctx_device) {
-    GST_ELEMENT_ERROR (self, CORE, NEGOTIATION,
-        ("hipbayer2rgb: buffers live on another GPU than device-id=%d",
-            self->ctx_device),
-        ("input memory on HIP device %d, output memory on %d; set the same "
-            "device-id on hipupload and hipbayer2rgb",
-            ((GstMiHipMemory *) * in_mem)->device,
-            ((GstMiHipMemory *) * out_mem)->device));
+  if (!hb2r_ensure_ctx (self, device))
     return FALSE;
-  }
   if (!gst_memory_map (*in_mem, in_map,
           GST_MAP_READ | GST_MAP_HIP | GST_MAP_HIP_ASYNC))
     return FALSE;
@@ -1186,6 +1254,20 @@ hb2r_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
       gst_buffer_unref (inbuf);
       return ret == GST_FLOW_OK ? GST_FLOW_ERROR : ret;
     }
+    /* frames of one list launch share a context: a frame from another GPU
+     * (upstream switched devices) first converts what is waiting */
+    {
+      gint device = 0;
+
+      if (hb2r_device_of (self, inbuf, &device) && self->ctx != NULL
+          && self->ctx_device != device && !g_queue_is_empty (&self->waiting))
+        ret = hb2r_convert_waiting (self);
+      if (ret != GST_FLOW_OK) {
+        gst_buffer_unref (inbuf);
+        gst_buffer_unref (out);
+        return ret;
+      }
+    }
     pair = g_new0 (Hb2rPair, 1);
     pair->in = inbuf;
     pair->out = out;
@@ -1240,6 +1322,7 @@ hb2r_stop (GstBaseTransform * trans)
 {
   hb2r_drop_queued ((GstMiHipBayer2RGB *) trans);
   hb2r_drop_ctx ((GstMiHipBayer2RGB *) trans);
+  hb2r_drop_out_pool ((GstMiHipBayer2RGB *) trans);
   ((GstMiHipBayer2RGB *) trans)->prerolled = FALSE;
   return TRUE;
 }
@@ -1255,8 +1338,11 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
   object_class->get_property = hb2r_get_property;
   object_class->finalize = hb2r_finalize;
   g_object_class_install_property (object_class, PROP_DEVICE_ID,
-      g_param_spec_int ("device-id", "Device ID", "HIP ordinal of the MI355X",
-          0, G_MAXINT, 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+      g_param_spec_int ("device-id", "Device ID",
+          "HIP ordinal of the MI355X; -1 = convert on whichever GPU the incoming "
+          "frames live on (hipupload's device-id decides).  A value >= 0 pins the "
+          "element: frames from another GPU are then refused",
+          -1, G_MAXINT, -1, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_BATCH,
       g_param_spec_int ("batch", "Frames per launch",
           "Convert this many queued frames with ONE kernel launch (each frame "
@@ -1272,8 +1358,8 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
   transform_class->transform_caps = GST_DEBUG_FUNCPTR (hb2r_transform_caps);
   transform_class->get_unit_size = GST_DEBUG_FUNCPTR (hb2r_get_unit_size);
   transform_class->set_caps = GST_DEBUG_FUNCPTR (hb2r_set_caps);
-  transform_class->decide_allocation =
-      GST_DEBUG_FUNCPTR (hb2r_decide_allocation);
+  transform_class->prepare_output_buffer =
+      GST_DEBUG_FUNCPTR (hb2r_prepare_output_buffer);
   transform_class->transform = GST_DEBUG_FUNCPTR (hb2r_transform);
   transform_class->generate_output = GST_DEBUG_FUNCPTR (hb2r_generate_output);
   transform_class->sink_event = GST_DEBUG_FUNCPTR (hb2r_sink_event);
@@ -1284,9 +1370,11 @@ static void
 gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
 {
   gst_video_info_init (&self->info);
-  self->device_id = 0;
+  self->device_id = -1;
   self->ctx = NULL;
   self->ctx_device = 0;
+  self->out_pool = NULL;
+  self->out_pool_device = 0;
   self->batch = 1;
   self->prerolled = FALSE;
   g_queue_init (&self->waiting);

@@ -318,6 +318,10 @@ mibayer_create (const mibayer_cfg * cfg, mibayer_ctx ** out)
     return MIBAYER_ERR_ARG;
   if (mibayer_device_count () <= 0)
     return MIBAYER_ERR_NO_DEVICE;
+  if (cfg->device >= mibayer_device_count ())
+    return MIBAYER_ERR_NO_DEVICE;
+  if (getenv ("MOCK_MIBAYER_LOG_DEVICES"))
+    fprintf (stderr, "mock_mibayer: context on device %d\n", cfg->device);
   inverse = (cfg->flags & MIBAYER_FLAG_RGB2BAYER) != 0;
   /* the real library's geometry domain for bayer2rgb */
   if (!inverse && (cfg->width < 4 || (cfg->width & 1) || cfg->height < 3))

@@ -352,19 +352,27 @@ def test_asynchronous_download_pushes_a_frame_only_when_its_copy_is_done(rig, tm
     assert kv["cycles_ok"] == "3"
 
 
-def test_hipbayer2rgb_refuses_frames_that_live_on_another_gpu(rig):
-    """The C ABI takes bare device pointers, so a frame uploaded to GPU 1 must not reach a context on GPU 0:
-    hipbayer2rgb compares the memory's device with its context's and posts a NEGOTIATION error instead of launching;
-    with matching ordinals the same pipeline runs."""
+def test_hipbayer2rgb_follows_the_frames_and_refuses_another_gpu_when_pinned(rig):
+    """The C ABI takes bare device pointers, so a frame uploaded to GPU 1 must never reach a context on GPU 0
+    (ADVICE r01).  hipbayer2rgb works where its input lives: with device-id left at -1 its context and output pool are
+    created on the device of the incoming frames (only hipupload needs a device-id); pinned to another ordinal it posts
+    a NEGOTIATION error instead of launching."""
     exe, env, _ = rig
-    desc = ("videotestsrc num-buffers=3 ! video/x-bayer,format=rggb,width=64,height=48 ! hipupload device-id=%d ! "
-            "hipbayer2rgb device-id=%d ! hipdownload ! fakesink")
+    src = "videotestsrc num-buffers=5 ! video/x-bayer,format=rggb,width=64,height=48 ! "
     two = dict(env, MOCK_MIBAYER_DEVICES="2")
-    res = subprocess.run([exe, "states", desc % (1, 0), "1"], capture_output=True, text=True, env=two, timeout=60)
+    res = subprocess.run([exe, "states", src + "hipupload device-id=1 ! hipbayer2rgb device-id=0 ! hipdownload ! fakesink",
+                          "1"], capture_output=True, text=True, env=two, timeout=60)
     out = res.stdout + res.stderr
     assert res.returncode != 0 and "another GPU" in out and "AddressSanitizer" not in out, out[-2000:]
-    kv = run(rig, "states", desc % (1, 1), 1, extra_env={"MOCK_MIBAYER_DEVICES": "2"})
-    assert kv["cycles_ok"] == "1"
+    for tail in ("hipupload device-id=1 ! hipbayer2rgb device-id=1 ! hipdownload ! fakesink",
+                 "hipupload device-id=1 ! hipbayer2rgb ! hipdownload ! fakesink",
+                 "hipupload device-id=1 ! hipbayer2rgb batch=4 ! hipdownload ! fakesink",
+                 "hipupload ! hipbayer2rgb ! fakesink"):
+        kv = run(rig, "states", src + tail, 2, extra_env={"MOCK_MIBAYER_DEVICES": "2"})
+        assert kv["cycles_ok"] == "2", tail
+    res = subprocess.run([exe, "states", src + "hipupload device-id=1 ! hipbayer2rgb ! hipdownload ! fakesink", "1"],
+                         capture_output=True, text=True, env=dict(two, MOCK_MIBAYER_LOG_DEVICES="1"), timeout=60)
+    assert res.returncode == 0 and "context on device 1" in res.stderr and "context on device 0" not in res.stderr
 
 
 def test_the_allocation_query_offers_a_pinned_pool_and_its_allocator(rig):
