@@ -123,7 +123,7 @@ int main (int argc, char **argv)
   if (argc > 2 && argv[2][0] == 'a') {
     /* arena mode: ONE allocation (physically contiguous if the driver grants it), the source at its start, the destination
      * slid through it in 128 MiB steps -- is the state a function of the distance between the two streams? */
-    const size_t step = (size_t) 128 << 20, first = (size_t) 1 << 30;
+    const size_t step = (size_t) (argc > 4 ? atoi (argv[4]) : 128) << 20, first = (size_t) (argc > 5 ? atoi (argv[5]) : 1024) << 20;
     const int npos = argc > 3 ? atoi (argv[3]) : 36;
     const size_t arena_bytes = first + (size_t) npos * step + N * db;
     char *arena = nullptr;
