@@ -25,7 +25,7 @@ plugin_init (GstPlugin * plugin)
   return ok;
 }
 
-GST_PLUGIN_DEFINE (GST_VERSION_MAJOR, GST_VERSION_MINOR, bayer,
+GST_PLUGIN_DEFINE (GST_VERSION_MAJOR, GST_VERSION_MINOR, MIBAYER_PLUGIN_NAME,
     "Elements to convert Bayer images", plugin_init, VERSION, "LGPL",
     "gst-plugins-bad_amd (MI355X-native bayer2rgb)",
     "https://gstreamer.freedesktop.org/")

@@ -30,7 +30,7 @@ GType gst_bayer2rgb_get_type (void);
   "video/x-bayer,format=(string){bggr,grbg,gbrg,rggb}," \
   "width=(int)[1,MAX],height=(int)[1,MAX],framerate=(fraction)[0/1,MAX]"
 
-G_DEFINE_TYPE (GstBayer2RGB, gst_bayer2rgb, GST_TYPE_BASE_TRANSFORM);
+MI_DEFINE_ELEMENT_TYPE (GstBayer2RGB, gst_bayer2rgb, MIBAYER_TYPE_NAME ("Bayer2RGB"));
 
 static void
 gst_bayer2rgb_class_init (GstBayer2RGBClass * klass)
@@ -66,6 +66,6 @@ gst_bayer2rgb_register (GstPlugin * plugin)
 {
   /* GST_ELEMENT_REGISTER (bayer2rgb, plugin) in the reference (:149-150,
    * gstbayer.c:33); spelled out so that it also builds against GStreamer < 1.20 */
-  return gst_element_register (plugin, "bayer2rgb", GST_RANK_NONE,
+  return gst_element_register (plugin, MIBAYER_FACTORY ("bayer2rgb"), GST_RANK_NONE,
       gst_bayer2rgb_get_type ());
 }

@@ -29,7 +29,7 @@ GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
     GST_STATIC_CAPS ("video/x-bayer,format=(string){bggr,gbrg,grbg,rggb},"
         "width=[1,MAX],height=[1,MAX],framerate=(fraction)[0/1,MAX]"));
 
-G_DEFINE_TYPE (GstRGB2Bayer, gst_rgb2bayer, GST_TYPE_BASE_TRANSFORM);
+MI_DEFINE_ELEMENT_TYPE (GstRGB2Bayer, gst_rgb2bayer, MIBAYER_TYPE_NAME ("RGB2Bayer"));
 
 static void
 gst_rgb2bayer_class_init (GstRGB2BayerClass * klass)
@@ -58,6 +58,6 @@ gboolean
 gst_rgb2bayer_register (GstPlugin * plugin)
 {
   /* reference gstrgb2bayer.c:80-81, gstbayer.c:34 */
-  return gst_element_register (plugin, "rgb2bayer", GST_RANK_NONE,
+  return gst_element_register (plugin, MIBAYER_FACTORY ("rgb2bayer"), GST_RANK_NONE,
       gst_rgb2bayer_get_type ());
 }

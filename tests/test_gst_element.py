@@ -85,6 +85,43 @@ def test_factory_details_match_reference(plugin, tmp_path):
     assert out.count("Availability: Always") == 2
 
 
+@pytest.fixture(scope="module")
+def side_by_side(plugin):
+    """`make side-by-side`: the same plugin under its own names (plugin mibayer, factories mibayer2rgb / mirgb2bayer)."""
+    res = subprocess.run(["make", "-C", PKG_DIR, "side-by-side"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    return os.path.join(PKG_DIR, "libgstmibayer.so")
+
+
+@needs_gst
+def test_side_by_side_build_coexists_with_the_drop_in_names(side_by_side, tmp_path):
+    """a registry that also holds a stock gst-plugins-bad keeps only one plugin `bayer`; the
+    side-by-side build registers the same elements as plugin `mibayer` / `mibayer2rgb` / `mirgb2bayer` with GType names
+    of their own, so both can be loaded into one process for A/B runs.  Everything but the names is the same code:
+    the factory details differ from the drop-in build's in the names only."""
+    env = gst_env(tmp_path)
+
+    def inspect(what):
+        return subprocess.run([GST_INSPECT, what], capture_output=True, text=True, env=env, timeout=120).stdout
+
+    plug = inspect("mibayer")
+    assert "mibayer2rgb: Bayer to RGB decoder for cameras" in plug and "mirgb2bayer:" in plug
+    assert "libgstmibayer.so" in plug
+    assert "libgstbayer.so" in inspect("bayer")                     # the drop-in plugin is still there
+    for ours, stock, tname in (("mibayer2rgb", "bayer2rgb", "Bayer2RGB"), ("mirgb2bayer", "rgb2bayer", "RGB2Bayer")):
+        a, b = inspect(ours), inspect(stock)
+        assert "GstMi" + tname in a and "Gst" + tname in b
+
+        def neutral(text):
+            keep = []
+            for line in text.splitlines():
+                if "Filename" in line or line.strip().startswith("Name "):
+                    continue
+                keep.append(line.replace("GstMi" + tname, "Gst" + tname).replace(ours, stock).replace("mibayer", "bayer"))
+            return keep
+        assert neutral(a) == neutral(b), ours
+
+
 @needs_gst
 def test_without_gpu_the_element_errors_instead_of_falling_back(plugin, pkg, tmp_path):
     if pkg.device_count() > 0:
@@ -253,6 +290,18 @@ def test_pinned_pools_are_proposed_and_used(plugin, gpu_pkg, oracle, tmp_path):
                           timeout=300)
     assert res2.returncode == 0, res2.stderr[-2000:]
     assert open(outp, "rb").read() == open(out2, "rb").read()
+
+
+@pytest.mark.gpu
+@needs_gst
+def test_side_by_side_elements_produce_the_same_bytes(side_by_side, gpu_pkg, tmp_path):
+    """Both builds in ONE process (tee): bayer2rgb and mibayer2rgb write identical frames."""
+    a, b = str(tmp_path / "a.raw"), str(tmp_path / "b.raw")
+    res = launch(tmp_path, "videotestsrc num-buffers=4 ! video/x-bayer,format=grbg,width=320,height=240 ! tee name=t "
+                           "t. ! queue ! bayer2rgb ! video/x-raw,format=BGRx ! filesink location=%s "
+                           "t. ! queue ! mibayer2rgb inflight=2 ! video/x-raw,format=BGRx ! filesink location=%s" % (a, b))
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert os.path.getsize(a) == 4 * 320 * 240 * 4 and open(a, "rb").read() == open(b, "rb").read()
 
 
 @pytest.mark.gpu
