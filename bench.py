@@ -285,6 +285,13 @@ class ControlPlane:
     def all_reduce(self, t, op):
         self._d.all_reduce(t, op=op, group=self._g)
 
+    def gather_objects(self, obj):
+        """One small host object per rank, for the per-GPU breakdown of the JSON line; always over the gloo bootstrap
+        group (the default group), whatever carries the barriers."""
+        out = [None] * self._d.get_world_size()
+        self._d.all_gather_object(out, obj)
+        return out
+
     def destroy_process_group(self):
         self._d.destroy_process_group()
 
@@ -485,6 +492,12 @@ def run(args):
     # the unwrapped bench line says null and carries the last profiled figure under its own name, with the
     # plan, the box and the build it was taken on (tools/summarize_profiles.py writes the file)
     result["roofline"]["traffic_profiled"] = profiled_traffic(ctx0.launch_geometry(BATCH)["band"])
+    if dist is not None:
+        # per-GPU breakdown (SURVEY.md section 5 "metrics"): `roofline` above is rank 0's kernel, this is every rank's
+        mine = {"rank": rank, "device": local_rank, "kernel_ms": round(kernel_ms, 4),
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "kernel_variant": ctx0.variant_name,
+                "band": ctx0.launch_geometry(BATCH)["band"], "parity": parity}
+        result["per_gpu"] = dist.gather_objects(mine)
     if rank == 0 and world == 1:
         if not args.no_host_path:
             for c in ctxs.values():

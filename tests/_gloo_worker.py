@@ -24,8 +24,12 @@ def main():
         time.sleep(0.02 * (rank + 1))       # rank 1 is the slow one: max-over-ranks must see it
 
     elapsed = bench.timed_region(step, steps=5, warmup=2, sync_fn=lambda: None, dist=dist)
+    # the per-GPU breakdown travels over the bootstrap group, as in bench.run()
+    plane = bench.ControlPlane(dist, None, "gloo", 0)
+    gathered = plane.gather_objects({"rank": rank, "kernel_ms": 0.4 + rank})
     with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
-        json.dump({"rank": rank, "world": world, "frames": frames, "calls": calls, "elapsed": elapsed}, f)
+        json.dump({"rank": rank, "world": world, "frames": frames, "calls": calls, "elapsed": elapsed,
+                   "gathered": gathered}, f)
     dist.barrier()
     dist.destroy_process_group()
 

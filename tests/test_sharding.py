@@ -49,3 +49,6 @@ def test_gloo_world_size_2(tmp_path):
     # both ranks report the same, slowest-rank time: rank 1 sleeps 40 ms/step
     assert abs(r[0]["elapsed"] - r[1]["elapsed"]) < 1e-9
     assert r[0]["elapsed"] >= 5 * 0.04 * 0.9
+    # per-GPU breakdown: every rank sees every rank's entry, in rank order
+    want = [{"rank": 0, "kernel_ms": 0.4}, {"rank": 1, "kernel_ms": 1.4}]
+    assert r[0]["gathered"] == want and r[1]["gathered"] == want
