@@ -4,7 +4,7 @@
 only stamps every output frame with its submission number and the first byte of its input -- and it touches
 every source and destination byte at *wait* time, the moment the real library finishes its asynchronous work, so a
 buffer that the element unmapped or released too early is a sanitizer report.  The element sources
-(gst-plugins-bad_amd/gst/*.c), the double and the GstHarness driver are built with -fsanitize=address into a
+(gst-plugins-bad_amd/gst/*.c), the double and the GstHarness driver are built with -fsanitize=address,undefined into a
 temporary directory; the shipped libraries are not involved.
 
 Covered: buffer ownership and order in the synchronous and the queued mode, EOS drain, flush drop, mid-stream
@@ -24,7 +24,7 @@ pytestmark = [needs_gst]
 
 INC = ["-I" + os.path.join(ROOT, "include"), "-I%s/include/gstreamer-1.0" % GST_PREFIX,
        "-I%s/include/glib-2.0" % GST_PREFIX, "-I%s/lib/glib-2.0/include" % GST_PREFIX]
-SAN = ["-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer", "-Wall"]
+SAN = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-Wall"]
 # GStreamer's libraries by full path, NOT -L<prefix>/lib: that directory also holds an old libasan which the sanitizer
 # link would otherwise pick instead of the compiler's own
 GSTLIBS = ["%s/lib/lib%s.so" % (GST_PREFIX, n) for n in ("gstvideo-1.0", "gstbase-1.0", "gstreamer-1.0",
