@@ -15,9 +15,9 @@ CSRC = os.path.join(ROOT, "gst-plugins-bad_amd", "csrc")
 CHECK = os.path.join(ROOT, "tests", "check")
 
 
-@pytest.fixture(scope="module", params=["address", "thread"])
+@pytest.fixture(scope="module", params=["address,undefined", "thread"])
 def driver(request, tmp_path_factory):
-    d = str(tmp_path_factory.mktemp("poollogic_" + request.param))
+    d = str(tmp_path_factory.mktemp("poollogic_" + request.param.replace(",", "_")))
     san = ["-O1", "-g", "-fsanitize=" + request.param, "-fno-omit-frame-pointer", "-Wall"]
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     obj = os.path.join(d, "mock.o")
