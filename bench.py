@@ -83,6 +83,19 @@ def aggregate_mpix_per_s(pixels_per_step_per_rank, world_size, steps, elapsed_s)
 # CPU baseline (oracle) -- reported beside the GPU number, never the thing optimised
 # ----------------------------------------------------------------------------------------------
 
+def stock_element_note():
+    """BASELINE.md section 4 "optional": where a stock gst-plugins-bad `bayer2rgb` (the literal ORC element) is installed on
+    the box it would be timed through `filesrc ! bayer2rgb ! fakesink`; this image ships GStreamer 1.14 without
+    gst-plugins-bad and without liborc, so the line only says so (the reference cannot travel to the GPU box)."""
+    prefix = os.environ.get("GST_PREFIX", "/opt/conda")
+    for d in (os.path.join(prefix, "lib", "gstreamer-1.0"), "/usr/lib/x86_64-linux-gnu/gstreamer-1.0",
+              "/usr/lib64/gstreamer-1.0"):
+        if os.path.exists(os.path.join(d, "libgstbayer.so")):
+            return {"installed": True, "path": os.path.join(d, "libgstbayer.so"),
+                    "note": "present but not timed: no pipeline leg for it in this harness yet"}
+    return {"installed": False, "note": "no stock gst-plugins-bad bayer plugin (nor liborc) on this box"}
+
+
 def cpu_baseline(budget_s=12.0, sample_frames=32):
     """Four legs on this box's host cores, all on the same 32 frames, all byte-identical restatements of the
     reference path (tests/test_oracle.py):
@@ -160,6 +173,7 @@ def cpu_baseline(budget_s=12.0, sample_frames=32):
                               "host core), several passes per thread creation, output pages first touched by the "
                               "thread that writes them" % (sample_frames, nbands, sample_frames * nbands, ncores)},
         "reference_c_path": ref,
+        "stock_orc_element": stock_element_note(),
     }
 
 
