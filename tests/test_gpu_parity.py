@@ -467,6 +467,75 @@ def test_pool_drops_a_failed_device_and_redoes_its_frames(gpu_pkg, oracle, memor
                 L.mibayer_host_free(pd)
 
 
+def test_pool_failover_randomised_drills(gpu_pkg, oracle):
+    """Seeded drills on real hardware: 2-6 logical shards, 1-3 frames in flight each, pinned or pageable frames (or a
+    mix: shards switch to their helper thread one by one), one to all-but-one shards failing after random frame counts.
+    Every frame comes back once, in order, bit-exact; one report per dropped shard; the survivors carry on."""
+    rng = np.random.default_rng(int(os.environ.get("MIBAYER_FUZZ_SEED", "4242")))
+    w, h = 642, 50                      # small frames (and the generic kernel): the drill is about the pool
+    L = gpu_pkg.lib()
+    ndev = gpu_pkg.device_count()
+    for drill in range(int(os.environ.get("MIBAYER_FUZZ_DRILLS", "12"))):
+        nshards = int(rng.integers(2, 7))
+        inflight = int(rng.integers(1, 4))
+        n = int(rng.integers(20, 60))
+        memory = ("pinned", "pageable", "mixed")[int(rng.integers(0, 3))]
+        nfail = int(rng.integers(1, nshards))
+        failing = sorted(rng.choice(nshards, size=nfail, replace=False).tolist())
+        after = {s_: int(rng.integers(0, 8)) for s_ in failing}
+        order_name = PATTERNS[int(rng.integers(0, 4))]
+        stride = (w + 3) & ~3
+        src = oracle.fill_synthetic(w, h, n, seed=200 + drill, stride=stride)
+        want = oracle.bayer2rgb_batch(src, w, order_name, 2, 1, 0, nthreads=2)
+        what = (drill, nshards, inflight, n, memory, after)
+        with gpu_pkg.Pool([i % ndev for i in range(nshards)], w, h, order_name, "BGRx", inflight=inflight) as pool:
+            cap0 = pool.capacity
+            bufs, pinned = [], []
+            for k in range(cap0):
+                if memory == "pinned" or (memory == "mixed" and rng.integers(0, 2)):
+                    a, b = _pinned(L, stride * h, (h, stride)), _pinned(L, 4 * w * h, (h, 4 * w))
+                    pinned += [a[0], b[0]]
+                    bufs.append((a[1], b[1]))
+                else:
+                    bufs.append((np.empty((h, stride), np.uint8), np.empty((h, 4 * w), np.uint8)))
+            for s_, k in after.items():
+                pool.inject_fault(s_, k)
+            outs, order, reports = {}, [], 0
+
+            def collect():
+                nonlocal reports
+                t = pool.wait()
+                order.append(t)
+                outs[t - 1] = bufs[(t - 1) % cap0][1].copy()
+                reports += pool.take_failure()[0]
+
+            for i in range(n):
+                s_arr, d_arr = bufs[i % cap0]
+                while True:
+                    if pool.pending() >= min(cap0, lib_capacity(gpu_pkg, pool)):
+                        collect()
+                        continue
+                    s_arr[:] = src[i]
+                    d_arr[:] = 0
+                    try:
+                        pool.submit(s_arr, d_arr, tag=i + 1)
+                        break
+                    except gpu_pkg.MibayerError as e:
+                        assert e.status == gpu_pkg.ERR_BUSY, what
+                        collect()
+            while pool.pending():
+                collect()
+            reports += pool.take_failure()[0]
+            assert order == list(range(1, n + 1)), what
+            for i in range(n):
+                assert np.array_equal(outs[i], want[i]), (what, i)
+            # a shard that never reached its failure point is still alive; every drop was reported exactly once
+            assert pool.alive() == nshards - reports and 0 <= reports <= nfail, what
+            assert pool.alive() >= nshards - nfail >= 1, what
+        for p_ in pinned:
+            L.mibayer_host_free(p_)
+
+
 def lib_capacity(gpu_pkg, pool):
     return gpu_pkg.lib().mibayer_pool_capacity(pool._h)
 
