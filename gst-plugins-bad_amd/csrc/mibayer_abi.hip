@@ -208,6 +208,9 @@ struct mibayer_ctx {
   int num_cus = 256;                    /* hipDeviceProp_t.multiProcessorCount */
   int persist_wgs_per_cu = 4;           /* MIBAYER_PERSIST_WGS (tuning), persistent arms */
   bool rows_off_sector = false;         /* dst_stride % 64 != 0: see plain_store_twin () */
+  int align_stores = 64;                /* generic geometries with output rows off the sector grid: boundary (bytes)
+                                           every wave-store starts on (bayer2rgb_lds_aligned_kernel); 0 = the
+                                           unshifted generic arm.  MIBAYER_ALIGN_STORES = 0 | 64 | 128 */
   int graph_mode = 0;                   /* MIBAYER_FLAG_HIPGRAPH: 0 = the compute-queue segment of a frame as
                                            a graph per slot (default), 1 = the whole upload -> kernel ->
                                            download chain as a graph per slot on the slot's own queue
@@ -370,14 +373,27 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
     return MIBAYER_ERR_GEOMETRY;
   const mibayer_cfg &f = c->cfg;
   /* pointers_aligned16 >= 0: a list launch, whose caller has looked at every
-   * frame pointer itself (frame strides do not apply) */
+   * frame pointer itself (frame strides do not apply): 1 = all 16-byte aligned,
+   * 2 = every destination 8-byte aligned, 0 = neither */
   const bool fast = (f.width % 16 == 0) && (f.src_stride % 16 == 0)
       && (f.dst_stride % 16 == 0)
-      && (pointers_aligned16 >= 0 ? pointers_aligned16 != 0
+      && (pointers_aligned16 >= 0 ? pointers_aligned16 == 1
           : (aligned16 (d_src) && aligned16 (d_dst)
               && (nframes == 1 || (src_frame_bytes % 16 == 0
                       && dst_frame_bytes % 16 == 0))));
   kern = fast ? c->var->fast : c->var->generic;
+  if (!fast && c->align_stores && c->var->aligned64) {
+    /* output rows off the sector grid, all of them 8-byte aligned (even per-row shifts): the sector-aligned arm */
+    const bool rows8 = (f.dst_stride % 8 == 0)
+        && (pointers_aligned16 >= 0 ? pointers_aligned16 >= 1
+            : ((((uintptr_t) d_dst) & 7u) == 0 && (nframes == 1 || dst_frame_bytes % 8 == 0)));
+    const unsigned a = (unsigned) c->align_stores;
+    const bool on_grid = (f.dst_stride % a == 0)
+        && (pointers_aligned16 >= 0 ? false
+            : ((((uintptr_t) d_dst) & (a - 1)) == 0 && (nframes == 1 || dst_frame_bytes % a == 0)));
+    if (rows8 && !on_grid)
+      kern = c->align_stores == 128 ? c->var->aligned128 : c->var->aligned64;
+  }
   /* The variant's default band map is dropped for the identity order in two cases
    * (profiles/r01_sweep_narrow_frames.log, r01_sweep_tile_multiple_widths.log):
    *  - one tile per row: every band map degenerates to the identity order, and the
@@ -647,6 +663,10 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
     c->band_override = atoi (e);
   if (const char *e = getenv ("MIBAYER_START_SLEEP"))
     c->start_sleep = atoi (e) >= 0 ? atoi (e) : -1;
+  if (const char *e = getenv ("MIBAYER_ALIGN_STORES")) {
+    const int a = atoi (e);
+    c->align_stores = (a == 64 || a == 128) ? a : 0;
+  }
   if (const char *e = getenv ("MIBAYER_R2B_FLAT"))
     c->r2b_flat_k = atoi (e);
   if (const char *e = getenv ("MIBAYER_R2B_PX"))
@@ -1457,15 +1477,17 @@ extern "C" int mibayer_process_device_list (mibayer_ctx *c,
   }
   for (int f0 = 0; f0 < nframes; f0 += kMaxList) {
     const int n = nframes - f0 < kMaxList ? nframes - f0 : kMaxList;
-    bool all16 = true;
-    for (int f = 0; f < n; f++)
+    bool all16 = true, dst8 = true;
+    for (int f = 0; f < n; f++) {
       all16 = all16 && aligned16 (d_srcs[f0 + f]) && aligned16 (d_dsts[f0 + f]);
+      dst8 = dst8 && (((uintptr_t) d_dsts[f0 + f]) & 7u) == 0;
+    }
     KParams p;
     KernelFn kern;
     unsigned grid;
     /* planned as a batch of n frames; the 16-byte path needs every pointer aligned */
     const int rc = plan_launch (c, d_srcs[f0], c->src_bytes, d_dsts[f0],
-        c->dst_bytes, n, p, kern, grid, nullptr, 0, -1, all16 ? 1 : 0);
+        c->dst_bytes, n, p, kern, grid, nullptr, 0, -1, all16 ? 1 : (dst8 ? 2 : 0));
     if (rc != MIBAYER_OK)
       return rc;
     p.src = nullptr;
@@ -1549,16 +1571,18 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
   /* candidate plans: {configured shape, one other production shape under
    * "auto"} x {band 1, one chunk per XCD, identity}; the band orders carry the
    * automatic start delay */
-  const Variant *shapes[3] = { c->var, nullptr, nullptr };
+  constexpr int kMaxShapes = 3;
+  const Variant *shapes[kMaxShapes] = { c->var, nullptr, nullptr };
   int nshapes = 1;
   if (c->cfg.variant == 0) {
-    /* the other production shapes (1024x8, 512x16, 256x32 px tiles), with plain
-     * stores where the output rows sit off the sector grid */
-    for (int v = 3; v >= 1; v--) {
-      const Variant *cand = &variant (c->rows_off_sector ? plain_store_twin (v) : v);
-      if (c->var != cand)
-        shapes[nshapes++] = cand;
-    }
+    /* the other production shapes (1024x8, 512x16, 256x32 px tiles), with plain stores where the context's own
+     * plan has them.  The configured shape stands for its own production id whichever store policy it carries
+     * (mibayer_create keeps the nt variant for rows that fit one tile), so at most two others join it. */
+    const int own = production_shape_of ((int) (c->var - &variant (0)));
+    const bool plain = own != (int) (c->var - &variant (0));
+    for (int v = 3; v >= 1 && nshapes < kMaxShapes; v--)
+      if (v != own)
+        shapes[nshapes++] = &variant (plain ? plain_store_twin (v) : v);
   }
   const bool band_forced = getenv ("MIBAYER_XCD_BAND") != NULL;
   const int bands[3] = { 1, -1, 0 };
@@ -1572,7 +1596,7 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
    * reason alone), one slow round (another process, a DVFS step) must not
    * decide the plan, and neither may one lucky round -- the plan has to be the
    * one that is fastest in steady state, which is what the caller then runs. */
-  constexpr int kRounds = 5, kWarm = 16, kReps = 6, kCands = 9;
+  constexpr int kRounds = 5, kWarm = 16, kReps = 6, kCands = 3 * kMaxShapes;
   constexpr double kWarmMs = 60.0;
   float round_ms[kCands][kRounds];
   float cand_ms[kCands];

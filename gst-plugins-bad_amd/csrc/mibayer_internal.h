@@ -168,6 +168,11 @@ struct Variant {
                                    CU-count-sized grid that loops over the tiles */
   void (*fast) (KParams);       /* W%16==0, 16-byte aligned rows both sides */
   void (*generic) (KParams);    /* any even W >= 4, 4-byte aligned rows     */
+  /* generic geometry whose output rows start off the 64-byte sector grid: every wave-store starts on a
+   * 64- / 128-byte boundary (per-row lane shift, mibayer_kernels.hip); needs 8-byte aligned output rows.
+   * nullptr: the variant has no such arm */
+  void (*aligned64) (KParams);
+  void (*aligned128) (KParams);
 };
 
 int variant_count ();
@@ -176,6 +181,7 @@ int resolve_variant (int id, int width);        /* 0 ("auto") -> a concrete id *
 /* the plain-store (write-back) arm of a production shape (ids 1-3), for output rows that start off a
  * 64-byte sector; any other id is returned unchanged */
 int plain_store_twin (int id);
+int production_shape_of (int id);               /* the inverse: 20 -> 1, 21 -> 2, 4 -> 3 */
 
 /* rgb2bayer (reference gst/bayer/gstrgb2bayer.c:230-278) */
 struct R2BParams {

@@ -442,6 +442,207 @@ bayer2rgb_lds_kernel (KParams p)
   }
 }
 
+/* a source dword at 2-byte alignment out of the LDS tile (gfx950 DS reads need no more) */
+typedef uint32_t u32_a2 __attribute__ ((aligned (2)));
+
+/* (E,O) of the four columns whose source bytes start at q (LDS, 2-byte aligned); lanes 0 / 63 take the dword
+ * left / right of the wave's columns from q + edge_off.  EDGE = false: no frame edge in this wave */
+template <bool EDGE>
+__device__ __forceinline__ Lines shifted_lines (const uint8_t *q, int edge_off,
+    int x, int width)
+{
+  const uint32_t c = *(const u32_a2 *) q;
+  const uint32_t edge = *(const u32_a2 *) (q + edge_off);
+  const uint32_t cl = from_lane_below (edge, c);
+  const uint32_t cr = from_lane_above (edge, c);
+  if constexpr (EDGE) {
+    const int lastmode = (x + 4 == width) ? 1 : ((x + 2 == width) ? 2 : 0);
+    return row_lines<true, true> (c, cl, cr, x == 0, lastmode);
+  } else {
+    return row_lines<true, false> (c, cl, cr, false, 0);
+  }
+}
+
+template <int ST>
+__device__ __forceinline__ void store_aligned16 (uint8_t *p, u32x4 px)
+{
+  if constexpr ((ST & 7) == 1)
+    __builtin_nontemporal_store (px, (u32x4 *) p);
+  else
+    *(u32x4 *) p = px;
+}
+
+/* ------------------------------------------------------------------------- */
+/* LDS-staged tile kernel, sector-aligned stores (generic geometries)          */
+/* ------------------------------------------------------------------------- */
+/* Output rows that do not start on a 64-byte sector (dst_stride % 64 != 0: every width % 16 != 0, e.g. 4056-,
+ * 3838-, 1366-px frames).  In the kernel above a lane owns the SAME four columns in every row, so the 1 KiB a wave
+ * stores per row starts wherever the row starts: each wave-store ends in a partial sector that a neighbouring wave
+ * (or workgroup, or XCD) completes later.  Here the lane -> column map is shifted PER ROW instead: output row j
+ * starts at address a_j = dst + j * dst_stride, s_j = ((-a_j) mod ALIGN) / 4 pixels, and lane l of wave wx of tile tx
+ * converts columns  tile_x + 256 wx + 4 l + s_j ...+3  of that row.  Its 16-byte store then sits at
+ * a_j + 4 s_j + 1024 (..) + 16 l: every wave-store is one 1 KiB run that starts on an ALIGN-byte boundary.  What is
+ * left over is written once per row, by the first wave of the row: the s_j < ALIGN/4 columns in front of the first
+ * boundary (the "head", at most ALIGN - 8 bytes); the row's ragged end is the last active lanes of the last tile.
+ *
+ * The price is arithmetic, not memory: the three source rows of an output row are looked up at that row's own
+ * shift, so the (E,O) lines of a source row are built three times (once per output row that uses it) instead of
+ * once -- ~45 instead of ~25 VALU instructions per 4 pixels, still a fraction of what the CUs have to spare on this
+ * stream; waves that hold no frame edge in a row (all but the first and last of a row) run without the edge-column
+ * selects.  Source dwords come out of the LDS tile at 2-byte granularity (ds_read_b32 needs no more on gfx950).
+ * The tile carries ALIGN/4 + 4 more source columns on its right for it.
+ *
+ * Needs even shifts (a_j % 8 == 0 for every row: dst, dst_stride and the frame pitch multiples of 8); anything
+ * else keeps the GENERIC arm of the kernel above.  Same arithmetic, bit-exact (tests/test_gpu_parity.py). */
+template <int WX, int WY, int RPW, int ST, int ALIGN>
+__global__ void __launch_bounds__ (64 * WX * WY)
+bayer2rgb_lds_aligned_kernel (KParams p)
+{
+  constexpr int NTHREADS = 64 * WX * WY;
+  constexpr int TW = 256 * WX;
+  constexpr int TR = WY * RPW;
+  constexpr int NROWS = TR + 2;
+  constexpr int SMAX = ALIGN / 4;               /* shifts are 0, 2, .. SMAX - 2 pixels */
+  /* LDS row: 12 B pad | left halo dword | TW bytes | RIGHT bytes.  The last lane of the tile at the largest shift
+   * reads its right neighbour dword at bytes TW - 4 + (SMAX - 2) + 4 .. + 7 */
+  constexpr int RIGHT = (SMAX + 4 + 15) & ~15;
+  constexpr int NRIGHT = (SMAX + 4) / 4;        /* dwords staged right of the tile */
+  constexpr int PITCH = 16 + TW + RIGHT;
+  constexpr int MAIN = 16;
+  static_assert (RPW % 2 == 0, "row parity is derived from the in-tile row");
+  static_assert (ALIGN == 64 || ALIGN == 128, "a sector or an L2 line");
+
+  __shared__ __attribute__ ((aligned (16))) uint8_t lds[NROWS * PITCH];
+
+  const TileId tile = block_to_tile (blockIdx.x, p.map);
+  if (!tile.valid)
+    return;
+  for (int z = 0; z < p.start_sleep; z++)
+    __builtin_amdgcn_s_sleep (1);
+  const uint32_t frame = fastdiv (tile.row, p.map.tiles_y);
+  const int ty = (int) (tile.row - frame * p.map.tiles_y.d);
+  const uint8_t *src = frame_src (p, frame);
+  uint8_t *dst = frame_dst (p, frame);
+  const int tile_x = (int) tile.tx * TW;
+  const int tile_y = ty * TR;
+  const int tid = threadIdx.x;
+
+  /* ---- stage rows tile_y-1 .. tile_y+TR, columns tile_x-4 .. tile_x+TW+4*NRIGHT-1 ---------- */
+  {
+    constexpr int TPR = TW / 16;
+    constexpr int RPP = NTHREADS / TPR;
+    constexpr int NPASS = (NROWS + RPP - 1) / RPP;
+    const int c = (tid % TPR) * 16;
+    const int rr = tid / TPR;
+    const int avail = p.wlimit4 - (tile_x + c);         /* readable bytes from this chunk on */
+    u32x4 v[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int r = i * RPP + rr;
+      const int y = tile_y - 1 + r;
+      v[i] = (u32x4) (0u);
+      if (r < NROWS && y <= p.height && avail > 0) {
+        const uint8_t *g = src
+            + (size_t) map_row (y, p.height, p.dn_last) * p.src_stride
+            + tile_x + c;
+        if (avail >= 16) {
+          v[i] = *(const u32x4_a4 *) g;
+        } else {
+          const uint32_t *q = (const uint32_t *) g;
+          v[i].x = q[0];
+          if (avail > 4) v[i].y = q[1];
+          if (avail > 8) v[i].z = q[2];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+      const int r = i * RPP + rr;
+      if (r < NROWS)
+        *(u32x4 *) &lds[r * PITCH + MAIN + c] = v[i];
+    }
+    /* halo dwords: one left of the tile, NRIGHT right of it */
+    for (int h = tid; h < (1 + NRIGHT) * NROWS; h += NTHREADS) {
+      const int r = h / (1 + NRIGHT);
+      const int k = h - r * (1 + NRIGHT);
+      const int y = tile_y - 1 + r;
+      const int off = k == 0 ? -4 : TW + 4 * (k - 1);
+      const int col = tile_x + off;
+      uint32_t hv = 0u;
+      if (y <= p.height && col >= 0 && col < p.wlimit4)
+        hv = *(const uint32_t *) (src
+            + (size_t) map_row (y, p.height, p.dn_last) * p.src_stride + col);
+      *(uint32_t *) &lds[r * PITCH + MAIN + off] = hv;
+    }
+  }
+  __syncthreads ();
+
+  /* ---- per-wave march -------------------------------------------------------- */
+  const int wave = __builtin_amdgcn_readfirstlane (tid >> 6);
+  const int lane = tid & 63;
+  const int wx = wave % WX;
+  const int wy = wave / WX;
+  const int xl = 256 * wx + 4 * lane;   /* column inside the tile, before the row's shift */
+  const int wave_x0 = tile_x + 256 * wx;
+  const int edge_off = (lane == 0) ? -4 : 4;
+  const int r0 = wy * RPW;
+  const int nrows = p.height - (tile_y + r0);   /* rows of this wave inside the frame */
+  const bool head_wave = (tile.tx == 0 && wx == 0);
+  const uint8_t *lrow = &lds[r0 * PITCH + MAIN + xl];
+#pragma unroll
+  for (int k = 0; k < RPW; k++) {
+    if (k >= nrows)
+      break;
+    uint8_t *row = dst + (size_t) (tile_y + r0 + k) * p.dst_stride;
+    const int s = (int) (((0u - (uint32_t) (uintptr_t) row) & (uint32_t) (ALIGN - 1)) >> 2);
+    const int type = (k & 1) ^ p.swap_rows;
+    const uint8_t *q = lrow + k * PITCH + s;
+    const int wave_x = wave_x0 + s;     /* first column of this wave in this row */
+    if (wave_x > 0 && wave_x + 256 < p.width) {
+      /* no frame edge inside this wave: every lane converts and stores four pixels */
+      const Lines up = shifted_lines<false> (q, edge_off, 0, 0);
+      const Lines cur = shifted_lines<false> (q + PITCH, edge_off, 0, 0);
+      const Lines dn = shifted_lines<false> (q + 2 * PITCH, edge_off, 0, 0);
+      const u32x4 px = merge_rows<true> (up, cur, dn, type, p.sel);
+      store_aligned16<ST> (row + (size_t) (wave_x + 4 * lane) * 4, px);
+    } else {
+      const int x = wave_x + 4 * lane;
+      const Lines up = shifted_lines<true> (q, edge_off, x, p.width);
+      const Lines cur = shifted_lines<true> (q + PITCH, edge_off, x, p.width);
+      const Lines dn = shifted_lines<true> (q + 2 * PITCH, edge_off, x, p.width);
+      const u32x4 px = merge_rows<true> (up, cur, dn, type, p.sel);
+      uint8_t *out = row + (size_t) x * 4;
+      if (x + 4 <= p.width) {
+        store_aligned16<ST> (out, px);
+      } else if (x + 2 == p.width) {
+        u32x2 two;
+        two.x = px.x;
+        two.y = px.y;
+        *(u32x2 *) out = two;
+      }
+    }
+    /* the head of the row: columns 0 .. s-1 in front of the first boundary, at the natural (unshifted) lane map */
+    if (head_wave && s > 0) {
+      const int hx = 4 * lane;
+      const uint8_t *hq = lrow + k * PITCH;
+      const Lines up = shifted_lines<true> (hq, edge_off, hx, p.width);
+      const Lines cur = shifted_lines<true> (hq + PITCH, edge_off, hx, p.width);
+      const Lines dn = shifted_lines<true> (hq + 2 * PITCH, edge_off, hx, p.width);
+      const u32x4 px = merge_rows<true> (up, cur, dn, type, p.sel);
+      const int lim = s < p.width ? s : p.width;
+      uint8_t *out = row + (size_t) hx * 4;
+      if (hx + 4 <= lim) {
+        *(u32x4_a4 *) out = px;
+      } else if (hx + 2 == lim) {
+        u32x2 two;
+        two.x = px.x;
+        two.y = px.y;
+        *(u32x2_a4 *) out = two;
+      }
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------- */
 /* direct kernel: no LDS, every wave streams its own strip                     */
 /* ------------------------------------------------------------------------- */
@@ -684,18 +885,25 @@ bayer2rgb_persist_kernel (KParams p)
 #define PERSIST_VARIANT(name, WX, WY, RPW, ST)                                 \
   { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1, 1,                   \
     bayer2rgb_persist_kernel<WX, WY, RPW, ST>,                                 \
-    bayer2rgb_lds_kernel<WX, WY, RPW, 0, ST, true, true> }
+    bayer2rgb_lds_kernel<WX, WY, RPW, 0, ST, true, true>, nullptr, nullptr }
 /* default block order per shape (measured on a dozen boxes, DESIGN.md "XCD map"):
  * 1024-px tiles -> band 1 (an XCD takes one full-width tile row at a time), the
  * only plan at 80-81.5 % of peak on EVERY box; narrower tiles -> identity */
 #define LDS_VARIANT(name, WX, WY, RPW, NEIGH, ST, INTRIN)                      \
   { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), (WX) == 4 ? 1 : 0, 0,    \
     bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, false>,               \
-    bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, true> }
+    bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, true>, nullptr, nullptr }
+/* production shapes and their plain-store twins: + the sector-aligned arms for generic geometries */
+#define LDS_VARIANT_AL(name, WX, WY, RPW, ST)                                  \
+  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), (WX) == 4 ? 1 : 0, 0,    \
+    bayer2rgb_lds_kernel<WX, WY, RPW, 0, ST, true, false>,                     \
+    bayer2rgb_lds_kernel<WX, WY, RPW, 0, ST, true, true>,                      \
+    bayer2rgb_lds_aligned_kernel<WX, WY, RPW, ST, 64>,                         \
+    bayer2rgb_lds_aligned_kernel<WX, WY, RPW, ST, 128> }
 #define DIRECT_VARIANT(name, WX, WY, RPW, ST, INTRIN)                          \
   { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1, 0,                   \
     bayer2rgb_direct_kernel<WX, WY, RPW, ST, INTRIN, false>,                   \
-    bayer2rgb_direct_kernel<WX, WY, RPW, ST, INTRIN, true> }
+    bayer2rgb_direct_kernel<WX, WY, RPW, ST, INTRIN, true>, nullptr, nullptr }
 
 /* Measured on MI355X (profiles/sweep_r01_*.log, interleaved A/B, 4K x 64 frames):
  * 4 rows per wave and 8 waves per workgroup is the sweet spot (83-84 % of the
@@ -704,13 +912,13 @@ bayer2rgb_persist_kernel (KParams p)
  * ds_bpermute and LDS neighbour reads tie; the no-LDS arm loses 15 points. */
 static const Variant kVariants[] = {
   /* 0: "auto" -- resolved per stream width by resolve_variant() below */
-  { "auto", 0, 0, 0, -1, 0, nullptr, nullptr },
+  { "auto", 0, 0, 0, -1, 0, nullptr, nullptr, nullptr, nullptr },
   /* 1-3: the production shapes (tile 1024x8, 512x16, 256x32; 512 threads) */
-  LDS_VARIANT ("lds_4x2_r4_dpp_nt", 4, 2, 4, 0, 1, true),
-  LDS_VARIANT ("lds_2x4_r4_dpp_nt", 2, 4, 4, 0, 1, true),
-  LDS_VARIANT ("lds_1x8_r4_dpp_nt", 1, 8, 4, 0, 1, true),
+  LDS_VARIANT_AL ("lds_4x2_r4_dpp_nt", 4, 2, 4, 1),
+  LDS_VARIANT_AL ("lds_2x4_r4_dpp_nt", 2, 4, 4, 1),
+  LDS_VARIANT_AL ("lds_1x8_r4_dpp_nt", 1, 8, 4, 1),
   /* 4.. : tuning / verification arms, all bit-exact (tests/test_gpu_parity.py) */
-  LDS_VARIANT ("lds_1x8_r4_dpp", 1, 8, 4, 0, 0, true),
+  LDS_VARIANT_AL ("lds_1x8_r4_dpp", 1, 8, 4, 0),
   LDS_VARIANT ("lds_1x8_r4_dpp_sc1", 1, 8, 4, 0, 2, true),
   LDS_VARIANT ("lds_1x8_r4_shfl_nt", 1, 8, 4, 1, 1, true),
   LDS_VARIANT ("lds_1x8_r4_ldsnb_nt", 1, 8, 4, 2, 1, true),
@@ -732,8 +940,8 @@ static const Variant kVariants[] = {
   LDS_VARIANT ("lds_4x2_r4_dpp_nt_glds", 4, 2, 4, 0, 17, true),
   /* 20-21: plain (write-back) stores in the wide shapes: for output rows that start off a 64-byte sector
    * (width % 16 != 0) the L2 then completes the partial sectors two waves share before they go out */
-  LDS_VARIANT ("lds_4x2_r4_dpp", 4, 2, 4, 0, 0, true),
-  LDS_VARIANT ("lds_2x4_r4_dpp", 2, 4, 4, 0, 0, true),
+  LDS_VARIANT_AL ("lds_4x2_r4_dpp", 4, 2, 4, 0),
+  LDS_VARIANT_AL ("lds_2x4_r4_dpp", 2, 4, 4, 0),
 };
 
 int variant_count ()
@@ -759,6 +967,17 @@ int plain_store_twin (int id)
     case 1: return 20;          /* lds_4x2_r4_dpp */
     case 2: return 21;          /* lds_2x4_r4_dpp */
     case 3: return 4;           /* lds_1x8_r4_dpp */
+    default: return id;
+  }
+}
+
+/* the production shape (ids 1-3) a plain-store twin stands for; any other id is returned unchanged */
+int production_shape_of (int id)
+{
+  switch (id) {
+    case 20: return 1;
+    case 21: return 2;
+    case 4: return 3;
     default: return id;
   }
 }

@@ -259,10 +259,13 @@ def test_pinned_host_memory_path(gpu_pkg, oracle):
         L.mibayer_host_free(p_dst)
 
 
-def test_autotune_keeps_results_bit_exact(gpu_pkg, oracle):
+@pytest.mark.parametrize("w,h,n", [(1280, 96, 12), (1000, 60, 6), (250, 40, 8), (4056, 24, 2), (1366, 30, 4)],
+                         ids=["1280", "1000_one_tile_off_sector", "250", "4056", "1366"])
+def test_autotune_keeps_results_bit_exact(gpu_pkg, oracle, w, h, n):
     """mibayer_autotune() runs every candidate plan on the caller's buffers: whichever wins, d_dst
-    holds the oracle's bytes afterwards and so does every later launch."""
-    w, h, n = 1280, 96, 12
+    holds the oracle's bytes afterwards and so does every later launch.  1000 px: rows that fit one tile and sit
+    off the sector grid -- the context keeps its nt shape while the other candidates used to be looked up as
+    plain-store twins, four shapes for a three-entry table."""
     src = oracle.fill_synthetic(w, h, n, seed=41)
     want = oracle.bayer2rgb_batch(src, w, "grbg", 1, 2, 3, nthreads=2)
     with gpu_pkg.Context(w, h, "grbg", "xRGB") as ctx:
@@ -746,6 +749,67 @@ def test_guard_bands_around_the_destination_stay_intact(gpu_pkg, oracle):
             body = out[guard:-guard].reshape(h, dstride)
             assert np.array_equal(body[:, :4 * w], want), (w, h, names[v])
             assert (body[:, 4 * w:] == 0xC3).all(), (w, h, names[v])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("align", ["0", "64", "128"])
+def test_sector_aligned_store_arm(gpu_pkg, oracle, align, monkeypatch):
+    """Generic geometries whose output rows start off the 64-byte sector grid (width % 16 != 0, padded pitches,
+    destinations at odd offsets): the per-row lane shift of bayer2rgb_lds_aligned_kernel -- every wave-store on a
+    64- / 128-byte boundary, the columns in front of the first boundary as the row's head -- against the oracle, with
+    guard bands, for every production shape and its plain-store twin, single frames, batches whose frame pitch moves
+    the phase from frame to frame, and list launches.  MIBAYER_ALIGN_STORES=0 is the unshifted generic arm."""
+    monkeypatch.setenv("MIBAYER_ALIGN_STORES", align)
+    rng = np.random.default_rng(314)
+    guard = 4096
+    names = gpu_pkg.variant_names()
+    shapes = [0] + [names.index(n) for n in ("lds_4x2_r4_dpp_nt", "lds_2x4_r4_dpp_nt", "lds_1x8_r4_dpp_nt",
+                                             "lds_1x8_r4_dpp", "lds_4x2_r4_dpp", "lds_2x4_r4_dpp")]
+    # (w, h, extra destination pitch, destination offset inside the allocation, frames)
+    cases = [(4056, 9, 0, 0, 1), (3838, 10, 0, 8, 1), (1366, 11, 0, 0, 3), (30, 7, 0, 40, 2), (6, 4, 0, 8, 3),
+             (4, 3, 8, 24, 2), (270, 5, 24, 56, 1), (1026, 17, 8, 0, 2), (2050, 12, 40, 16, 1), (1030, 33, 0, 120, 2),
+             (258, 35, 0, 0, 4), (1290, 8, 104, 72, 1), (14, 40, 0, 8, 1), (1024 + 18, 9, 0, 0, 1)]
+    for ci, (w, h, pad, off, n) in enumerate(cases):
+        sstride = (w + 3) & ~3
+        dstride = 4 * w + pad
+        src = rng.integers(0, 256, (n, h, sstride), dtype=np.uint8)
+        pat = PATTERNS[ci % 4]
+        fmt = LAYOUTS[(ci // 2) % 4]
+        r, g, b = gpu_pkg.FORMATS[fmt]
+        want = np.stack([oracle.bayer2rgb(src[f], w, pat, r, g, b) for f in range(n)])
+        for v in shapes:
+            with gpu_pkg.Context(w, h, pat, fmt, src_stride=sstride, dst_stride=dstride, variant=v) as ctx:
+                fb = ctx.dst_bytes + (8 if (ci & 1) else 0)      # frame pitch: moves the row phase per frame
+                total = n * fb
+                d_src = ctx.device_alloc(n * ctx.src_bytes)
+                d_all = ctx.device_alloc(total + 2 * guard + 128)
+                ctx.to_device(d_src, src)
+                ctx.to_device(d_all, np.full(total + 2 * guard + 128, 0xC3, np.uint8))
+                ctx.process_device(d_src, d_all + guard + off, n, dst_frame_bytes=fb)
+                ctx.sync()
+                out = ctx.from_device(d_all, total + 2 * guard + 128)
+                key = (w, h, pad, off, n, names[v], align)
+                assert (out[:guard + off] == 0xC3).all() and (out[guard + off + total:] == 0xC3).all(), key
+                for f in range(n):
+                    body = out[guard + off + f * fb: guard + off + f * fb + ctx.dst_bytes].reshape(h, dstride)
+                    bad = np.argwhere(body[:, :4 * w] != want[f])
+                    assert bad.size == 0, (key, f, bad[:4].tolist())
+                    assert (body[:, 4 * w:] == 0xC3).all(), key
+                    assert (out[guard + off + f * fb + ctx.dst_bytes: guard + off + (f + 1) * fb] == 0xC3).all(), key
+                if n > 1 and v in (0, shapes[1]):
+                    # the same frames as separate allocations at different phases: one list launch
+                    ctx.to_device(d_all, np.full(total + 2 * guard + 128, 0xC3, np.uint8))
+                    srcs = [d_src + f * ctx.src_bytes for f in range(n)]
+                    dsts = [d_all + guard + off + f * fb for f in range(n)]
+                    ctx.process_device_list(srcs, dsts)
+                    ctx.sync()
+                    out = ctx.from_device(d_all, total + 2 * guard + 128)
+                    for f in range(n):
+                        body = out[guard + off + f * fb: guard + off + f * fb + ctx.dst_bytes].reshape(h, dstride)
+                        assert np.array_equal(body[:, :4 * w], want[f]), (key, "list", f)
+                    assert (out[:guard + off] == 0xC3).all() and (out[guard + off + total:] == 0xC3).all(), key
+                ctx.device_free(d_src)
+                ctx.device_free(d_all)
 
 
 GRAPH_SCRIPT = r"""

@@ -2,7 +2,7 @@
 selectors the library really computes, must equal the oracle for every order x format x edge geometry."""
 import numpy as np
 
-from kernel_model import alignbit, bayer2rgb_model, lerp_u8, perm
+from kernel_model import alignbit, bayer2rgb_model, bayer2rgb_model_aligned, lerp_u8, perm
 
 PATTERNS = ("bggr", "gbrg", "grbg", "rggb")
 ALL_FORMATS = ("RGBx", "xRGB", "BGRx", "xBGR", "RGBA", "ARGB", "BGRA", "ABGR")
@@ -32,6 +32,24 @@ def test_lane_model_equals_oracle(pkg, oracle):
                 want = oracle.bayer2rgb(src, w, pat, r, g, b)
                 got = bayer2rgb_model(pkg, src, w, pat, fmt)
                 assert np.array_equal(got, want), (w, h, pat, fmt)
+
+
+def test_aligned_lane_map_equals_oracle(pkg, oracle):
+    """The per-row shifted lane map of bayer2rgb_lds_aligned_kernel (every wave-store on a 64- / 128-byte boundary,
+    the columns in front of the first boundary as the row's head): every pixel written exactly once, same bytes as
+    the oracle, for row pitches and base addresses that put the rows anywhere on the 8-byte grid."""
+    rng = np.random.default_rng(13)
+    cases = [(4, 3), (6, 4), (10, 7), (14, 5), (18, 4), (30, 6), (34, 9), (66, 5), (130, 7), (258, 4), (270, 5)]
+    for (w, h) in cases:
+        stride = (w + 3) & ~3
+        src = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+        for align in (64, 128):
+            for dst_stride, base in ((4 * w, 0), (4 * w, 8), (4 * w + 8, 40), (4 * w + 24, 56), (4 * w + 64, 120)):
+                for pat, fmt in (("bggr", "RGBx"), ("gbrg", "xBGR"), ("grbg", "BGRx"), ("rggb", "xRGB")):
+                    r, g, b = pkg.FORMATS[fmt]
+                    want = oracle.bayer2rgb(src, w, pat, r, g, b)
+                    got = bayer2rgb_model_aligned(pkg, src, w, pat, fmt, dst_stride, base, align)
+                    assert np.array_equal(got, want), (w, h, align, dst_stride, base, pat, fmt)
 
 
 def test_lane_model_on_golden_fixtures(pkg, golden):

@@ -4,7 +4,8 @@
 All arms are created up front and timed for several rounds in ONE process, in a freshly shuffled order each
 round, so slow drifts of the box (clock / thermal state) and "who ran before me" effects hit every arm alike;
 reports min and median per arm.
-Usage: python tools/sweep2.py W H N rounds arm [arm ...]   with arm = variant_name[:band[:start_sleep]]
+Usage: python tools/sweep2.py W H N rounds arm [arm ...]   with arm = variant_name[:band[:start_sleep[:align]]]
+(align = MIBAYER_ALIGN_STORES: 0 | 64 | 128, the store-alignment arm for generic geometries)
 (the logs under profiles/ were taken with earlier builds of this tool that also carried knobs for the block->XCD
 rotation, an occupancy throttle, a staggered / repositioned delay; those lost and were removed from the product)"""
 import os
@@ -21,8 +22,8 @@ names = pkg.variant_names()
 arms = []
 for spec in sys.argv[5:]:
     name, _, rest = spec.partition(":")
-    parts = (rest.split(":") + ["", ""])[:2]          # band : start_sleep
-    for key, val in zip(("MIBAYER_XCD_BAND", "MIBAYER_START_SLEEP"), parts):
+    parts = (rest.split(":") + ["", "", ""])[:3]      # band : start_sleep : align
+    for key, val in zip(("MIBAYER_XCD_BAND", "MIBAYER_START_SLEEP", "MIBAYER_ALIGN_STORES"), parts):
         if val:
             os.environ[key] = val
         else:
@@ -31,6 +32,7 @@ for spec in sys.argv[5:]:
     arms.append((spec, ctx, []))
 os.environ.pop("MIBAYER_XCD_BAND", None)
 os.environ.pop("MIBAYER_START_SLEEP", None)
+os.environ.pop("MIBAYER_ALIGN_STORES", None)
 c0 = arms[0][1]
 d_src = c0.device_alloc(N * c0.src_bytes)
 d_dst = c0.device_alloc(N * c0.dst_bytes)
