@@ -208,9 +208,12 @@ struct mibayer_ctx {
   int num_cus = 256;                    /* hipDeviceProp_t.multiProcessorCount */
   int persist_wgs_per_cu = 4;           /* MIBAYER_PERSIST_WGS (tuning), persistent arms */
   bool rows_off_sector = false;         /* dst_stride % 64 != 0: see plain_store_twin () */
-  int align_stores = 64;                /* generic geometries with output rows off the sector grid: boundary (bytes)
-                                           every wave-store starts on (bayer2rgb_lds_aligned_kernel); 0 = the
-                                           unshifted generic arm.  MIBAYER_ALIGN_STORES = 0 | 64 | 128 */
+  int align_stores = 0;                 /* generic geometries with output rows off the sector grid: boundary (bytes)
+                                           every wave-store starts on (the shifted arm, bayer2rgb_lds_aligned_kernel);
+                                           0 = the unshifted generic arm.  Chosen by mibayer_autotune() where it
+                                           wins; MIBAYER_ALIGN_STORES = 0 | 64 | 128 forces it (-1 in the
+                                           environment keeps it out of the autotuner's candidates) */
+  bool align_tunable = true;
   int graph_mode = 0;                   /* MIBAYER_FLAG_HIPGRAPH: 0 = the compute-queue segment of a frame as
                                            a graph per slot (default), 1 = the whole upload -> kernel ->
                                            download chain as a graph per slot on the slot's own queue
@@ -375,7 +378,8 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
   /* pointers_aligned16 >= 0: a list launch, whose caller has looked at every
    * frame pointer itself (frame strides do not apply): 1 = all 16-byte aligned,
    * 2 = every destination 8-byte aligned, 0 = neither */
-  const bool fast = (f.width % 16 == 0) && (f.src_stride % 16 == 0)
+  static const bool force_generic = getenv ("MIBAYER_FORCE_GENERIC") != NULL;   /* A/B: tools/sweep2.py */
+  const bool fast = !force_generic && (f.width % 16 == 0) && (f.src_stride % 16 == 0)
       && (f.dst_stride % 16 == 0)
       && (pointers_aligned16 >= 0 ? pointers_aligned16 == 1
           : (aligned16 (d_src) && aligned16 (d_dst)
@@ -391,7 +395,8 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
     const bool on_grid = (f.dst_stride % a == 0)
         && (pointers_aligned16 >= 0 ? false
             : ((((uintptr_t) d_dst) & (a - 1)) == 0 && (nframes == 1 || dst_frame_bytes % a == 0)));
-    if (rows8 && !on_grid)
+    static const bool force_arm = getenv ("MIBAYER_FORCE_ALIGNED_ARM") != NULL;     /* A/B: tools/sweep2.py */
+    if (rows8 && (!on_grid || force_arm))
       kern = c->align_stores == 128 ? c->var->aligned128 : c->var->aligned64;
   }
   /* The variant's default band map is dropped for the identity order in two cases
@@ -652,12 +657,23 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   c->dst_bytes = (size_t) f.dst_stride * f.height;
   c->inverse = (f.flags & MIBAYER_FLAG_RGB2BAYER) != 0;
   c->var = &variant (resolve_variant (f.variant, f.width));
-  /* output rows off the 64-byte sector grid: write-back stores + one chunk of the batch per XCD
-   * (plain_store_twin, mibayer_kernels.hip); rows that fit one tile keep their identity-order plan */
+  /* Output rows off the 64-byte sector grid (generic geometries; profiles/r03_generic_path.log).  Rows that fit one
+   * tile keep their identity-order plan.  Wider ones:
+   *  - rows 16-byte aligned (width % 4 == 0, e.g. 4056 px): every lane's 16-byte store is aligned, only the two
+   *    ends of a wave-store share a line with a neighbour -> hybrid store policy (nt inside, write-back at the
+   *    ragged ends; store_pixels_hybrid) in the allocation-independent band-1 order;
+   *  - rows at an 8-byte phase (width % 4 == 2): every lane's store straddles a 16-byte boundary -> write-back
+   *    stores + one chunk of the batch per XCD, where the L2 puts the pieces together (plain_store_twin).
+   * mibayer_autotune() times all store policies, and the shifted arm, against each other. */
   c->rows_off_sector = !c->inverse && (f.dst_stride % 64) != 0;
   if (c->rows_off_sector && f.variant == 0 && f.width > c->var->tile_w) {
-    c->var = &variant (plain_store_twin (resolve_variant (0, f.width)));
-    c->band_override = -1;
+    if (f.dst_stride % 16 == 0) {
+      c->var = &variant (hybrid_store_twin (resolve_variant (0, f.width)));
+      c->band_override = 1;
+    } else {
+      c->var = &variant (plain_store_twin (resolve_variant (0, f.width)));
+      c->band_override = -1;
+    }
   }
   if (const char *e = getenv ("MIBAYER_XCD_BAND"))
     c->band_override = atoi (e);
@@ -666,6 +682,7 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   if (const char *e = getenv ("MIBAYER_ALIGN_STORES")) {
     const int a = atoi (e);
     c->align_stores = (a == 64 || a == 128) ? a : 0;
+    c->align_tunable = false;
   }
   if (const char *e = getenv ("MIBAYER_R2B_FLAT"))
     c->r2b_flat_k = atoi (e);
@@ -1556,6 +1573,17 @@ extern "C" int mibayer_time_device (mibayer_ctx *c, const void *d_src,
 /* Measured plan selection.  The kernel is idempotent and deterministic, so the
  * candidates are simply run on the caller's real buffers: d_dst ends up holding
  * the correct output whichever plan wins. */
+namespace {
+struct Candidate {
+  const Variant *var;
+  int band;                     /* band_override value */
+  int align;                    /* align_stores value */
+  float ms;
+  bool alive;
+};
+constexpr int kMaxCands = 48;
+}
+
 extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     char *report, size_t report_len)
@@ -1568,42 +1596,83 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
 
-  /* candidate plans: {configured shape, one other production shape under
-   * "auto"} x {band 1, one chunk per XCD, identity}; the band orders carry the
-   * automatic start delay */
-  constexpr int kMaxShapes = 3;
-  const Variant *shapes[kMaxShapes] = { c->var, nullptr, nullptr };
-  int nshapes = 1;
-  if (c->cfg.variant == 0) {
-    /* the other production shapes (1024x8, 512x16, 256x32 px tiles), with plain stores where the context's own
-     * plan has them.  The configured shape stands for its own production id whichever store policy it carries
-     * (mibayer_create keeps the nt variant for rows that fit one tile), so at most two others join it. */
-    const int own = production_shape_of ((int) (c->var - &variant (0)));
-    const bool plain = own != (int) (c->var - &variant (0));
-    for (int v = 3; v >= 1 && nshapes < kMaxShapes; v--)
-      if (v != own)
-        shapes[nshapes++] = &variant (plain ? plain_store_twin (v) : v);
-  }
+  /* Candidate plans.  Sector-aligned geometries (the 16-byte kernel): {configured shape, the other production
+   * shapes under "auto"} x {band 1, one chunk per XCD, identity}; the band orders carry the automatic start delay.
+   * Generic geometries whose rows sit off the sector grid add the store policy as a dimension -- streaming,
+   * write-back, hybrid (mibayer_kernels.hip) -- and the shifted arm (every wave-store on a 128-byte boundary) in
+   * the two narrow shapes: which of them wins depends on the row phase and on the box
+   * (profiles/r03_generic_path.log). */
   const bool band_forced = getenv ("MIBAYER_XCD_BAND") != NULL;
-  const int bands[3] = { 1, -1, 0 };
+  static const int kBands[3] = { 1, -1, 0 };
   const int nbands = band_forced ? 1 : 3;
-
+  Candidate cand[kMaxCands];
+  int ncand = 0;
+  auto add = [&](const Variant *v, int band, int align) {
+    for (int i = 0; i < ncand; i++)
+      if (cand[i].var == v && cand[i].band == band && cand[i].align == align)
+        return;
+    if (ncand < kMaxCands)
+      cand[ncand++] = Candidate { v, band, align, 0.f, true };
+  };
   const Variant *keep_var = c->var;
   const int keep_band = c->band_override;
+  const int keep_align = c->align_stores;
+  bool generic_off_grid = false;
+  {
+    KParams p;
+    KernelFn kern;
+    unsigned grid;
+    const int prc = plan_launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes, p, kern, grid);
+    if (prc != MIBAYER_OK)
+      return prc;
+    generic_off_grid = kern != c->var->fast && c->rows_off_sector;
+  }
+  /* the configured plan first: it also wins ties */
+  add (c->var, band_forced ? keep_band : (keep_band == INT32_MIN ? kBands[0] : keep_band), 0);
+  if (c->cfg.variant != 0) {
+    for (int bi = 0; bi < nbands; bi++)
+      add (c->var, band_forced ? keep_band : kBands[bi], 0);
+  } else {
+    const int own_id = (int) (c->var - &variant (0));
+    for (int v = 3; v >= 1; v--) {
+      int ids[3], nids = 0;
+      if (generic_off_grid) {
+        ids[nids++] = hybrid_store_twin (v);
+        ids[nids++] = plain_store_twin (v);
+        ids[nids++] = v;
+      } else {
+        /* the store policy the context was created with */
+        ids[nids++] = own_id == plain_store_twin (production_shape_of (own_id)) && own_id != production_shape_of (own_id)
+            ? plain_store_twin (v) : v;
+      }
+      for (int k = 0; k < nids; k++)
+        for (int bi = 0; bi < nbands; bi++)
+          add (&variant (ids[k]), band_forced ? keep_band : kBands[bi], 0);
+    }
+    if (generic_off_grid && c->align_tunable) {
+      add (&variant (3), band_forced ? keep_band : 0, 128);
+      add (&variant (3), band_forced ? keep_band : 1, 128);
+      add (&variant (2), band_forced ? keep_band : 0, 128);
+      add (&variant (2), band_forced ? keep_band : 1, 128);
+    }
+  }
+
   /* The candidates are timed in interleaved rounds after a common, TIME-based
    * warm-up, and each is judged by the MEDIAN of its rounds: an idle GPU needs
    * tens of milliseconds to clock up (the first candidate used to lose for that
    * reason alone), one slow round (another process, a DVFS step) must not
    * decide the plan, and neither may one lucky round -- the plan has to be the
-   * one that is fastest in steady state, which is what the caller then runs. */
-  constexpr int kRounds = 5, kWarm = 16, kReps = 6, kCands = 3 * kMaxShapes;
+   * one that is fastest in steady state, which is what the caller then runs.
+   * With many candidates (generic geometries) only those within 6 % of the best
+   * of the first round stay in the race. */
+  constexpr int kRounds = 5, kWarm = 16, kReps = 6, kKeep = 9;
   constexpr double kWarmMs = 60.0;
-  float round_ms[kCands][kRounds];
-  float cand_ms[kCands];
-  for (float &m : cand_ms)
-    m = 0.f;
+  float (*rm)[kRounds] = new (std::nothrow) float[kMaxCands][kRounds];
+  if (!rm)
+    return MIBAYER_ERR_NOMEM;
   int rc = MIBAYER_OK;
   float ms = 0.f;
+  c->align_stores = 0;
   {
     timespec t0, t1;
     clock_gettime (CLOCK_MONOTONIC, &t0);
@@ -1615,58 +1684,61 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
             + (double) (t1.tv_nsec - t0.tv_nsec) * 1e-6) < kWarmMs);
   }
   for (int round = 0; round < kRounds && rc == MIBAYER_OK; round++) {
-    for (int si = 0; si < nshapes && rc == MIBAYER_OK; si++) {
-      for (int bi = 0; bi < nbands && rc == MIBAYER_OK; bi++) {
-        c->var = shapes[si];
-        if (!band_forced)
-          c->band_override = bands[bi];
-        rc = mibayer_time_device (c, d_src, src_frame_bytes, d_dst,
-            dst_frame_bytes, nframes, 1, kReps, &ms);
-        round_ms[si * 3 + bi][round] = ms;
-      }
+    for (int i = 0; i < ncand && rc == MIBAYER_OK; i++) {
+      if (!cand[i].alive)
+        continue;
+      c->var = cand[i].var;
+      c->band_override = cand[i].band;
+      c->align_stores = cand[i].align;
+      rc = mibayer_time_device (c, d_src, src_frame_bytes, d_dst,
+          dst_frame_bytes, nframes, 1, kReps, &ms);
+      rm[i][round] = ms;
     }
-  }
-  if (rc == MIBAYER_OK) {
-    for (int si = 0; si < nshapes; si++)
-      for (int bi = 0; bi < nbands; bi++) {
-        float *r = round_ms[si * 3 + bi];
-        for (int i = 1; i < kRounds; i++)       /* insertion sort of 5 */
-          for (int j = i; j > 0 && r[j] < r[j - 1]; j--) {
-            const float t = r[j];
-            r[j] = r[j - 1];
-            r[j - 1] = t;
-          }
-        cand_ms[si * 3 + bi] = r[kRounds / 2];
-      }
+    if (round == 0 && rc == MIBAYER_OK && ncand > kKeep) {
+      float best = 0.f;
+      for (int i = 0; i < ncand; i++)
+        if (best == 0.f || rm[i][0] < best)
+          best = rm[i][0];
+      for (int i = 1; i < ncand; i++)           /* candidate 0, the configured plan, always stays */
+        cand[i].alive = rm[i][0] <= best * 1.06f;
+    }
   }
   if (rc != MIBAYER_OK) {
     c->var = keep_var;
     c->band_override = keep_band;
+    c->align_stores = keep_align;
+    delete[] rm;
     return rc;
   }
-  const Variant *best_var = keep_var;
-  int best_band = keep_band;
-  float best_ms = 0.f;
+  int best = 0;
   size_t used = 0;
-  for (int si = 0; si < nshapes; si++) {
-    for (int bi = 0; bi < nbands; bi++) {
-      const float m = cand_ms[si * 3 + bi];
-      if (report && used < report_len) {
-        int n = snprintf (report + used, report_len - used, "%s%s/band%d=%.4fms",
-            used ? " " : "", shapes[si]->name,
-            band_forced ? keep_band : bands[bi], m);
-        if (n > 0)
-          used += (size_t) n;
-      }
-      if (best_ms == 0.f || m < best_ms) {
-        best_ms = m;
-        best_var = shapes[si];
-        best_band = band_forced ? keep_band : bands[bi];
-      }
+  for (int i = 0; i < ncand; i++) {
+    if (!cand[i].alive) {
+      cand[i].ms = rm[i][0];                     /* its one round, for the report */
+    } else {
+      float *r = rm[i];
+      for (int a = 1; a < kRounds; a++)          /* insertion sort of 5 */
+        for (int b = a; b > 0 && r[b] < r[b - 1]; b--) {
+          const float t = r[b];
+          r[b] = r[b - 1];
+          r[b - 1] = t;
+        }
+      cand[i].ms = r[kRounds / 2];
+      if (!cand[best].alive || cand[i].ms < cand[best].ms)
+        best = i;
+    }
+    if (report && used < report_len) {
+      int n = snprintf (report + used, report_len - used, "%s%s%s/band%d=%.4fms%s",
+          used ? " " : "", cand[i].var->name, cand[i].align ? "+shift" : "",
+          cand[i].band, cand[i].ms, cand[i].alive ? "" : "(dropped)");
+      if (n > 0)
+        used += (size_t) n;
     }
   }
-  c->var = best_var;
-  c->band_override = best_band;
+  delete[] rm;
+  c->var = cand[best].var;
+  c->band_override = cand[best].band;
+  c->align_stores = cand[best].align;
   return MIBAYER_OK;
 }
 
@@ -1678,6 +1750,7 @@ extern "C" int mibayer_copy_plan (mibayer_ctx *dst, const mibayer_ctx *src)
     return MIBAYER_ERR_GEOMETRY;
   dst->var = src->var;
   dst->band_override = src->band_override;
+  dst->align_stores = src->align_stores;
   return MIBAYER_OK;
 }
 

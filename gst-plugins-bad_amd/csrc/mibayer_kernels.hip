@@ -40,6 +40,7 @@
 #include "mibayer_internal.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace mibayer {
 
@@ -204,7 +205,7 @@ __device__ __forceinline__ void store_pixels (uint8_t *p, u32x4 px,
 {
   constexpr int ST = STLD & 7;  /* bit 3 = nt hint on the tile's row loads, bit 4 = direct-to-LDS loads */
   if constexpr (!GENERIC) {
-    if constexpr (ST == 1)
+    if constexpr (ST == 1 || ST == 5)         /* 5: the hybrid policy of generic geometries; aligned rows stream */
       __builtin_nontemporal_store (px, (u32x4 *) p);
     else if constexpr (ST == 2)
       asm volatile ("global_store_dwordx4 %0, %1, off sc1" :: "v" (p), "v" (px) : "memory");
@@ -231,6 +232,32 @@ __device__ __forceinline__ void store_pixels (uint8_t *p, u32x4 px,
       else
         *(u32x2_a4 *) p = two;
     }
+  }
+}
+
+/* Store policy 5 ("hybrid"), generic geometries: output rows that start off the 128-byte line grid make every 1 KiB
+ * wave-store begin and end inside a line that a neighbouring wave (or tile) completes.  Streaming (nt) stores push
+ * such half-written lines out one half at a time and lose 4-11 points of HBM peak; write-back stores let the L2 put
+ * the halves together but give up what nt gains on a pure output stream (3 points; profiles/r03_generic_path.log).
+ * Here each lane picks by itself: nt when every line its 16 bytes touch lies completely inside this wave-store,
+ * write-back for the one or two ragged lines at either end.  a7 = position of the lane's first byte in its line;
+ * the wave-store covers bytes [-lane16, len - lane16) relative to it. */
+__device__ __forceinline__ void store_pixels_hybrid (uint8_t *p, u32x4 px,
+    int lastmode, int lane16, int len)
+{
+  const int a7 = (int) ((uint32_t) (uintptr_t) p & 127u);
+  const int need = a7 > 112 ? 256 : 128;        /* the 16 bytes straddle a line boundary: both lines count */
+  const bool inside = a7 <= lane16 && lane16 + need - a7 <= len;
+  if (lastmode == 2) {
+    u32x2 two;
+    two.x = px.x;
+    two.y = px.y;
+    *(u32x2_a4 *) p = two;
+  } else if (inside) {
+    /* spelled out: the compiler folds an nt and a plain store of the same value under if / else into ONE plain store */
+    asm volatile ("global_store_dwordx4 %0, %1, off nt" :: "v" (p), "v" (px) : "memory");
+  } else {
+    asm volatile ("global_store_dwordx4 %0, %1, off" :: "v" (p), "v" (px) : "memory");
   }
 }
 
@@ -429,38 +456,61 @@ bayer2rgb_lds_kernel (KParams p)
   Lines cur = lines_of (r0 + 1);
   uint8_t *out = dst + (size_t) (tile_y + r0) * p.dst_stride + (size_t) x0 * 4;
   const int nrows = p.height - (tile_y + r0);   /* rows of this wave inside the frame */
+  /* bytes of a row this wave writes (store policy 5): 1 KiB, less for the wave that holds the end of the row */
+  const int wave_left = 4 * (p.width - (tile_x + 256 * wx));
+  const int wave_len = wave_left < 1024 ? wave_left : 1024;
 #pragma unroll
   for (int k = 0; k < RPW; k++) {
     const Lines dn = lines_of (r0 + k + 2);
     const int type = (k & 1) ^ p.swap_rows;
     const u32x4 px = merge_rows<INTRIN> (up, cur, dn, type, p.sel);
-    if (active && k < nrows)
-      store_pixels<ST, GENERIC> (out, px, lastmode);
+    if (active && k < nrows) {
+      if constexpr (GENERIC && (ST & 7) == 5)
+        store_pixels_hybrid (out, px, lastmode, 16 * lane, wave_len);
+      else
+        store_pixels<ST, GENERIC> (out, px, lastmode);
+    }
     out += p.dst_stride;
     up = cur;
     cur = dn;
   }
 }
 
-/* a source dword at 2-byte alignment out of the LDS tile (gfx950 DS reads need no more) */
-typedef uint32_t u32_a2 __attribute__ ((aligned (2)));
-
-/* (E,O) of the four columns whose source bytes start at q (LDS, 2-byte aligned); lanes 0 / 63 take the dword
- * left / right of the wave's columns from q + edge_off.  EDGE = false: no frame edge in this wave */
-template <bool EDGE>
-__device__ __forceinline__ Lines shifted_lines (const uint8_t *q, int edge_off,
-    int x, int width)
+/* (E,O) of four columns whose source bytes start R bytes (0 or 2) behind the dword-aligned LDS address qa: the
+ * column dword and its x-1 / x+1 neighbour windows all come out of the aligned dwords around it (for R = 2 out of
+ * two of them), so no lane exchange and no wave-edge special case is needed.  EDGE: this wave holds the first column
+ * of the frame, or its last ones (reference gstbayer2rgb.c:360-363, :372-380) */
+template <int R, bool EDGE>
+__device__ __forceinline__ Lines shifted_lines (const uint8_t *qa, int x, int width)
 {
-  const uint32_t c = *(const u32_a2 *) q;
-  const uint32_t edge = *(const u32_a2 *) (q + edge_off);
-  const uint32_t cl = from_lane_below (edge, c);
-  const uint32_t cr = from_lane_above (edge, c);
-  if constexpr (EDGE) {
-    const int lastmode = (x + 4 == width) ? 1 : ((x + 2 == width) ? 2 : 0);
-    return row_lines<true, true> (c, cl, cr, x == 0, lastmode);
+  const uint32_t d0 = *(const uint32_t *) qa;
+  const uint32_t d1 = *(const uint32_t *) (qa + 4);
+  uint32_t lsh, c, rsh;         /* columns x-1..x+2, x..x+3, x+1..x+4 */
+  if constexpr (R == 0) {
+    const uint32_t dm = *(const uint32_t *) (qa - 4);
+    lsh = __builtin_amdgcn_alignbit (d0, dm, 24);
+    c = d0;
+    rsh = __builtin_amdgcn_alignbit (d1, d0, 8);
   } else {
-    return row_lines<true, false> (c, cl, cr, false, 0);
+    lsh = __builtin_amdgcn_alignbit (d1, d0, 8);
+    c = __builtin_amdgcn_alignbit (d1, d0, 16);
+    rsh = __builtin_amdgcn_alignbit (d1, d0, 24);
   }
+  if constexpr (EDGE) {
+    /* O[0] = S[1]: the left neighbour of column 0 is S[1] */
+    const uint32_t lsh_first = (lsh & 0xffffff00u) | ((c >> 8) & 0xffu);
+    lsh = (x == 0) ? lsh_first : lsh;
+    /* E[W-1] = S[W-2], O[W-2] = S[W-3]: the right neighbours of the last two columns are their left ones */
+    const uint32_t t = lsh >> 16;
+    const uint32_t rsh_last = t | (t << 16);
+    rsh = (x + 4 == width) ? rsh_last : rsh;
+    rsh = (x + 2 == width) ? lsh : rsh;
+  }
+  const uint32_t a = avg4<true> (lsh, rsh);
+  Lines r;
+  r.e = bsel (kEvenBytes, c, a);
+  r.o = bsel (kEvenBytes, a, c);
+  return r;
 }
 
 template <int ST>
@@ -489,8 +539,9 @@ __device__ __forceinline__ void store_aligned16 (uint8_t *p, u32x4 px)
  * shift, so the (E,O) lines of a source row are built three times (once per output row that uses it) instead of
  * once -- ~45 instead of ~25 VALU instructions per 4 pixels, still a fraction of what the CUs have to spare on this
  * stream; waves that hold no frame edge in a row (all but the first and last of a row) run without the edge-column
- * selects.  Source dwords come out of the LDS tile at 2-byte granularity (ds_read_b32 needs no more on gfx950).
- * The tile carries ALIGN/4 + 4 more source columns on its right for it.
+ * selects.  A lane's column dword and both neighbour windows come out of the two or three ALIGNED LDS dwords around
+ * them through v_alignbit_b32 (unaligned ds_reads were measured 2x slower), so the shifted arm needs no lane
+ * exchange at all.  The tile carries ALIGN/4 + 4 more source columns on its right for it.
  *
  * Needs even shifts (a_j % 8 == 0 for every row: dst, dst_stride and the frame pitch multiples of 8); anything
  * else keeps the GENERIC arm of the kernel above.  Same arithmetic, bit-exact (tests/test_gpu_parity.py). */
@@ -584,11 +635,37 @@ bayer2rgb_lds_aligned_kernel (KParams p)
   const int wy = wave / WX;
   const int xl = 256 * wx + 4 * lane;   /* column inside the tile, before the row's shift */
   const int wave_x0 = tile_x + 256 * wx;
-  const int edge_off = (lane == 0) ? -4 : 4;
   const int r0 = wy * RPW;
   const int nrows = p.height - (tile_y + r0);   /* rows of this wave inside the frame */
   const bool head_wave = (tile.tx == 0 && wx == 0);
   const uint8_t *lrow = &lds[r0 * PITCH + MAIN + xl];
+
+  /* one output row of this wave at shift s: convert, store */
+  auto shifted_row = [&](auto rtag, auto etag, const uint8_t *qa, int x, int type, uint8_t *row, int lim) {
+    constexpr int R = decltype (rtag)::value;
+    constexpr bool EDGE = decltype (etag)::value;
+    const Lines up = shifted_lines<R, EDGE> (qa, x, p.width);
+    const Lines cur = shifted_lines<R, EDGE> (qa + PITCH, x, p.width);
+    const Lines dn = shifted_lines<R, EDGE> (qa + 2 * PITCH, x, p.width);
+    const u32x4 px = merge_rows<true> (up, cur, dn, type, p.sel);
+    uint8_t *out = row + (size_t) x * 4;
+    if constexpr (!EDGE) {
+      store_aligned16<ST> (out, px);
+    } else {
+      /* lim: one past the last column this pass may write (the frame width, or the first boundary for the head) */
+      if (x + 4 <= lim) {
+        *(u32x4_a4 *) out = px;
+      } else if (x + 2 == lim) {
+        u32x2 two;
+        two.x = px.x;
+        two.y = px.y;
+        *(u32x2_a4 *) out = two;
+      }
+    }
+  };
+  using R0 = std::integral_constant<int, 0>;
+  using R2 = std::integral_constant<int, 2>;
+
 #pragma unroll
   for (int k = 0; k < RPW; k++) {
     if (k >= nrows)
@@ -596,50 +673,24 @@ bayer2rgb_lds_aligned_kernel (KParams p)
     uint8_t *row = dst + (size_t) (tile_y + r0 + k) * p.dst_stride;
     const int s = (int) (((0u - (uint32_t) (uintptr_t) row) & (uint32_t) (ALIGN - 1)) >> 2);
     const int type = (k & 1) ^ p.swap_rows;
-    const uint8_t *q = lrow + k * PITCH + s;
+    const uint8_t *qa = lrow + k * PITCH + (s & ~3);
     const int wave_x = wave_x0 + s;     /* first column of this wave in this row */
+    const int x = wave_x + 4 * lane;
     if (wave_x > 0 && wave_x + 256 < p.width) {
       /* no frame edge inside this wave: every lane converts and stores four pixels */
-      const Lines up = shifted_lines<false> (q, edge_off, 0, 0);
-      const Lines cur = shifted_lines<false> (q + PITCH, edge_off, 0, 0);
-      const Lines dn = shifted_lines<false> (q + 2 * PITCH, edge_off, 0, 0);
-      const u32x4 px = merge_rows<true> (up, cur, dn, type, p.sel);
-      store_aligned16<ST> (row + (size_t) (wave_x + 4 * lane) * 4, px);
+      if (s & 2)
+        shifted_row (R2 (), std::false_type (), qa, x, type, row, 0);
+      else
+        shifted_row (R0 (), std::false_type (), qa, x, type, row, 0);
     } else {
-      const int x = wave_x + 4 * lane;
-      const Lines up = shifted_lines<true> (q, edge_off, x, p.width);
-      const Lines cur = shifted_lines<true> (q + PITCH, edge_off, x, p.width);
-      const Lines dn = shifted_lines<true> (q + 2 * PITCH, edge_off, x, p.width);
-      const u32x4 px = merge_rows<true> (up, cur, dn, type, p.sel);
-      uint8_t *out = row + (size_t) x * 4;
-      if (x + 4 <= p.width) {
-        store_aligned16<ST> (out, px);
-      } else if (x + 2 == p.width) {
-        u32x2 two;
-        two.x = px.x;
-        two.y = px.y;
-        *(u32x2 *) out = two;
-      }
+      if (s & 2)
+        shifted_row (R2 (), std::true_type (), qa, x, type, row, p.width);
+      else
+        shifted_row (R0 (), std::true_type (), qa, x, type, row, p.width);
     }
     /* the head of the row: columns 0 .. s-1 in front of the first boundary, at the natural (unshifted) lane map */
-    if (head_wave && s > 0) {
-      const int hx = 4 * lane;
-      const uint8_t *hq = lrow + k * PITCH;
-      const Lines up = shifted_lines<true> (hq, edge_off, hx, p.width);
-      const Lines cur = shifted_lines<true> (hq + PITCH, edge_off, hx, p.width);
-      const Lines dn = shifted_lines<true> (hq + 2 * PITCH, edge_off, hx, p.width);
-      const u32x4 px = merge_rows<true> (up, cur, dn, type, p.sel);
-      const int lim = s < p.width ? s : p.width;
-      uint8_t *out = row + (size_t) hx * 4;
-      if (hx + 4 <= lim) {
-        *(u32x4_a4 *) out = px;
-      } else if (hx + 2 == lim) {
-        u32x2 two;
-        two.x = px.x;
-        two.y = px.y;
-        *(u32x2_a4 *) out = two;
-      }
-    }
+    if (head_wave && s > 0)
+      shifted_row (R0 (), std::true_type (), lrow + k * PITCH, 4 * lane, type, row, s < p.width ? s : p.width);
   }
 }
 
@@ -942,6 +993,11 @@ static const Variant kVariants[] = {
    * (width % 16 != 0) the L2 then completes the partial sectors two waves share before they go out */
   LDS_VARIANT_AL ("lds_4x2_r4_dpp", 4, 2, 4, 0),
   LDS_VARIANT_AL ("lds_2x4_r4_dpp", 2, 4, 4, 0),
+  /* 22-24: hybrid store policy in the production shapes (generic geometries: nt for the lines a wave-store covers
+   * completely, write-back for its ragged ends; sector-aligned geometries: nt) */
+  LDS_VARIANT ("lds_4x2_r4_dpp_hy", 4, 2, 4, 0, 5, true),
+  LDS_VARIANT ("lds_2x4_r4_dpp_hy", 2, 4, 4, 0, 5, true),
+  LDS_VARIANT ("lds_1x8_r4_dpp_hy", 1, 8, 4, 0, 5, true),
 };
 
 int variant_count ()
@@ -971,13 +1027,25 @@ int plain_store_twin (int id)
   }
 }
 
-/* the production shape (ids 1-3) a plain-store twin stands for; any other id is returned unchanged */
+/* the hybrid-store arm of a production shape (store_pixels_hybrid: nt inside, write-back at the ragged ends of a
+ * wave-store), for generic geometries whose output rows are 16-byte aligned but off the line grid */
+int hybrid_store_twin (int id)
+{
+  switch (id) {
+    case 1: return 22;          /* lds_4x2_r4_dpp_hy */
+    case 2: return 23;          /* lds_2x4_r4_dpp_hy */
+    case 3: return 24;          /* lds_1x8_r4_dpp_hy */
+    default: return id;
+  }
+}
+
+/* the production shape (ids 1-3) a plain-store or hybrid-store twin stands for; any other id is returned unchanged */
 int production_shape_of (int id)
 {
   switch (id) {
-    case 20: return 1;
-    case 21: return 2;
-    case 4: return 3;
+    case 20: case 22: return 1;
+    case 21: case 23: return 2;
+    case 4: case 24: return 3;
     default: return id;
   }
 }

@@ -266,8 +266,8 @@ def test_autotune_keeps_results_bit_exact(gpu_pkg, oracle, w, h, n):
     holds the oracle's bytes afterwards and so does every later launch.  1000 px: rows that fit one tile and sit
     off the sector grid -- the context keeps its nt shape while the other candidates used to be looked up as
     plain-store twins, four shapes for a three-entry table."""
-    src = oracle.fill_synthetic(w, h, n, seed=41)
-    want = oracle.bayer2rgb_batch(src, w, "grbg", 1, 2, 3, nthreads=2)
+    src = np.random.default_rng(41).integers(0, 256, (n, h, (w + 3) & ~3), dtype=np.uint8)
+    want = np.stack([oracle.bayer2rgb(src[f], w, "grbg", 1, 2, 3) for f in range(n)])
     with gpu_pkg.Context(w, h, "grbg", "xRGB") as ctx:
         d_src = ctx.device_alloc(n * ctx.src_bytes)
         d_dst = ctx.device_alloc(n * ctx.dst_bytes)

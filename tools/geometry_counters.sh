@@ -11,16 +11,20 @@ export TMPDIR=/tmp
 cd /tmp
 run() {   # name W H N env...
   name=$1; W=$2; H=$3; N=$4; shift 4
+  RUN_VARIANT=""
+  for kv in "$@"; do case $kv in RUN_VARIANT=*) RUN_VARIANT=${kv#RUN_VARIANT=};; esac; done
   for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
     d=$O/${name}_$(echo $c | tr ' ' '+')
-    env "$@" timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o x -- python $R/tools/run_geometry.py $W $H $N --reps 8 2>&1 | grep -E "GB/s|rror" | tail -1
+    env "$@" timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $d -o x -- python $R/tools/run_geometry.py $W $H $N --reps 8 ${RUN_VARIANT:+--variant $RUN_VARIANT} 2>&1 | grep -E "GB/s|rror" | tail -1
   done
 }
 for geo in "4056 3040 32" "3838 2160 64" "1366 768 512"; do
   set -- $geo
-  for al in 0 64 128; do
-    run g${1}x${2}x${3}_align$al $1 $2 $3 MIBAYER_ALIGN_STORES=$al
-  done
+  run g${1}x${2}x${3}_default $1 $2 $3 MIBAYER_UNUSED=1
+  run g${1}x${2}x${3}_wb-chunk $1 $2 $3 MIBAYER_XCD_BAND=-1 RUN_VARIANT=lds_4x2_r4_dpp
+  run g${1}x${2}x${3}_nt-band1 $1 $2 $3 MIBAYER_XCD_BAND=1 RUN_VARIANT=lds_4x2_r4_dpp_nt
+  run g${1}x${2}x${3}_hybrid-band1 $1 $2 $3 MIBAYER_XCD_BAND=1 RUN_VARIANT=lds_4x2_r4_dpp_hy
+  run g${1}x${2}x${3}_shift128-1x8 $1 $2 $3 MIBAYER_XCD_BAND=0 MIBAYER_ALIGN_STORES=128 RUN_VARIANT=lds_1x8_r4_dpp_nt
 done
 # aligned geometries: the plans autotune picks (chunk at 8K, band 1 at 1080p / 4K)
 run g7680x4320x64_chunk 7680 4320 64 MIBAYER_XCD_BAND=-1

@@ -6,6 +6,9 @@ round, so slow drifts of the box (clock / thermal state) and "who ran before me"
 reports min and median per arm.
 Usage: python tools/sweep2.py W H N rounds arm [arm ...]   with arm = variant_name[:band[:start_sleep[:align]]]
 (align = MIBAYER_ALIGN_STORES: 0 | 64 | 128, the store-alignment arm for generic geometries)
+Environment: SWEEP_SRC_STRIDE / SWEEP_DST_STRIDE (row pitches), SWEEP_DST_OFFSET (bytes added to the destination),
+MIBAYER_FORCE_GENERIC=1 (sector-aligned geometries through the generic arm) -- to separate code path, read
+misalignment and write misalignment.
 (the logs under profiles/ were taken with earlier builds of this tool that also carried knobs for the block->XCD
 rotation, an occupancy throttle, a staggered / repositioned delay; those lost and were removed from the product)"""
 import os
@@ -28,14 +31,17 @@ for spec in sys.argv[5:]:
             os.environ[key] = val
         else:
             os.environ.pop(key, None)
-    ctx = pkg.Context(W, H, "rggb", "BGRx", variant=names.index(name))
+    ctx = pkg.Context(W, H, "rggb", "BGRx", variant=names.index(name),
+                      src_stride=int(os.environ.get("SWEEP_SRC_STRIDE", "0")),
+                      dst_stride=int(os.environ.get("SWEEP_DST_STRIDE", "0")))
     arms.append((spec, ctx, []))
 os.environ.pop("MIBAYER_XCD_BAND", None)
 os.environ.pop("MIBAYER_START_SLEEP", None)
 os.environ.pop("MIBAYER_ALIGN_STORES", None)
 c0 = arms[0][1]
 d_src = c0.device_alloc(N * c0.src_bytes)
-d_dst = c0.device_alloc(N * c0.dst_bytes)
+DST_OFF = int(os.environ.get("SWEEP_DST_OFFSET", "0"))     # bytes: moves the destination off its 256-byte grid
+d_dst = c0.device_alloc(N * c0.dst_bytes + 256) + DST_OFF
 print("d_src %#x d_dst %#x" % (d_src, d_dst))
 c0.fill_synthetic(d_src, N, 2)
 c0.sync()
