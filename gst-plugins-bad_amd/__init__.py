@@ -36,8 +36,8 @@ FORMATS = {
 }
 
 OK = 0
-ERR_ARG, ERR_GEOMETRY, ERR_LAYOUT, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_BUSY, ERR_EMPTY = (
-    -1, -2, -3, -4, -5, -6, -7, -8)
+ERR_ARG, ERR_GEOMETRY, ERR_LAYOUT, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_BUSY, ERR_EMPTY, ERR_TIMEOUT = (
+    -1, -2, -3, -4, -5, -6, -7, -8, -9)
 
 
 class MibayerError(RuntimeError):
@@ -96,6 +96,9 @@ ABI = {
     "mibayer_submit": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "mibayer_wait": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     "mibayer_pending": (ctypes.c_int, [_vp]),
+    "mibayer_set_wait_timeout": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mibayer_pool_set_wait_timeout": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mibayer_pool_inject_stall": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "mibayer_pool_create": (ctypes.c_int, [ctypes.POINTER(PoolCfg), ctypes.POINTER(_vp)]),
     "mibayer_pool_destroy": (None, [_vp]),
     "mibayer_pool_capacity": (ctypes.c_int, [_vp]),
@@ -176,7 +179,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.mibayer_abi_version() != 2:
+        if L.mibayer_abi_version() != 3:
             raise MibayerErrorNoLib("libmibayer.so ABI version mismatch")
         _lib = L
     return _lib
@@ -239,6 +242,12 @@ class Pool:
 
     def alive(self):
         return lib().mibayer_pool_alive(self._h)
+
+    def set_wait_timeout(self, ms):
+        _check(lib().mibayer_pool_set_wait_timeout(self._h, ms), "mibayer_pool_set_wait_timeout")
+
+    def inject_stall(self, shard, ms):
+        _check(lib().mibayer_pool_inject_stall(self._h, shard, ms), "mibayer_pool_inject_stall")
 
     def inject_fault(self, shard, after_frames):
         _check(lib().mibayer_pool_inject_fault(self._h, shard, after_frames), "mibayer_pool_inject_fault")
@@ -328,6 +337,15 @@ class Context:
 
     def pending(self):
         return lib().mibayer_pending(self._h)
+
+    def set_wait_timeout(self, ms):
+        _check(lib().mibayer_set_wait_timeout(self._h, ms), "mibayer_set_wait_timeout")
+
+    def stall(self, ms):
+        """Drill (csrc/mibayer_hooks.h): occupy the context's compute queue for `ms` milliseconds."""
+        fn = lib().mibayer_internal_stall
+        fn.restype, fn.argtypes = ctypes.c_int, [_vp, ctypes.c_int]
+        _check(fn(self._h, ms), "mibayer_internal_stall")
 
     # -- device path ------------------------------------------------------------------------
     def device_alloc(self, nbytes):

@@ -183,6 +183,46 @@ struct DeviceQueues {
 static std::mutex g_queues_mu;
 static DeviceQueues g_queues[64];
 
+/* Device frames of contexts that were destroyed, kept for the next context of the same geometry on that device
+ * (renegotiation, one element after another): hipFree waits for EVERY queue of the device to drain, so a context
+ * that frees its ring on the way out would wait for its neighbours' batches.  Bounded (kCacheMax blocks per device);
+ * emptied when the last context of the device goes.  Guarded by g_queues_mu. */
+struct BufCache {
+  std::vector<std::pair<void *, size_t>> bufs;
+  int contexts = 0;
+};
+constexpr size_t kCacheMax = 16;
+static BufCache g_cache[64];
+
+static hipError_t cached_malloc (int dev, void **p, size_t bytes)
+{
+  if (dev >= 0 && dev < 64) {
+    std::lock_guard<std::mutex> lk (g_queues_mu);
+    std::vector<std::pair<void *, size_t>> &v = g_cache[dev].bufs;
+    for (size_t i = 0; i < v.size (); i++)
+      if (v[i].second == bytes) {
+        *p = v[i].first;
+        v.erase (v.begin () + (long) i);
+        return hipSuccess;
+      }
+  }
+  return hipMalloc (p, bytes);
+}
+
+static void cached_free (int dev, void *p, size_t bytes)
+{
+  if (!p)
+    return;
+  if (dev >= 0 && dev < 64) {
+    std::lock_guard<std::mutex> lk (g_queues_mu);
+    if (g_cache[dev].bufs.size () < kCacheMax) {
+      g_cache[dev].bufs.emplace_back (p, bytes);
+      return;
+    }
+  }
+  (void) hipFree (p);
+}
+
 static bool shared_queues_enabled ()
 {
   static const bool on = [] {
@@ -233,6 +273,16 @@ struct mibayer_ctx {
   hipStream_t s_d2h = nullptr;
   bool shared_queues = false;           /* the three above belong to g_queues[device] */
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+  hipEvent_t ev_fence = nullptr;        /* fence of mibayer_sync / of a failed submit */
+  /* Deadline of every host-side wait for the device (mibayer_wait, the synchronous frame call, sync, destroy):
+   * a GPU that has stopped answering returns nothing, so an unbounded hipEventSynchronize would hang the streaming
+   * thread for good.  0 = wait for ever.  MIBAYER_WAIT_TIMEOUT_MS / mibayer_set_wait_timeout(). */
+  int wait_timeout_ms = 10000;
+  bool wedged = false;                  /* a wait ran into the deadline: nothing of this context is waited for again,
+                                           and its device-side resources are left alone (freeing would block) */
+  bool counted = false;                 /* in g_cache[device].contexts */
+  bool dirty_compute = false;           /* device-resident work was queued on s_compute through this context since
+                                           the last mibayer_sync */
   std::vector<Slot> ring;
   Slot spare;                   /* mibayer_internal_run_spare: outside the ring */
   bool spare_ready = false;
@@ -240,6 +290,81 @@ struct mibayer_ctx {
   int tail = 0;                 /* oldest in-flight slot    */
   int pending = 0;
 };
+
+/* ---- bounded waits ---------------------------------------------------------- */
+
+static double now_ms ()
+{
+  timespec t;
+  clock_gettime (CLOCK_MONOTONIC, &t);
+  return (double) t.tv_sec * 1e3 + (double) t.tv_nsec * 1e-6;
+}
+
+/* Host wait for an event, bounded by the context's deadline: the event is polled (a tight loop for the first two
+ * milliseconds -- a frame takes about one -- then in 50 us naps).  MIBAYER_ERR_TIMEOUT marks the context wedged.
+ * Reference analogue of a bounded wait on a stream that may stall: gst/debugutils/gstwatchdog.c:21-123. */
+static int wait_event (mibayer_ctx *c, hipEvent_t ev)
+{
+  if (c->wedged)
+    return MIBAYER_ERR_TIMEOUT;
+  if (c->wait_timeout_ms <= 0) {
+    HIP_TRY (hipEventSynchronize (ev));
+    return MIBAYER_OK;
+  }
+  const double t0 = now_ms ();
+  for (;;) {
+    const hipError_t e = hipEventQuery (ev);
+    if (e == hipSuccess)
+      return MIBAYER_OK;
+    if (e != hipErrorNotReady) {
+      (void) hip_failed (e, "hipEventQuery");
+      return MIBAYER_ERR_HIP;
+    }
+    (void) hipGetLastError ();
+    const double dt = now_ms () - t0;
+    if (dt >= (double) c->wait_timeout_ms) {
+      c->wedged = true;
+      snprintf (t_hip_error, sizeof t_hip_error,
+          "HIP device %d did not complete a frame within %d ms", c->device, c->wait_timeout_ms);
+      return MIBAYER_ERR_TIMEOUT;
+    }
+    if (dt > 2.0) {
+      const timespec nap = { 0, 50000 };
+      nanosleep (&nap, NULL);
+    }
+  }
+}
+
+/* everything this context has queued so far on its three queues (a failed submit may have left a copy behind that
+ * no slot event covers): one fence per queue, each waited for with the deadline */
+static void fence_queues (mibayer_ctx *c)
+{
+  if (c->wedged || !c->ev_fence)
+    return;
+  for (hipStream_t q : { c->s_h2d, c->s_compute, c->s_d2h }) {
+    if (!q)
+      continue;
+    if (hipEventRecord (c->ev_fence, q) != hipSuccess) {
+      (void) hipGetLastError ();
+      continue;
+    }
+    if (wait_event (c, c->ev_fence) == MIBAYER_ERR_TIMEOUT)
+      return;
+  }
+}
+
+/* the frames this context still has in flight: their own download events, nothing of the neighbours that share
+ * the device's queues */
+static int wait_own_frames (mibayer_ctx *c)
+{
+  int rc = MIBAYER_OK;
+  if (!c->ring.empty ()) {
+    const int n = (int) c->ring.size ();
+    for (int i = 0; i < c->pending && rc == MIBAYER_OK; i++)
+      rc = wait_event (c, c->ring[(size_t) ((c->tail + i) % n)].ev_out);
+  }
+  return rc;
+}
 
 /* ---- plan ----------------------------------------------------------------- */
 
@@ -529,6 +654,7 @@ extern "C" const char *mibayer_strerror (int status)
     case MIBAYER_ERR_NOMEM: return "out of memory";
     case MIBAYER_ERR_BUSY: return "frames in flight: ring full or busy";
     case MIBAYER_ERR_EMPTY: return "no frame in flight";
+    case MIBAYER_ERR_TIMEOUT: return "the device did not answer within the wait deadline";
     default: return "unknown mibayer status";
   }
 }
@@ -626,6 +752,7 @@ static int validate (const mibayer_cfg *in, mibayer_cfg *out)
 }
 
 static int choose_host_bands (const mibayer_ctx *c);
+extern "C" void mibayer_internal_private_queues (mibayer_ctx *c);
 
 extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
 {
@@ -692,6 +819,8 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
     c->r2b_flat_ld = atoi (e);
   if (const char *e = getenv ("MIBAYER_R2B_ROWS"))
     c->r2b_rows = atoi (e);
+  if (const char *e = getenv ("MIBAYER_WAIT_TIMEOUT_MS"))
+    c->wait_timeout_ms = atoi (e) > 0 ? atoi (e) : 0;
   if (const char *e = getenv ("MIBAYER_GRAPH_MODE"))
     c->graph_mode = (strcmp (e, "chain") == 0 || strcmp (e, "1") == 0) ? 1 : 0;
   if (const char *e = getenv ("MIBAYER_PERSIST_WGS"))
@@ -712,6 +841,11 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   if (!guard.ok) {
     delete c;
     return MIBAYER_ERR_HIP;
+  }
+  if (dev < 64) {
+    std::lock_guard<std::mutex> lk (g_queues_mu);
+    g_cache[dev].contexts++;
+    c->counted = true;
   }
   bool bad = false;
   if (shared_queues_enabled () && dev < 64) {
@@ -749,6 +883,7 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   }
   bad |= hip_failed (hipEventCreate (&c->ev_t0), "hipEventCreate");
   bad |= hip_failed (hipEventCreate (&c->ev_t1), "hipEventCreate");
+  bad |= hip_failed (hipEventCreateWithFlags (&c->ev_fence, hipEventDisableTiming), "hipEventCreate");
   if (bad) {
     mibayer_destroy (c);
     return MIBAYER_ERR_HIP;
@@ -759,12 +894,10 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   return MIBAYER_OK;
 }
 
-static void free_slot (Slot &s)
+static void free_slot (mibayer_ctx *c, Slot &s)
 {
-  if (s.d_src)
-    (void) hipFree (s.d_src);
-  if (s.d_dst)
-    (void) hipFree (s.d_dst);
+  cached_free (c->device, s.d_src, c->src_bytes);
+  cached_free (c->device, s.d_dst, c->dst_bytes);
   if (s.ev_in)
     (void) hipEventDestroy (s.ev_in);
   if (s.ev_kernel)
@@ -793,47 +926,52 @@ static void free_slot (Slot &s)
 static void free_ring (mibayer_ctx *c)
 {
   for (Slot &s : c->ring)
-    free_slot (s);
+    free_slot (c, s);
   c->ring.clear ();
 }
 
+/* Waits for the context's OWN frames (their download events), never for the queues it may share with the other
+ * contexts of the device, and hands its device frames to the per-device cache instead of hipFree (which drains the
+ * whole device).  A wedged context (a wait ran into its deadline) waits for nothing and leaves its device-side
+ * resources alone: every HIP call that releases them could block on the dead device. */
 extern "C" void mibayer_destroy (mibayer_ctx *c)
 {
   if (!c)
     return;
   DeviceGuard guard (c->device);
-  if (c->s_h2d)
-    (void) hipStreamSynchronize (c->s_h2d);
-  if (c->s_compute)
-    (void) hipStreamSynchronize (c->s_compute);
-  if (c->s_d2h)
-    (void) hipStreamSynchronize (c->s_d2h);
-  for (Slot &sl : c->ring)
-    if (sl.s_graph)
-      (void) hipStreamSynchronize (sl.s_graph);
-  free_ring (c);
-  free_slot (c->spare);
-  if (c->ev_t0)
-    (void) hipEventDestroy (c->ev_t0);
-  if (c->ev_t1)
-    (void) hipEventDestroy (c->ev_t1);
-  if (c->shared_queues) {
-    std::lock_guard<std::mutex> lk (g_queues_mu);
-    DeviceQueues &q = g_queues[c->device];
-    if (--q.refs == 0) {
-      (void) hipStreamDestroy (q.h2d);
-      (void) hipStreamDestroy (q.compute);
-      (void) hipStreamDestroy (q.d2h);
-      q = DeviceQueues ();
-    }
-  } else {
-    if (c->s_h2d)
-      (void) hipStreamDestroy (c->s_h2d);
-    if (c->s_compute)
-      (void) hipStreamDestroy (c->s_compute);
-    if (c->s_d2h)
-      (void) hipStreamDestroy (c->s_d2h);
+  const bool leak = c->wedged;
+  if (!leak) {
+    (void) wait_own_frames (c);
+    free_ring (c);
+    free_slot (c, c->spare);
+    for (hipEvent_t ev : { c->ev_t0, c->ev_t1, c->ev_fence })
+      if (ev)
+        (void) hipEventDestroy (ev);
   }
+  std::vector<std::pair<void *, size_t>> trim;
+  {
+    std::lock_guard<std::mutex> lk (g_queues_mu);
+    if (c->shared_queues) {
+      DeviceQueues &q = g_queues[c->device];
+      if (--q.refs == 0) {
+        if (!leak) {
+          (void) hipStreamDestroy (q.h2d);
+          (void) hipStreamDestroy (q.compute);
+          (void) hipStreamDestroy (q.d2h);
+        }
+        q = DeviceQueues ();
+      }
+    }
+    if (c->device < 64 && c->counted && --g_cache[c->device].contexts == 0 && !leak)
+      trim.swap (g_cache[c->device].bufs);
+  }
+  if (!c->shared_queues && !leak) {
+    for (hipStream_t st : { c->s_h2d, c->s_compute, c->s_d2h })
+      if (st)
+        (void) hipStreamDestroy (st);
+  }
+  for (auto &b : trim)          /* the last context of the device: nothing of ours is queued there any more */
+    (void) hipFree (b.first);
   delete c;
 }
 
@@ -909,9 +1047,9 @@ extern "C" int mibayer_launch_geometry (const mibayer_ctx *c, int nframes,
 static int alloc_slot (mibayer_ctx *c, Slot &s, bool bands)
 {
   bool bad = false;
-  const hipError_t e_src = hipMalloc ((void **) &s.d_src, c->src_bytes);
+  const hipError_t e_src = cached_malloc (c->device, (void **) &s.d_src, c->src_bytes);
   const hipError_t e_dst = e_src == hipSuccess
-      ? hipMalloc ((void **) &s.d_dst, c->dst_bytes) : e_src;
+      ? cached_malloc (c->device, (void **) &s.d_dst, c->dst_bytes) : e_src;
   if (e_src == hipErrorOutOfMemory || e_dst == hipErrorOutOfMemory) {
     (void) hip_failed (hipErrorOutOfMemory, "hipMalloc (frame ring)");
     (void) hipGetLastError ();
@@ -1253,16 +1391,18 @@ static int enqueue_frame (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
 static int submit_locked (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
     void *tag, bool alone)
 {
+  if (c->wedged)
+    return MIBAYER_ERR_TIMEOUT;
   const int rc = enqueue_frame (c, src, dst, tag, alone);
   if (rc != MIBAYER_OK && rc != MIBAYER_ERR_BUSY) {
     char keep[sizeof t_hip_error];
     memcpy (keep, t_hip_error, sizeof keep);    /* report the first error */
-    (void) hipStreamSynchronize (c->s_h2d);
-    (void) hipStreamSynchronize (c->s_compute);
-    (void) hipStreamSynchronize (c->s_d2h);
-    for (Slot &sl : c->ring)
-      if (sl.s_graph)
-        (void) hipStreamSynchronize (sl.s_graph);
+    fence_queues (c);
+    (void) wait_own_frames (c);
+    /* a context whose device call failed leaves the queues it shares with the other contexts of the device: what it
+     * does from now on (the pool re-does its frames elsewhere and abandons it) stays its own */
+    if (rc == MIBAYER_ERR_HIP)
+      mibayer_internal_private_queues (c);
     memcpy (t_hip_error, keep, sizeof keep);
   }
   return rc;
@@ -1275,7 +1415,9 @@ static int wait_locked (mibayer_ctx *c, void **tag)
   Slot &s = c->ring[(size_t) c->tail];
   {
     Range r ("mibayer:wait");
-    HIP_TRY (hipEventSynchronize (s.ev_out));
+    const int rc = wait_event (c, s.ev_out);
+    if (rc != MIBAYER_OK)
+      return rc;                /* the frame stays where it is: its buffers are still the device's */
   }
   if (tag)
     *tag = s.tag;
@@ -1340,22 +1482,21 @@ extern "C" int mibayer_internal_run_spare (mibayer_ctx *c, const uint8_t *src,
   if (!c->spare_ready) {
     const int rc = alloc_slot (c, c->spare, false);
     if (rc != MIBAYER_OK) {
-      free_slot (c->spare);
+      free_slot (c, c->spare);
       return rc;
     }
     c->spare_ready = true;
   }
+  if (c->wedged)
+    return MIBAYER_ERR_TIMEOUT;
   int rc = enqueue_plain (c, c->spare, src, dst, written_row_bytes (c));
   if (rc != MIBAYER_OK) {
     /* nothing of a half-queued frame may touch the buffers after the error */
-    (void) hipStreamSynchronize (c->s_h2d);
-    (void) hipStreamSynchronize (c->s_compute);
-    (void) hipStreamSynchronize (c->s_d2h);
+    fence_queues (c);
     return rc;
   }
   Range r ("mibayer:wait");
-  HIP_TRY (hipEventSynchronize (c->spare.ev_out));
-  return MIBAYER_OK;
+  return wait_event (c, c->spare.ev_out);
 }
 
 extern "C" int mibayer_internal_is_pageable (const void *p)
@@ -1395,9 +1536,7 @@ extern "C" void mibayer_internal_private_queues (mibayer_ctx *c)
     std::lock_guard<std::mutex> lk (g_queues_mu);
     DeviceQueues &dq = g_queues[c->device];
     if (--dq.refs == 0) {
-      (void) hipStreamSynchronize (dq.h2d);
-      (void) hipStreamSynchronize (dq.compute);
-      (void) hipStreamSynchronize (dq.d2h);
+      /* the last user of the shared set: whatever is still queued there is this context's own */
       (void) hipStreamDestroy (dq.h2d);
       (void) hipStreamDestroy (dq.compute);
       (void) hipStreamDestroy (dq.d2h);
@@ -1426,19 +1565,31 @@ extern "C" int mibayer_host_is_pinned (const void *p)
 
 extern "C" void mibayer_internal_abandon (mibayer_ctx *c)
 {
-  if (!c)
-    return;
+  if (!c || c->wedged)
+    return;                     /* a device that does not answer is not waited for again */
   DeviceGuard guard (c->device);
-  if (c->s_h2d)
-    (void) hipStreamSynchronize (c->s_h2d);
-  if (c->s_compute)
-    (void) hipStreamSynchronize (c->s_compute);
-  if (c->s_d2h)
-    (void) hipStreamSynchronize (c->s_d2h);
-  for (Slot &sl : c->ring)
-    if (sl.s_graph)
-      (void) hipStreamSynchronize (sl.s_graph);
+  (void) wait_own_frames (c);
+  fence_queues (c);
   (void) hipGetLastError ();
+}
+
+extern "C" int mibayer_internal_stall (mibayer_ctx *c, int ms)
+{
+  if (!c || ms < 1 || ms > 5000)
+    return MIBAYER_ERR_ARG;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  HIP_TRY (launch_stall (ms, c->s_compute));
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_set_wait_timeout (mibayer_ctx *c, int ms)
+{
+  if (!c)
+    return MIBAYER_ERR_ARG;
+  c->wait_timeout_ms = ms < 0 ? 10000 : ms;
+  return MIBAYER_OK;
 }
 
 /* ---- device-resident batch path ------------------------------------------------------ */
@@ -1459,6 +1610,8 @@ extern "C" int mibayer_process_device (mibayer_ctx *c, const void *d_src,
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
   Range r ("mibayer:process_device");
+  if ((hipStream_t) hip_stream == c->s_compute)
+    c->dirty_compute = true;
   return launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes,
       (hipStream_t) hip_stream);
 }
@@ -1483,6 +1636,8 @@ extern "C" int mibayer_process_device_list (mibayer_ctx *c,
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
   Range r ("mibayer:process_device_list");
+  if ((hipStream_t) hip_stream == c->s_compute)
+    c->dirty_compute = true;
   if (c->inverse) {             /* no table in the rgb2bayer kernel: frame by frame */
     for (int f = 0; f < nframes; f++) {
       const int rc = launch (c, d_srcs[f], c->src_bytes, d_dsts[f],
@@ -1526,6 +1681,9 @@ extern "C" void *mibayer_ctx_stream (mibayer_ctx *c)
   return c ? (void *) c->s_compute : NULL;
 }
 
+/* Waits for what THIS context has in flight: the download events of its own pending frames and, if it queued
+ * device-resident work on its compute queue since the last call, a fence behind that work.  The queues may be shared
+ * with the other contexts of the device (DeviceQueues): their copies and kernels are not waited for. */
 extern "C" int mibayer_sync (mibayer_ctx *c)
 {
   if (!c)
@@ -1533,9 +1691,18 @@ extern "C" int mibayer_sync (mibayer_ctx *c)
   DeviceGuard guard (c->device);
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
-  HIP_TRY (hipStreamSynchronize (c->s_h2d));
-  HIP_TRY (hipStreamSynchronize (c->s_compute));
-  HIP_TRY (hipStreamSynchronize (c->s_d2h));
+  int rc = wait_own_frames (c);
+  if (rc != MIBAYER_OK)
+    return rc;
+  if (c->dirty_compute) {
+    if (c->wedged)
+      return MIBAYER_ERR_TIMEOUT;
+    HIP_TRY (hipEventRecord (c->ev_fence, c->s_compute));
+    rc = wait_event (c, c->ev_fence);
+    if (rc != MIBAYER_OK)
+      return rc;
+    c->dirty_compute = false;
+  }
   return MIBAYER_OK;
 }
 
@@ -2094,6 +2261,8 @@ extern "C" int mibayer_fill_synthetic (mibayer_ctx *c, void *d_src,
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
   hipStream_t s = (hipStream_t) hip_stream;
+  if (s == c->s_compute)
+    c->dirty_compute = true;
   HIP_TRY (launch_fill_synthetic ((uint8_t *) d_src, c->cfg.width,
           c->cfg.height, c->cfg.src_stride, src_frame_bytes, first_frame,
           nframes, seed, s));

@@ -21,8 +21,9 @@ extern "C" {
  * returns when `dst` is complete.  Safe to call from one other thread while the
  * owner of the context uses mibayer_submit / mibayer_wait (the ring state is not
  * touched; HIP streams are thread-safe); two concurrent calls on one context are
- * not allowed.  This is what the pool's per-shard helper thread runs for frames
- * in pageable memory, and what re-does the frames of a device that failed. */
+ * not allowed.  This is what re-does, on a surviving device, the frames of a
+ * device that failed (the pool's helper threads drive their context's ordinary
+ * submit / wait ring). */
 int mibayer_internal_run_spare (mibayer_ctx *ctx, const uint8_t *src,
     uint8_t *dst);
 
@@ -41,9 +42,19 @@ int mibayer_internal_is_pageable (const void *p);
  * Frames already queued finish where they are; safe at any time. */
 void mibayer_internal_private_queues (mibayer_ctx *ctx);
 
-/* Best-effort quiesce of a context whose device reported an error: waits for
- * whatever still completes, never fails. */
+/* Best-effort quiesce of a context whose device reported an error: waits -- with
+ * the context's deadline -- for the frames it still has in flight and for what a
+ * half-failed submit left on its queues; never fails.  Returns at once for a
+ * context that already ran into a wait deadline (MIBAYER_ERR_TIMEOUT): a device
+ * that does not answer is not waited for again. */
 void mibayer_internal_abandon (mibayer_ctx *ctx);
+
+/* Drill: occupy the context's compute queue for `ms` milliseconds (1 .. 5000) with
+ * a kernel that does nothing but wait -- what a wedged GPU looks like to the host,
+ * except that it ends by itself.  Everything queued behind it on that queue
+ * (frames of this context; of its neighbours too while the device's queues are
+ * shared) completes only afterwards.  Tests and mibayer_pool_inject_stall(). */
+int mibayer_internal_stall (mibayer_ctx *ctx, int ms);
 
 #ifdef __cplusplus
 }

@@ -217,6 +217,9 @@ struct R2BParams {
 hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
     long long row0 = 0, long long nrows = -1);
 
+/* a kernel that only waits, `ms` milliseconds (drills: mibayer_internal_stall) */
+hipError_t launch_stall (int ms, hipStream_t stream);
+
 /* synthetic mosaic generator kernel launcher */
 hipError_t launch_fill_synthetic (uint8_t *d_buf, int width, int height,
     int stride, unsigned long long frame_bytes, uint32_t first_frame,

@@ -1348,6 +1348,26 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
 }
 
 /* ------------------------------------------------------------------------- */
+/* stall drill                                                                 */
+/* ------------------------------------------------------------------------- */
+/* One wave that does nothing for `ticks` ticks of the 100 MHz wall clock: occupies a queue the way a device that
+ * has stopped answering does, and ends by itself (mibayer_internal_stall). */
+__global__ void __launch_bounds__ (64)
+stall_kernel (unsigned long long ticks)
+{
+  const unsigned long long t0 = wall_clock64 ();
+  while (wall_clock64 () - t0 < ticks)
+    __builtin_amdgcn_s_sleep (127);
+}
+
+hipError_t launch_stall (int ms, hipStream_t stream)
+{
+  hipLaunchKernelGGL (stall_kernel, dim3 (1), dim3 (64), 0, stream,
+      (unsigned long long) ms * 100000ull);
+  return hipGetLastError ();
+}
+
+/* ------------------------------------------------------------------------- */
 /* synthetic mosaic (counter-based, stateless per byte)                        */
 /* ------------------------------------------------------------------------- */
 

@@ -32,6 +32,18 @@
  *    buffer was rejected: the runtime's own staging moves ~40 GB/s, a memcpy
  *    thread ~10.)
  *
+ *  - DEADLINES.  A device that stops answering completes nothing: every wait of a context is bounded
+ *    (mibayer_set_wait_timeout), MIBAYER_ERR_TIMEOUT counts as a device failure like MIBAYER_ERR_HIP, and a
+ *    context that timed out is never waited for again (mibayer_internal_abandon returns at once for it).
+ *
+ *  - NUMA-LOCAL ROUTING.  On a two-socket node a frame whose pinned buffer sits next to GPU k should go to GPU k:
+ *    when the shards' devices span more than one NUMA node, a frame is routed to the live shard on the node that
+ *    holds its 4-byte-per-pixel buffer as long as that keeps the rotation balanced (no shard more than its in-flight
+ *    share ahead); otherwise, and whenever the node is unknown, strictly g mod N.  Results keep submission order.
+ *
+ *  - A SUBMIT THREAD PER SHARD (MIBAYER_POOL_THREADS=1): every shard is driven by its helper thread from the start,
+ *    pinned frames included, so N GPUs are fed by N host threads instead of the one streaming thread.
+ *
  *  - FAULT INJECTION for drills and tests: mibayer_pool_inject_fault() /
  *    MIBAYER_INJECT_FAULT=shard:frames make a shard report a device error after
  *    it has completed that many frames.
@@ -47,6 +59,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -75,6 +88,8 @@ struct Shard {
   int device = 0;
   bool alive = true;
   int inflight = 0;             /* frames owned and not yet handed back (streaming thread) */
+  int node = -1;                /* NUMA node next to the device; -1 unknown */
+  long long assigned = 0;       /* frames routed here so far (balance of the NUMA-local routing) */
   std::atomic<long long> completions { 0 };
   std::atomic<long long> fail_after { -1 };     /* fault injection; -1 = never */
   /* helper thread */
@@ -85,6 +100,7 @@ struct Shard {
   std::deque<Frame *> jobs;     /* waiting for room in the context's ring             */
   std::deque<Frame *> ring;     /* in the context's ring, oldest first (helper mode)  */
   bool helper_mode = false;     /* the helper thread owns the context's submit / wait */
+  bool pageable_seen = false;   /* a pageable frame came by: the context has queues of its own */
   int ring_room = 2;            /* stream.inflight                                     */
   bool quit = false;
   bool broken = false;
@@ -101,7 +117,7 @@ struct Shard {
 
 bool device_failure (int rc)
 {
-  return rc == MIBAYER_ERR_HIP || rc == MIBAYER_ERR_NOMEM;
+  return rc == MIBAYER_ERR_HIP || rc == MIBAYER_ERR_NOMEM || rc == MIBAYER_ERR_TIMEOUT;
 }
 
 /* everything the helper still holds is re-done elsewhere (mu held) */
@@ -194,6 +210,9 @@ struct mibayer_pool {
   size_t rr = 0;                /* shard whose turn it is */
   size_t redo_rr = 0;
   bool use_helpers = true;      /* MIBAYER_POOL_HELPERS=0: pageable frames on the calling thread */
+  bool numa_route = false;      /* the shards' devices span more than one NUMA node */
+  bool inverse = false;         /* MIBAYER_FLAG_RGB2BAYER: the source is the 4 B/px side */
+  std::unordered_map<const void *, int> node_of;        /* NUMA node of buffers seen so far (pools recycle them) */
   /* failure report */
   int unreported = 0;
   int failed_device = -1;
@@ -279,13 +298,15 @@ static void queue_to_helper (Shard *sh, Frame *f)
  * one that touches the context's submit / wait ring.  Frames the streaming
  * thread had submitted itself and that are still in that ring are handed over,
  * in order, so the helper retires them first. */
-static void enter_helper_mode (mibayer_pool *pool, int idx)
+static void enter_helper_mode (mibayer_pool *pool, int idx, bool pageable)
 {
   Shard *sh = pool->shards[(size_t) idx];
+  /* blocking (pageable) copies must not queue behind the other shards' (mibayer_hooks.h); pinned frames keep the
+   * shared queues, where their copies go back to back */
   if (sh->helper_mode)
-    return;
-  /* its blocking copies must not queue behind the other shards' (mibayer_hooks.h) */
-  mibayer_internal_private_queues (sh->ctx);
+    return;                     /* its thread already drives the context: the queues stay as they are */
+  if (pageable)
+    mibayer_internal_private_queues (sh->ctx);
   start_helper (sh);
   std::lock_guard<std::mutex> lk (sh->mu);
   sh->helper_mode = true;
@@ -345,6 +366,24 @@ extern "C" int mibayer_pool_create (const mibayer_pool_cfg *cfg,
   pool->use_helpers = pool->shards.size () > 1;
   if (const char *e = getenv ("MIBAYER_POOL_HELPERS"))
     pool->use_helpers = atoi (e) != 0;
+  pool->inverse = (cfg->stream.flags & MIBAYER_FLAG_RGB2BAYER) != 0;
+  {
+    int first = -2;
+    for (Shard *sh : pool->shards) {
+      sh->node = mibayer_device_numa_node (sh->device);
+      if (sh->node >= 0 && first == -2)
+        first = sh->node;
+      else if (sh->node >= 0 && sh->node != first)
+        pool->numa_route = true;
+    }
+    if (const char *e = getenv ("MIBAYER_POOL_NUMA"))
+      pool->numa_route = pool->numa_route && atoi (e) != 0;
+  }
+  /* a submit thread per shard, pinned frames included (include/mibayer.h) */
+  if (const char *e = getenv ("MIBAYER_POOL_THREADS"))
+    if (atoi (e) != 0 && pool->shards.size () > 1)
+      for (size_t i = 0; i < pool->shards.size (); i++)
+        enter_helper_mode (pool, (int) i, false);
   if (const char *e = getenv ("MIBAYER_INJECT_FAULT")) {
     /* "shard:frames[,shard:frames...]" */
     while (*e) {
@@ -412,6 +451,22 @@ extern "C" int mibayer_pool_inject_fault (mibayer_pool *pool, int shard,
   return MIBAYER_OK;
 }
 
+extern "C" int mibayer_pool_set_wait_timeout (mibayer_pool *pool, int ms)
+{
+  if (!pool)
+    return MIBAYER_ERR_ARG;
+  for (Shard *sh : pool->shards)
+    (void) mibayer_set_wait_timeout (sh->ctx, ms);
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_pool_inject_stall (mibayer_pool *pool, int shard, int ms)
+{
+  if (!pool || shard < 0 || shard >= (int) pool->shards.size ())
+    return MIBAYER_ERR_ARG;
+  return mibayer_internal_stall (pool->shards[(size_t) shard]->ctx, ms);
+}
+
 extern "C" int mibayer_pool_take_failure (mibayer_pool *pool, int *device,
     int *alive, char *msg, size_t msg_len)
 {
@@ -448,16 +503,50 @@ extern "C" int mibayer_pool_submit (mibayer_pool *pool, const uint8_t *src,
     }
     if (idx == n)
       return MIBAYER_ERR_HIP;   /* no device left */
-    Shard *sh = pool->shards[idx];
     if (reap_if_broken (pool, (int) idx))
       continue;
+    const size_t turn = idx;
+    if (pool->numa_route) {
+      /* the live shard next to the frame's big buffer, if taking it keeps the rotation balanced */
+      const void *big = pool->inverse ? (const void *) src : (const void *) dst;
+      int node;
+      auto it = pool->node_of.find (big);
+      if (it != pool->node_of.end ()) {
+        node = it->second;
+      } else {
+        node = mibayer_host_numa_node (big);
+        if (pool->node_of.size () > 4096)
+          pool->node_of.clear ();
+        pool->node_of.emplace (big, node);
+      }
+      if (node >= 0 && pool->shards[turn]->node != node) {
+        for (size_t k = 1; k < n; k++) {
+          const size_t i = (turn + k) % n;
+          Shard *cand = pool->shards[i];
+          if (cand->alive && cand->node == node && cand->inflight < pool->per_shard
+              && cand->assigned < pool->shards[turn]->assigned + pool->per_shard) {
+            bool broken;
+            {
+              std::lock_guard<std::mutex> lk (cand->mu);
+              broken = cand->broken;
+            }
+            if (!broken) {
+              idx = i;
+              break;
+            }
+          }
+        }
+      }
+    }
+    Shard *sh = pool->shards[idx];
     if (sh->inflight >= pool->per_shard)
       return MIBAYER_ERR_BUSY;
     Frame f = { src, dst, tag, (int) idx, (int) idx, F_DIRECT, MIBAYER_OK };
-    if (pool->use_helpers && !sh->helper_mode
-        && (mibayer_internal_is_pageable (src)
-            || mibayer_internal_is_pageable (dst)))
-      enter_helper_mode (pool, (int) idx);
+    if (pool->use_helpers && (mibayer_internal_is_pageable (src) || mibayer_internal_is_pageable (dst))
+        && !sh->pageable_seen) {
+      sh->pageable_seen = true;
+      enter_helper_mode (pool, (int) idx, true);
+    }
     if (sh->helper_mode) {
       pool->fifo.push_back (f);
       queue_to_helper (sh, &pool->fifo.back ());
@@ -472,7 +561,9 @@ extern "C" int mibayer_pool_submit (mibayer_pool *pool, const uint8_t *src,
       pool->fifo.push_back (f);
     }
     sh->inflight++;
-    pool->rr = (idx + 1) % n;
+    sh->assigned++;
+    if (idx == turn)
+      pool->rr = (idx + 1) % n;
     return MIBAYER_OK;
   }
 }
@@ -508,14 +599,13 @@ extern "C" int mibayer_pool_wait (mibayer_pool *pool, void **tag)
       kill_shard (pool, f.shard, rc, mibayer_last_hip_error ());    /* f becomes F_REDO */
       continue;
     }
-    if (state == F_FAILED) {
-      if (!device_failure (f.rc))
-        return f.rc;
-      f.state = F_REDO;
-      kill_shard (pool, f.shard, f.rc, NULL);
-      continue;
-    }
-    /* F_REDO: once more on a device that is still in the rotation */
+    if (state == F_FAILED)
+      return f.rc;              /* not a device failure (those become F_REDO): the caller's to handle */
+    /* F_REDO: once more on a device that is still in the rotation.  First the shard it came from: if its helper
+     * thread saw the failure, the shard is still "alive" to this thread and its context still has the frame's
+     * copies queued -- take it out and abandon it BEFORE the frame is converted elsewhere and handed back, or a late
+     * DMA of the dead context lands in a buffer the caller has already released. */
+    (void) reap_if_broken (pool, f.shard);
     size_t idx = n;
     for (size_t k = 0; k < n; k++) {
       const size_t i = (pool->redo_rr + k) % n;

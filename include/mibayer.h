@@ -42,7 +42,10 @@ extern "C" {
  * mibayer_dev_stream_* / mibayer_dev_upload_async / mibayer_dev_event_query;
  * MIBAYER_FLAG_HIPGRAPH now captures the compute-queue segment of a frame.
  * Every v1 entry point keeps its signature and meaning. */
-#define MIBAYER_ABI_VERSION 2
+/* 3: additive over 2 -- deadlines on every host-side wait (MIBAYER_ERR_TIMEOUT,
+ * mibayer_set_wait_timeout, mibayer_pool_set_wait_timeout); mibayer_sync /
+ * mibayer_destroy wait for the context's own frames only. */
+#define MIBAYER_ABI_VERSION 3
 
 /* Bayer order; numbering identical to the reference's anonymous enum
  * GST_BAYER_2_RGB_FORMAT_*, gstbayer2rgb.c:95-101. */
@@ -64,7 +67,11 @@ typedef enum mibayer_status {
   MIBAYER_ERR_HIP = -5,         /* a HIP runtime call failed                 */
   MIBAYER_ERR_NOMEM = -6,
   MIBAYER_ERR_BUSY = -7,        /* async ring full: call mibayer_wait()      */
-  MIBAYER_ERR_EMPTY = -8        /* mibayer_wait() with nothing in flight     */
+  MIBAYER_ERR_EMPTY = -8,       /* mibayer_wait() with nothing in flight     */
+  MIBAYER_ERR_TIMEOUT = -9      /* the device did not complete a frame within
+                                   the wait deadline (mibayer_set_wait_timeout);
+                                   the context is wedged from then on: every
+                                   later call returns this at once           */
 } mibayer_status;
 
 /* Per-stream configuration == the fields of struct _GstBayer2RGB
@@ -145,16 +152,28 @@ int mibayer_submit (mibayer_ctx *ctx, const uint8_t *src, uint8_t *dst,
     void *tag);
 int mibayer_wait (mibayer_ctx *ctx, void **tag);
 int mibayer_pending (const mibayer_ctx *ctx);
+/* Deadline, in milliseconds, of every host-side wait for the device on behalf of
+ * this context (mibayer_wait, mibayer_process_host, mibayer_sync, mibayer_destroy):
+ * a GPU that has stopped answering completes nothing, and the reference's
+ * streaming thread must not hang on it (cf. gst/debugutils/gstwatchdog.c:21-123).
+ * Default 10000 (also MIBAYER_WAIT_TIMEOUT_MS); 0 = wait for ever; < 0 = default.
+ * A wait that runs into the deadline returns MIBAYER_ERR_TIMEOUT and leaves the
+ * frame where it is -- its buffers still belong to the device. */
+int mibayer_set_wait_timeout (mibayer_ctx *ctx, int ms);
 
 /* ---- multi-GPU frame sharding (host path) ------------------------------------ */
 
 /* Frames are independent (the reference keeps no state between frames,
  * gstbayer2rgb.c:387-451), so a stream is sharded round-robin over GPUs with no
  * collective: frame g goes to shard g % ndevices, every shard is a mibayer_ctx
- * with its own streams, device ring and (optionally) graphs, and results are
- * handed back in submission order.  One host thread drives all shards: with
- * pinned buffers every call below only enqueues work.  Ordinals may repeat
- * (N logical shards on one GPU). */
+ * with its own device ring and (optionally) graphs, and results are handed back
+ * in submission order.  By default the calling thread drives all shards -- with
+ * pinned buffers every call below only enqueues work -- and a shard that sees
+ * pageable buffers gets a helper thread; MIBAYER_POOL_THREADS=1 gives every
+ * shard its own submit thread from the start.  When the devices span more than
+ * one NUMA node, a frame goes to the live shard next to its 4-byte-per-pixel
+ * buffer as long as that keeps the rotation balanced (MIBAYER_POOL_NUMA=0:
+ * strictly g % ndevices).  Ordinals may repeat (N logical shards on one GPU). */
 #define MIBAYER_MAX_SHARDS 16
 typedef struct mibayer_pool_cfg {
   uint32_t struct_size;         /* = sizeof (mibayer_pool_cfg)                  */
@@ -198,6 +217,14 @@ int mibayer_pool_take_failure (mibayer_pool *pool, int *device, int *alive,
  * the same at mibayer_pool_create(). */
 int mibayer_pool_inject_fault (mibayer_pool *pool, int shard,
     long long after_frames);
+/* The wait deadline of every shard (mibayer_set_wait_timeout): a device that
+ * does not complete a frame within `ms` milliseconds is dropped from the rotation
+ * like one that reported an error, and is never waited for again. */
+int mibayer_pool_set_wait_timeout (mibayer_pool *pool, int ms);
+/* Stall drill: the compute queue of shard `shard` is occupied for `ms`
+ * milliseconds (1 .. 5000) by a kernel that only waits -- a device that has
+ * stopped answering, as far as the host can tell. */
+int mibayer_pool_inject_stall (mibayer_pool *pool, int shard, int ms);
 
 /* ---- device-resident batch path (roofline runs, GPU-side consumers) -------- */
 

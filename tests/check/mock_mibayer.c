@@ -14,7 +14,14 @@
  * would write, so a buffer the element unmapped or released too early is a sanitizer report.  The output is a
  * stamp, not an image: bytes 0..3 of the frame = submission sequence number, every other written byte = the
  * first source byte of that frame.  MOCK_MIBAYER_FAIL="index:frames" turns the index-th context into a failed
- * device after that many frames; MOCK_MIBAYER_PAGEABLE=1 sends every frame down the pool's helper-thread path.
+ * device after that many frames; MOCK_MIBAYER_HANG="index:frames" into one that stops answering (its waits run into
+ * the deadline of mibayer_set_wait_timeout and return MIBAYER_ERR_TIMEOUT; anything that would block on it for
+ * ever -- a wait with no deadline, a destroy of a context that was never abandoned -- aborts the test);
+ * MOCK_MIBAYER_PAGEABLE=1 sends every frame down the pool's helper-thread path; MOCK_MIBAYER_NUMA_NODES=k spreads
+ * the fake devices over k NUMA nodes (device d -> node d % k) and mibayer_host_alloc_near() remembers where it
+ * "placed" a block.  A failed context that still holds frames and was NOT abandoned writes them LATE, when it is
+ * destroyed -- the DMA that a dead device's queue may still carry out -- so a pool that hands a re-done frame back
+ * before abandoning the context it came from is a sanitizer report (the driver frees every frame on delivery).
  */
 #include "mibayer.h"
 
@@ -23,6 +30,7 @@
 
 #include <pthread.h>
 #include <stdio.h>
+#include <time.h>
 
 #include "mibayer_hooks.h"
 
@@ -56,7 +64,59 @@ struct mibayer_ctx
   int completed;                /* frames finished on this "device" */
   int fail_after;               /* MOCK_MIBAYER_FAIL=index:frames -> device error after that many frames; -1 never */
   int dead;
+  int hang_after;               /* MOCK_MIBAYER_HANG=index:frames -> stops answering after that many frames; -1 never */
+  int hung;
+  int timeout_ms;               /* mibayer_set_wait_timeout; 0 = none */
+  int abandoned;
 };
+
+/* fake NUMA placement: blocks handed out by mibayer_host_alloc_near */
+#define MOCK_MAX_BLOCKS 4096
+static struct
+{
+  const uint8_t *base;
+  size_t bytes;
+  int node;
+} g_blocks[MOCK_MAX_BLOCKS];
+static int g_nblocks;
+static int g_numa_local, g_numa_remote;
+
+static int
+mock_nodes (void)
+{
+  const char *e = getenv ("MOCK_MIBAYER_NUMA_NODES");
+
+  return e ? atoi (e) : 0;
+}
+
+int
+mibayer_device_numa_node (int device)
+{
+  const int k = mock_nodes ();
+
+  return (k > 0 && device >= 0) ? device % k : -1;
+}
+
+int
+mibayer_host_numa_node (const void *p)
+{
+  int i, node = -1;
+
+  pthread_mutex_lock (&g_lock);
+  for (i = 0; i < g_nblocks; i++)
+    if ((const uint8_t *) p >= g_blocks[i].base && (const uint8_t *) p < g_blocks[i].base + g_blocks[i].bytes)
+      node = g_blocks[i].node;
+  pthread_mutex_unlock (&g_lock);
+  return node;
+}
+
+/* frames converted on the node of their destination buffer / on another one (the driver prints both) */
+void
+mock_numa_counts (int *local, int *remote)
+{
+  *local = g_numa_local;
+  *remote = g_numa_remote;
+}
 
 int
 mibayer_device_count (void)
@@ -87,7 +147,20 @@ mibayer_host_alloc (size_t bytes)
 void *
 mibayer_host_alloc_near (int device, size_t bytes)
 {
-  return mibayer_host_alloc (bytes);
+  void *p = mibayer_host_alloc (bytes);
+  const int node = mibayer_device_numa_node (device);
+
+  if (p && node >= 0) {
+    pthread_mutex_lock (&g_lock);
+    if (g_nblocks < MOCK_MAX_BLOCKS) {
+      g_blocks[g_nblocks].base = p;
+      g_blocks[g_nblocks].bytes = bytes ? bytes : 1;
+      g_blocks[g_nblocks].node = node;
+      g_nblocks++;
+    }
+    pthread_mutex_unlock (&g_lock);
+  }
+  return p;
 }
 
 /* MOCK_MIBAYER_PAGEABLE=1 makes every host buffer count as pageable */
@@ -102,6 +175,15 @@ mibayer_host_is_pinned (const void *p)
 void
 mibayer_host_free (void *p)
 {
+  int i;
+
+  pthread_mutex_lock (&g_lock);
+  for (i = 0; i < g_nblocks; i++)
+    if (g_blocks[i].base == (const uint8_t *) p) {
+      g_blocks[i] = g_blocks[--g_nblocks];
+      break;
+    }
+  pthread_mutex_unlock (&g_lock);
   free (p);
 }
 
@@ -130,6 +212,38 @@ mock_convert (const mibayer_ctx * c, const mock_frame * fr)
   memcpy (fr->dst, &fr->seq, 4);
   if (sum == 0xffffffffu)       /* keep the reads */
     fr->dst[4] ^= 1;
+  if (mock_nodes () > 0) {
+    const int bn = mibayer_host_numa_node (inverse ? (const void *) fr->src : (const void *) fr->dst);
+
+    pthread_mutex_lock (&g_lock);
+    if (bn >= 0 && bn == mibayer_device_numa_node (f->device))
+      g_numa_local++;
+    else
+      g_numa_remote++;
+    pthread_mutex_unlock (&g_lock);
+  }
+}
+
+/* 1 when this "device" has stopped answering (from now on): the caller's wait runs into its deadline */
+static int
+mock_device_hangs (mibayer_ctx * c)
+{
+  if (c->hung)
+    return 1;
+  if (c->hang_after >= 0 && c->completed >= c->hang_after) {
+    c->hung = 1;
+    if (c->timeout_ms <= 0) {
+      fprintf (stderr, "mock_mibayer: wait without a deadline on a device that never answers\n");
+      abort ();
+    }
+    {
+      struct timespec nap = { 0, (c->timeout_ms > 20 ? 20 : c->timeout_ms) * 1000000L };
+
+      nanosleep (&nap, NULL);   /* the deadline passes */
+    }
+    return 1;
+  }
+  return 0;
 }
 
 /* 1 when this "device" fails now (and from now on) */
@@ -152,6 +266,8 @@ mibayer_submit (mibayer_ctx * c, const uint8_t * src, uint8_t * dst, void *tag)
 
   if (!c || !src || !dst)
     return MIBAYER_ERR_ARG;
+  if (c->hung)
+    return MIBAYER_ERR_TIMEOUT;
   if (c->dead)
     return MIBAYER_ERR_HIP;
   if (c->count == c->cfg.inflight)
@@ -176,6 +292,8 @@ mibayer_wait (mibayer_ctx * c, void **tag)
     return MIBAYER_ERR_ARG;
   if (c->count == 0)
     return MIBAYER_ERR_EMPTY;
+  if (mock_device_hangs (c))
+    return MIBAYER_ERR_TIMEOUT; /* nothing comes back: the frame stays where it is */
   if (mock_device_fails (c))
     return MIBAYER_ERR_HIP;     /* nothing was converted: the frame stays where it is */
   fr = c->ring[c->head];
@@ -212,6 +330,8 @@ mibayer_internal_run_spare (mibayer_ctx * c, const uint8_t * src, uint8_t * dst)
 
   if (!c || !src || !dst)
     return MIBAYER_ERR_ARG;
+  if (mock_device_hangs (c))
+    return MIBAYER_ERR_TIMEOUT;
   if (mock_device_fails (c))
     return MIBAYER_ERR_HIP;
   fr.src = src;
@@ -243,8 +363,28 @@ mibayer_internal_private_queues (mibayer_ctx * c)
 void
 mibayer_internal_abandon (mibayer_ctx * c)
 {
-  if (c)
+  if (c) {
     c->count = 0;               /* whatever the dead device held is never written */
+    c->abandoned = 1;
+  }
+}
+
+int
+mibayer_set_wait_timeout (mibayer_ctx * c, int ms)
+{
+  if (!c)
+    return MIBAYER_ERR_ARG;
+  c->timeout_ms = ms < 0 ? 10000 : ms;
+  return MIBAYER_OK;
+}
+
+int
+mibayer_internal_stall (mibayer_ctx * c, int ms)
+{
+  if (!c)
+    return MIBAYER_ERR_ARG;
+  c->hang_after = c->completed; /* from the next frame on */
+  return MIBAYER_OK;
 }
 
 /* ---- the entry points plugin `mihip` uses (device memory, events, device-resident launches) ------------------
@@ -339,6 +479,8 @@ mibayer_create (const mibayer_cfg * cfg, mibayer_ctx ** out)
   c->src_bytes = (size_t) c->cfg.src_stride * cfg->height;
   c->dst_bytes = (size_t) c->cfg.dst_stride * cfg->height;
   c->fail_after = -1;
+  c->hang_after = -1;
+  c->timeout_ms = 10000;
   pthread_mutex_lock (&g_lock);
   if (g_live_host_ctx++ == 0)
     g_seq = 0;                  /* a new pool stamps its frames from 0 */
@@ -363,6 +505,21 @@ mibayer_create (const mibayer_cfg * cfg, mibayer_ctx ** out)
         c->fail_after = (int) n;
       e = (*end == ',') ? end + 1 : end;
     }
+    e = getenv ("MOCK_MIBAYER_HANG");
+    while (e && *e) {
+      char *end = NULL;
+      long idx = strtol (e, &end, 10), n;
+
+      if (end == e || *end != ':')
+        break;
+      e = end + 1;
+      n = strtol (e, &end, 10);
+      if (end == e)
+        break;
+      if (idx == c->index)
+        c->hang_after = (int) n;
+      e = (*end == ',') ? end + 1 : end;
+    }
   }
   *out = c;
   return MIBAYER_OK;
@@ -384,6 +541,18 @@ mibayer_destroy (mibayer_ctx * c)
 {
   if (!c)
     return;
+  if (c->hung && !c->abandoned && c->count > 0) {
+    fprintf (stderr, "mock_mibayer: destroy would block for ever on a device that never answers\n");
+    abort ();
+  }
+  /* a failed device whose context was never abandoned still carries out what it had queued: late writes */
+  while (c->dead && !c->abandoned && c->count > 0) {
+    mock_frame fr = c->ring[c->head];
+
+    c->head = (c->head + 1) % MOCK_MAX_PENDING;
+    c->count--;
+    mock_convert (c, &fr);
+  }
   mibayer_sync (c);
   pthread_mutex_lock (&g_lock);
   g_live_host_ctx--;

@@ -5,7 +5,14 @@
  *
  *   pool_logic <shards> <inflight> <frames> <pageable 0|1> <fault list "shard:after,..." or -> <expect ok|dead>
  *
- * Prints: delivered=<n> dropped_devices=<n> alive=<n> capacity=<n> rc=<last status>
+ * Environment: POOL_LOGIC_DISTINCT=1 gives shard i the device ordinal i (the double needs MOCK_MIBAYER_DEVICES >= shards);
+ * POOL_LOGIC_NEAR=1 allocates frame f's buffers with mibayer_host_alloc_near (devices[f % shards]) -- what the
+ * element's pinned pool does -- so the NUMA-local routing has something to look at; POOL_LOGIC_TIMEOUT_MS sets the
+ * pool's wait deadline; POOL_LOGIC_STALL="shard" calls mibayer_pool_inject_stall on that shard after a few frames.
+ * Every frame's buffers are freed the moment it has been delivered and checked: anything that touches them later
+ * (a DMA of a context that should have been abandoned first) is a sanitizer report.
+ *
+ * Prints: delivered=<n> dropped_devices=<n> alive=<n> capacity=<n> rc=<last status> local=<n> remote=<n>
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,6 +22,8 @@
 #include "mibayer.h"
 
 static const int W = 64, H = 8;
+
+extern "C" void mock_numa_counts (int *local, int *remote);
 
 int
 main (int argc, char **argv)
@@ -42,8 +51,10 @@ main (int argc, char **argv)
   pc.stream.b_off = 2;
   pc.stream.inflight = inflight;
   pc.ndevices = nshards;
+  const bool distinct = getenv ("POOL_LOGIC_DISTINCT") != NULL;
+  const bool near_alloc = getenv ("POOL_LOGIC_NEAR") != NULL;
   for (int i = 0; i < nshards; i++)
-    pc.devices[i] = 0;
+    pc.devices[i] = distinct ? i : 0;
   mibayer_pool *pool = NULL;
   int rc = mibayer_pool_create (&pc, &pool);
   if (rc != MIBAYER_OK) {
@@ -62,12 +73,21 @@ main (int argc, char **argv)
     e = *end == ',' ? end + 1 : end;
   }
 
+  if (const char *e = getenv ("POOL_LOGIC_TIMEOUT_MS"))
+    if (mibayer_pool_set_wait_timeout (pool, atoi (e)) != MIBAYER_OK)
+      return 64;
+  const int stall_shard = getenv ("POOL_LOGIC_STALL") ? atoi (getenv ("POOL_LOGIC_STALL")) : -1;
   const size_t src_bytes = (size_t) W * H, dst_bytes = (size_t) 4 * W * H;
   /* exact-size heap buffers per frame: the sanitizer sees every out-of-bounds or use-after-free */
   std::vector<uint8_t *> srcs ((size_t) nframes), dsts ((size_t) nframes);
   for (int f = 0; f < nframes; f++) {
-    srcs[(size_t) f] = (uint8_t *) malloc (src_bytes);
-    dsts[(size_t) f] = (uint8_t *) malloc (dst_bytes);
+    if (near_alloc) {
+      srcs[(size_t) f] = (uint8_t *) mibayer_host_alloc_near (pc.devices[f % nshards], src_bytes);
+      dsts[(size_t) f] = (uint8_t *) mibayer_host_alloc_near (pc.devices[f % nshards], dst_bytes);
+    } else {
+      srcs[(size_t) f] = (uint8_t *) malloc (src_bytes);
+      dsts[(size_t) f] = (uint8_t *) malloc (dst_bytes);
+    }
     memset (srcs[(size_t) f], 1 + f % 250, src_bytes);
     memset (dsts[(size_t) f], 0, dst_bytes);
   }
@@ -97,6 +117,15 @@ main (int argc, char **argv)
     for (size_t k = 4; k < dst_bytes; k++)
       if (d[k] != (uint8_t) (1 + delivered % 250))
         exit (12);
+    /* handed back: the caller may release the buffers now */
+    if (near_alloc) {
+      mibayer_host_free (srcs[(size_t) delivered]);
+      mibayer_host_free (dsts[(size_t) delivered]);
+    } else {
+      free (srcs[(size_t) delivered]);
+      free (dsts[(size_t) delivered]);
+    }
+    srcs[(size_t) delivered] = dsts[(size_t) delivered] = NULL;
     delivered++;
     return true;
   };
@@ -117,6 +146,8 @@ main (int argc, char **argv)
       break;
     }
     submitted++;
+    if (submitted == 3 && stall_shard >= 0 && mibayer_pool_inject_stall (pool, stall_shard, 1000) != MIBAYER_OK)
+      return 64;
     if (mibayer_pool_pending (pool) > mibayer_pool_capacity (pool) + inflight * nshards)
       exit (14);
   }
@@ -128,14 +159,21 @@ main (int argc, char **argv)
     int dev, alive;
     dropped += mibayer_pool_take_failure (pool, &dev, &alive, msg, sizeof msg);
   }
-  printf ("delivered=%d dropped_devices=%d alive=%d capacity=%d rc=%d\n", delivered, dropped,
-      mibayer_pool_alive (pool), mibayer_pool_capacity (pool), last);
+  int local = 0, remote = 0;
+  mock_numa_counts (&local, &remote);
+  printf ("delivered=%d dropped_devices=%d alive=%d capacity=%d rc=%d local=%d remote=%d\n", delivered, dropped,
+      mibayer_pool_alive (pool), mibayer_pool_capacity (pool), last, local, remote);
   mibayer_pool_destroy (pool);
   for (int f = 0; f < nframes; f++) {
-    free (srcs[(size_t) f]);
-    free (dsts[(size_t) f]);
+    if (near_alloc) {
+      mibayer_host_free (srcs[(size_t) f]);
+      mibayer_host_free (dsts[(size_t) f]);
+    } else {
+      free (srcs[(size_t) f]);
+      free (dsts[(size_t) f]);
+    }
   }
   if (expect_dead)
-    return (dead && last == MIBAYER_ERR_HIP) ? 0 : 20;
+    return (dead && (last == MIBAYER_ERR_HIP || last == MIBAYER_ERR_TIMEOUT)) ? 0 : 20;
   return (!dead && delivered == nframes) ? 0 : 21;
 }

@@ -107,3 +107,67 @@ def test_randomised_scenarios(driver):
         assert res.returncode in (0, 21), (res.returncode, shards, inflight, frames, pageable, faults, out[-1000:])
         if res.returncode == 21:
             assert len(which) == shards, (shards, faults, out[-500:])
+
+
+@pytest.mark.parametrize("pageable", [False, True], ids=["pinned", "pageable"])
+def test_a_device_that_stops_answering_is_dropped_after_the_deadline(driver, pageable):
+    """MOCK_MIBAYER_HANG: the context's waits run into the deadline (MIBAYER_ERR_TIMEOUT).  The pool treats that
+    like a device error -- the shard leaves the rotation, its frames are converted again elsewhere, order is kept,
+    ONE note -- and never waits for that context again (the double aborts on a wait without deadline, and on the
+    destroy of a hung context that was not abandoned)."""
+    env = {"MOCK_MIBAYER_HANG": "1:3", "POOL_LOGIC_TIMEOUT_MS": "30"}
+    kv, err = run(driver, 4, 2, 60, pageable, "-", "ok", env=env)
+    assert kv["delivered"] == "60" and kv["dropped_devices"] == "1" and kv["alive"] == "3"
+    assert err.count("note:") == 1 and "dropped from the rotation" in err
+    # two of three stop answering at different times; hang and error mixed
+    kv, _ = run(driver, 3, 2, 50, pageable, "-", "ok", env={"MOCK_MIBAYER_HANG": "0:2,2:7", "POOL_LOGIC_TIMEOUT_MS": "20"})
+    assert kv["delivered"] == "50" and kv["alive"] == "1"
+    kv, _ = run(driver, 4, 3, 70, pageable, "3:4", "ok", env={"MOCK_MIBAYER_HANG": "1:5", "POOL_LOGIC_TIMEOUT_MS": "20"})
+    assert kv["delivered"] == "70" and kv["alive"] == "2"
+    # every device hangs: the stream ends with the timeout status, nothing blocks
+    kv, _ = run(driver, 2, 2, 30, pageable, "-", "dead", env={"MOCK_MIBAYER_HANG": "0:3,1:5", "POOL_LOGIC_TIMEOUT_MS": "20"})
+    assert kv["alive"] == "0" and kv["rc"] in ("-9", "-5")
+
+
+def test_stall_drill_through_the_pool_api(driver):
+    kv, err = run(driver, 3, 2, 40, False, "-", "ok", env={"POOL_LOGIC_STALL": "2", "POOL_LOGIC_TIMEOUT_MS": "25"})
+    assert kv["delivered"] == "40" and kv["alive"] == "2" and err.count("note:") == 1
+
+
+@pytest.mark.parametrize("threads", ["0", "1"], ids=["streaming_thread", "thread_per_shard"])
+def test_numa_local_routing_keeps_order_and_balance(driver, threads):
+    """Two fake NUMA nodes, four devices (device d on node d % 2), frame f's buffers allocated next to
+    devices[f % 4] as the element's pinned pool does: every frame is converted on the node that holds its buffer,
+    in order; with a device gone the survivors on the right node take over as far as the balance allows, and the
+    stream still delivers everything.  MIBAYER_POOL_THREADS=1: a submit thread per shard (pinned frames too)."""
+    env = {"MOCK_MIBAYER_DEVICES": "4", "MOCK_MIBAYER_NUMA_NODES": "2", "POOL_LOGIC_DISTINCT": "1",
+           "POOL_LOGIC_NEAR": "1", "MIBAYER_POOL_THREADS": threads}
+    kv, _ = run(driver, 4, 2, 96, False, "-", "ok", env=env)
+    assert kv["delivered"] == "96" and int(kv["local"]) >= 0.9 * 96, kv
+    # buffers handed out in an order that does not match the rotation: frame f next to devices[(f * 3 + 1) % 4]
+    # is not what the driver does, but a dead device gives the same effect -- its node-mates take its frames
+    kv, _ = run(driver, 4, 2, 96, False, "1:5", "ok", env=env)
+    assert kv["delivered"] == "96" and kv["alive"] == "3" and int(kv["local"]) >= 0.6 * 96, kv
+    # routing off: strictly g mod N (same result here, since the buffers follow the rotation)
+    kv, _ = run(driver, 4, 2, 40, False, "-", "ok", env=dict(env, MIBAYER_POOL_NUMA="0"))
+    assert kv["delivered"] == "40"
+    # one node only: nothing to route
+    kv, _ = run(driver, 4, 2, 40, False, "-", "ok", env=dict(env, MOCK_MIBAYER_NUMA_NODES="1"))
+    assert kv["delivered"] == "40" and kv["local"] == "40"
+
+
+def test_thread_per_shard_with_faults(driver):
+    for faults in ("-", "2:4", "0:1,3:6"):
+        kv, _ = run(driver, 4, 2, 70, False, faults, "ok", env={"MIBAYER_POOL_THREADS": "1"})
+        assert kv["delivered"] == "70", (faults, kv)
+
+
+def test_a_redone_frame_is_not_handed_back_before_its_dead_context_is_abandoned(driver):
+    """a helper thread sees its device fail near the end of the stream; the streaming thread, which is
+    only draining, re-does the frames on another shard.  Before they are handed back, the context they came from
+    must have been taken out and abandoned -- the double lets a failed, un-abandoned context carry out its queued
+    writes late, into buffers the driver frees on delivery."""
+    for spec in ((4, 2, 11), (4, 2, 10), (3, 3, 9), (4, 3, 14), (2, 2, 7)):
+        for fail in ("1:2", "2:1", "3:2", "0:3"):
+            kv, _ = run(driver, spec[0], spec[1], spec[2], True, "-", "ok", env={"MOCK_MIBAYER_FAIL": fail})
+            assert kv["delivered"] == str(spec[2]), (spec, fail, kv)
