@@ -1978,19 +1978,26 @@ extern "C" void *mibayer_host_alloc_near (int device, size_t bytes)
   const int node = mibayer_device_numa_node (device);
   if (node < 0 || node >= 1024)
     return mibayer_host_alloc (bytes);
-  constexpr int kMpolDefault = 0, kMpolPreferred = 1;
+  constexpr int kMpolPreferred = 1;
   unsigned long mask[1024 / (8 * sizeof (unsigned long))];
   memset (mask, 0, sizeof mask);
   mask[(size_t) node / (8 * sizeof (unsigned long))]
       |= 1ul << ((size_t) node % (8 * sizeof (unsigned long)));
-  const bool bound = syscall (SYS_set_mempolicy, kMpolPreferred, mask,
+  /* the calling thread's own policy (numactl --interleave, an application's set_mempolicy ...) is put back
+   * exactly as it was: this runs on arbitrary streaming threads, once per pool buffer */
+  int old_mode = 0;
+  unsigned long old_mask[1024 / (8 * sizeof (unsigned long))];
+  memset (old_mask, 0, sizeof old_mask);
+  const bool saved = syscall (SYS_get_mempolicy, &old_mode, old_mask,
+      (unsigned long) (8 * sizeof old_mask), NULL, 0ul) == 0;
+  const bool bound = saved && syscall (SYS_set_mempolicy, kMpolPreferred, mask,
       (unsigned long) (8 * sizeof mask)) == 0;
   void *p = NULL;
   const bool bad = hip_failed (hipHostMalloc (&p, bytes ? bytes : 1,
           (bound ? hipHostMallocNumaUser : 0u) | hipHostMallocPortable),
       "hipHostMalloc");
   if (bound)
-    (void) syscall (SYS_set_mempolicy, kMpolDefault, NULL, 0ul);
+    (void) syscall (SYS_set_mempolicy, old_mode, old_mask, (unsigned long) (8 * sizeof old_mask));
   if (bad) {
     (void) hipGetLastError ();
     return mibayer_host_alloc (bytes);

@@ -65,13 +65,15 @@ enum
   PROP_DEVICES,
   PROP_INFLIGHT,
   PROP_HIPGRAPH,
-  PROP_PINNED_POOL
+  PROP_PINNED_POOL,
+  PROP_TIMEOUT_MS
 };
 
 #define DEFAULT_DEVICE_ID 0
 #define DEFAULT_INFLIGHT 1
 #define DEFAULT_HIPGRAPH FALSE
 #define DEFAULT_PINNED_POOL TRUE
+#define DEFAULT_TIMEOUT_MS 10000
 
 /* one frame between submit and wait: both buffers stay mapped until the GPU
  * has written the output */
@@ -109,6 +111,23 @@ post_gpu_failure (GstMiBayerElement * self, int rc)
       ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
 }
 
+/* an error found while flow_lock is held: remembered (the first one wins), posted by element_post_notes once
+ * the lock is released -- posting runs the bus' sync handler, i.e. application code */
+static void
+element_defer_error (GstMiBayerElement * self, GQuark domain, gint code,
+    gchar * text, gchar * debug)
+{
+  if (self->error_text != NULL) {
+    g_free (text);
+    g_free (debug);
+    return;
+  }
+  self->error_domain = domain;
+  self->error_code = code;
+  self->error_text = text;
+  self->error_debug = debug;
+}
+
 /* the pool dropped a device (flow_lock held): remember ONE note for the bus
  * and follow the pool's new capacity */
 static void
@@ -136,12 +155,22 @@ element_note_failures (GstMiBayerElement * self)
 static void
 element_post_notes (GstMiBayerElement * self)
 {
-  gchar *note;
+  gchar *note, *text, *debug;
+  GQuark domain;
+  gint code;
 
   g_mutex_lock (&self->flow_lock);
   note = self->failure_note;
   self->failure_note = NULL;
+  text = self->error_text;
+  debug = self->error_debug;
+  domain = self->error_domain;
+  code = self->error_code;
+  self->error_text = self->error_debug = NULL;
   g_mutex_unlock (&self->flow_lock);
+  if (text != NULL)             /* takes ownership of both strings */
+    gst_element_message_full (GST_ELEMENT (self), GST_MESSAGE_ERROR, domain,
+        code, text, debug, __FILE__, GST_FUNCTION, __LINE__);
   if (note != NULL) {
     GST_ELEMENT_WARNING (self, RESOURCE, FAILED,
         ("%s: a GPU failed and was dropped from the rotation; its frames were "
@@ -292,8 +321,25 @@ element_ensure_pool (GstMiBayerElement * self, gint video_stride)
 
   if (self->pool && self->pool_stride == video_stride)
     return TRUE;
-  /* (flow_lock held) a new stride with frames still in flight cannot happen:
-   * set_caps drained them; what is left is an idle pool of the old stride */
+  /* (flow_lock held) The mapped stride comes with every buffer (GstVideoMeta): it can change without a CAPS
+   * event -- a RECONFIGURE, a new downstream pool -- while frames of the old stride are still in flight in queued
+   * mode.  They belong to the old pool: finish them, in order, before it goes (their outputs wait in `ready`
+   * and leave ahead of the new frame). */
+  while (self->pool != NULL && !g_queue_is_empty (&self->pending)) {
+    GstBuffer *done = NULL;
+    gboolean owned = FALSE;
+    int gpu_rc = MIBAYER_OK;
+
+    if (element_collect_locked (self, &done, &owned, &gpu_rc) != GST_FLOW_OK) {
+      element_defer_error (self, GST_RESOURCE_ERROR, GST_RESOURCE_ERROR_FAILED,
+          g_strdup_printf ("%s: GPU conversion failed", LABEL (self)),
+          g_strdup_printf ("%s %s", mibayer_strerror (gpu_rc),
+              mibayer_last_hip_error ()));
+      continue;
+    }
+    if (done != NULL && owned)
+      g_queue_push_tail (&self->ready, done);
+  }
   if (self->pool) {
     mibayer_pool_destroy (self->pool);
     self->pool = NULL;
@@ -321,9 +367,9 @@ element_ensure_pool (GstMiBayerElement * self, gint video_stride)
   pc.stream.flags = (self->act.use_hipgraph ? MIBAYER_FLAG_HIPGRAPH : 0)
       | (inverse ? MIBAYER_FLAG_RGB2BAYER : 0);
   if (!element_parse_devices (self, &pc)) {
-    GST_ELEMENT_ERROR (self, LIBRARY, SETTINGS,
-        ("%s: cannot parse devices=\"%s\"", LABEL (self), self->act.devices),
-        (NULL));
+    element_defer_error (self, GST_LIBRARY_ERROR, GST_LIBRARY_ERROR_SETTINGS,
+        g_strdup_printf ("%s: cannot parse devices=\"%s\"", LABEL (self),
+            self->act.devices), NULL);
     return FALSE;
   }
 
@@ -331,22 +377,27 @@ element_ensure_pool (GstMiBayerElement * self, gint video_stride)
   if (rc != MIBAYER_OK) {
     self->pool = NULL;
     if (rc == MIBAYER_ERR_NO_DEVICE) {
-      GST_ELEMENT_ERROR (self, RESOURCE, NOT_FOUND,
+      element_defer_error (self, GST_RESOURCE_ERROR, GST_RESOURCE_ERROR_NOT_FOUND,
+          g_strdup_printf
           ("%s: no usable MI355X / HIP device (device-id=%d devices=%s)",
               LABEL (self), self->act.device_id,
               self->act.devices ? self->act.devices : ""),
-          ("%s; this element has no CPU path", mibayer_strerror (rc)));
+          g_strdup_printf ("%s; this element has no CPU path",
+              mibayer_strerror (rc)));
     } else if (rc == MIBAYER_ERR_GEOMETRY) {
-      GST_ELEMENT_ERROR (self, STREAM, FORMAT,
-          ("%s: unsupported frame geometry %dx%d", LABEL (self), self->width,
-              self->height), ("%s", mibayer_strerror (rc)));
+      element_defer_error (self, GST_STREAM_ERROR, GST_STREAM_ERROR_FORMAT,
+          g_strdup_printf ("%s: unsupported frame geometry %dx%d", LABEL (self),
+              self->width, self->height), g_strdup (mibayer_strerror (rc)));
     } else {
-      GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
-          ("%s: cannot create GPU context", LABEL (self)),
-          ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
+      element_defer_error (self, GST_RESOURCE_ERROR, GST_RESOURCE_ERROR_FAILED,
+          g_strdup_printf ("%s: cannot create GPU context", LABEL (self)),
+          g_strdup_printf ("%s %s", mibayer_strerror (rc),
+              mibayer_last_hip_error ()));
     }
     return FALSE;
   }
+  /* a GPU that stops answering is dropped like one that reports an error, after this long */
+  (void) mibayer_pool_set_wait_timeout (self->pool, self->act.timeout_ms);
   self->pool_stride = video_stride;
   self->capacity = mibayer_pool_capacity (self->pool);
   EL_DEBUG (self, "GPU pool: %d device(s), %d frame(s) in flight, "
@@ -389,6 +440,9 @@ element_set_property (GObject * object, guint prop_id, const GValue * value,
     case PROP_PINNED_POOL:
       self->pinned_pool = g_value_get_boolean (value);
       break;
+    case PROP_TIMEOUT_MS:
+      self->timeout_ms = g_value_get_int (value);
+      break;
     default:
       G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
       break;
@@ -419,6 +473,9 @@ element_get_property (GObject * object, guint prop_id, GValue * value,
     case PROP_PINNED_POOL:
       g_value_set_boolean (value, self->pinned_pool);
       break;
+    case PROP_TIMEOUT_MS:
+      g_value_set_int (value, self->timeout_ms);
+      break;
     default:
       G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
       break;
@@ -438,6 +495,9 @@ element_finalize (GObject * object)
   self->act.devices = NULL;
   g_free (self->failure_note);
   self->failure_note = NULL;
+  g_free (self->error_text);
+  g_free (self->error_debug);
+  self->error_text = self->error_debug = NULL;
   g_mutex_clear (&self->flow_lock);
   G_OBJECT_CLASS (BASE_CLASS (self))->finalize (object);
 }
@@ -579,9 +639,14 @@ element_make_pinned_pool (GstMiBayerElement * self, GstCaps * caps, guint size,
 
   if (mibayer_device_count () <= 0)
     return NULL;
-  /* pinned memory on the NUMA node next to the (first) GPU that will read it */
-  pool = gst_mi_host_pool_new (element_parse_devices (self, &pc)
-      ? pc.devices[0] : self->act.device_id);
+  /* Pinned memory next to the GPU that will read / write it: buffer k of the pool sits on the NUMA node of
+   * devices[k % N], the device frame k of a `devices=` list goes to ("own pinned host
+   * staging" per GPU; on a two-socket node a pool placed next to devices[0] alone puts half of the GPUs behind the
+   * socket link).  Reference pattern: sys/nvcodec/gstcudabasetransform.c:301-329. */
+  if (element_parse_devices (self, &pc))
+    pool = gst_mi_host_pool_new_for_devices (pc.devices, (guint) pc.ndevices);
+  else
+    pool = gst_mi_host_pool_new (self->act.device_id);
   config = gst_buffer_pool_get_config (pool);
   gst_buffer_pool_config_set_params (config, caps, size, min, 0);
   if (!gst_buffer_pool_set_config (pool, config)) {
@@ -612,8 +677,10 @@ element_propose_allocation (GstBaseTransform * base, GstQuery * decide_query,
   gst_query_parse_allocation (query, &caps, &need_pool);
   if (caps == NULL || !element_get_unit_size (base, caps, &size))
     return TRUE;
-  /* every frame in flight keeps its input buffer mapped */
-  min = (guint) (MAX (self->act.inflight, 1) * element_ndevices (self) + 2);
+  /* every frame in flight keeps its input buffer mapped; a whole number of rounds over the devices, so that a
+   * pool that recycles its buffers in order keeps buffer and device aligned */
+  min = (guint) ((MAX (self->act.inflight, 1) + 1) * element_ndevices (self)
+      + (element_ndevices (self) == 1 ? 1 : 0));
   pool = element_make_pinned_pool (self, caps, (guint) size, min);
   if (pool) {
     mibayer_pool_cfg pc;
@@ -623,8 +690,11 @@ element_propose_allocation (GstBaseTransform * base, GstQuery * decide_query,
     gst_query_add_allocation_pool (query, pool, (guint) size, min, 0);
     gst_object_unref (pool);
     /* and the allocator behind it, for an upstream that builds its own pool */
-    allocator = gst_mi_host_allocator_new (element_parse_devices (self, &pc)
-        ? pc.devices[0] : self->act.device_id);
+    if (element_parse_devices (self, &pc))
+      allocator = gst_mi_host_allocator_new_for_devices (pc.devices,
+          (guint) pc.ndevices);
+    else
+      allocator = gst_mi_host_allocator_new (self->act.device_id);
     gst_allocation_params_init (&params);
     gst_query_add_allocation_param (query, allocator, &params);
     gst_object_unref (allocator);
@@ -646,10 +716,12 @@ element_decide_allocation (GstBaseTransform * base, GstQuery * query)
 
     gst_query_parse_allocation (query, &caps, NULL);
     if (caps != NULL && element_get_unit_size (base, caps, &size)) {
+      const guint nd = (guint) element_ndevices (self);
       guint min = (guint) (self->capacity > 0 ? self->capacity + 1 : 2);
-      GstBufferPool *pool =
-          element_make_pinned_pool (self, caps, (guint) size, min);
+      GstBufferPool *pool;
 
+      min = (min + nd - 1) / nd * nd;   /* whole rounds over the devices */
+      pool = element_make_pinned_pool (self, caps, (guint) size, min);
       if (pool) {
         gst_query_add_allocation_pool (query, pool, (guint) size, min, 0);
         gst_object_unref (pool);
@@ -689,10 +761,11 @@ element_submit (GstMiBayerElement * self, GstBuffer * inbuf, GstBuffer * outbuf,
     return GST_FLOW_CUSTOM_ERROR;
   }
   if (p->mosaic.size < (gsize) GST_ROUND_UP_4 (self->width) * self->height) {
-    GST_ELEMENT_ERROR (self, STREAM, FORMAT,
-        ("%s: short %s buffer", LABEL (self), inverse ? "output" : "input"),
-        ("%" G_GSIZE_FORMAT " bytes for %dx%d", p->mosaic.size, self->width,
-            self->height));
+    element_defer_error (self, GST_STREAM_ERROR, GST_STREAM_ERROR_FORMAT,
+        g_strdup_printf ("%s: short %s buffer", LABEL (self),
+            inverse ? "output" : "input"),
+        g_strdup_printf ("%" G_GSIZE_FORMAT " bytes for %dx%d", p->mosaic.size,
+            self->width, self->height));
     goto fail;
   }
   if (!element_ensure_pool (self, GST_VIDEO_FRAME_PLANE_STRIDE (&p->video, 0)))
@@ -918,6 +991,7 @@ element_start (GstBaseTransform * base)
   self->act.inflight = self->inflight;
   self->act.use_hipgraph = self->use_hipgraph;
   self->act.pinned_pool = self->pinned_pool;
+  self->act.timeout_ms = self->timeout_ms;
   GST_OBJECT_UNLOCK (self);
   g_atomic_int_set (&self->flushing, 0);
   self->prerolled = FALSE;
@@ -970,14 +1044,25 @@ gst_mi_bayer_element_class_setup (GstMiBayerElementClass * klass,
           "when the element starts)", 1, 16,
           DEFAULT_INFLIGHT, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_HIPGRAPH,
-      g_param_spec_boolean ("hipgraph", "hipGraph per frame",
-          "Run each frame's upload/kernel/download chain as one instantiated "
-          "hipGraph (bayer2rgb direction)", DEFAULT_HIPGRAPH,
+      g_param_spec_boolean ("hipgraph", "hipGraph-captured launch",
+          "Replay the compute-queue segment of every frame (wait for the upload, "
+          "kernel, signal the download) as a hipGraph captured once per ring "
+          "slot; the pinned H2D / D2H copies stay asynchronous copies on the two "
+          "copy queues (bayer2rgb direction)", DEFAULT_HIPGRAPH,
           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_PINNED_POOL,
       g_param_spec_boolean ("pinned-pool", "Pinned buffer pools",
           "Propose hipHostMalloc-pinned buffer pools upstream and use them "
           "downstream when no other pool is offered", DEFAULT_PINNED_POOL,
+          G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+
+  g_object_class_install_property (object_class, PROP_TIMEOUT_MS,
+      g_param_spec_int ("timeout-ms", "GPU wait deadline",
+          "Milliseconds a GPU may take to hand a frame back before it counts as "
+          "failed: it is dropped from the rotation like a device that reported an "
+          "error and is not waited for again (with one device the stream errors "
+          "out instead of hanging); 0 = wait for ever (latched when the element "
+          "starts)", 0, 3600000, DEFAULT_TIMEOUT_MS,
           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
 
   transform_class->transform_caps = GST_DEBUG_FUNCPTR (element_transform_caps);
@@ -1005,6 +1090,9 @@ gst_mi_bayer_element_instance_setup (GstMiBayerElement * self)
   self->inflight = DEFAULT_INFLIGHT;
   self->use_hipgraph = DEFAULT_HIPGRAPH;
   self->pinned_pool = DEFAULT_PINNED_POOL;
+  self->timeout_ms = DEFAULT_TIMEOUT_MS;
+  self->act.timeout_ms = DEFAULT_TIMEOUT_MS;
+  self->error_text = self->error_debug = NULL;
   self->act.device_id = DEFAULT_DEVICE_ID;
   self->act.devices = NULL;
   self->act.inflight = DEFAULT_INFLIGHT;

@@ -45,6 +45,7 @@ struct _GstMiBayerElement
   gint inflight;                /* frames in flight per device; 1 = synchronous */
   gboolean use_hipgraph;
   gboolean pinned_pool;
+  gint timeout_ms;              /* deadline of every wait for a GPU; 0 = none */
   /* ... and latched into these by start(): the streaming thread only ever reads
    * the latched copies, so a property changed while PLAYING takes effect at the
    * next READY -> PAUSED and never races with the data flow */
@@ -55,6 +56,7 @@ struct _GstMiBayerElement
     gint inflight;
     gboolean use_hipgraph;
     gboolean pinned_pool;
+    gint timeout_ms;
   } act;
 
   /* GPU side: one shard (mibayer_ctx) per device behind a round-robin pool;
@@ -69,6 +71,12 @@ struct _GstMiBayerElement
   volatile gint flushing;       /* between FLUSH_START and FLUSH_STOP: nothing is submitted or pushed */
   gboolean prerolled;           /* a frame has left since start / flush; the first one is never held back */
   gchar *failure_note;          /* a device was dropped: posted as ONE element warning (flow_lock) */
+  /* an error found while flow_lock was held: posted once the lock is released (a bus sync handler runs
+   * application code, which may call back into the element) */
+  GQuark error_domain;
+  gint error_code;
+  gchar *error_text;
+  gchar *error_debug;
 };
 
 struct _GstMiBayerElementClass

@@ -279,6 +279,33 @@ gst_mi_hip_pool_alloc_buffer (GstBufferPool * pool, GstBuffer ** buffer,
   return GST_FLOW_OK;
 }
 
+/* A buffer that comes back to the pool carries a frame nobody will look at again: the next user defines the
+ * contents afresh.  Without this, every WRITE-only CPU map of a recycled buffer first downloaded the stale frame
+ * (a whole frame over PCIe and a host sync) only to have it overwritten.  GPU work still queued on the memory
+ * stays ordered: the "last access" event is not touched. */
+static void
+gst_mi_hip_pool_reset_buffer (GstBufferPool * pool, GstBuffer * buffer)
+{
+  guint i, n = gst_buffer_n_memory (buffer);
+
+  for (i = 0; i < n; i++) {
+    GstMemory *mem = gst_buffer_peek_memory (buffer, i);
+
+    if (gst_is_mi_hip_memory (mem)) {
+      GstMiHipMemory *m = (GstMiHipMemory *) mem;
+
+      g_mutex_lock (&m->lock);
+      if (m->cpu_maps == 0) {
+        m->device_defined = FALSE;
+        m->cpu_dirty = FALSE;
+      }
+      g_mutex_unlock (&m->lock);
+    }
+  }
+  GST_BUFFER_POOL_CLASS (gst_mi_hip_pool_parent_class)->reset_buffer (pool,
+      buffer);
+}
+
 static void
 gst_mi_hip_pool_class_init (GstMiHipPoolClass * klass)
 {
@@ -286,6 +313,7 @@ gst_mi_hip_pool_class_init (GstMiHipPoolClass * klass)
 
   pool_class->set_config = gst_mi_hip_pool_set_config;
   pool_class->alloc_buffer = gst_mi_hip_pool_alloc_buffer;
+  pool_class->reset_buffer = gst_mi_hip_pool_reset_buffer;
 }
 
 static void

@@ -120,7 +120,8 @@ gst_mi_host_pool_alloc_buffer (GstBufferPool * pool, GstBuffer ** buffer,
     (void) gst_buffer_pool_config_get_allocator (config, &ignored, &aparams);
     gst_structure_free (config);
   }
-  mem = pinned_memory_new (self->device, self->size, &aparams);
+  mem = pinned_memory_new (self->ndevices > 0
+      ? self->devices[(guint) g_atomic_int_add (&self->next, 1) % self->ndevices] : -1, self->size, &aparams);
   if (mem == NULL) {
     GST_ERROR_OBJECT (pool, "hipHostMalloc of %u bytes failed: %s",
         self->size, mibayer_last_hip_error ());
@@ -146,17 +147,28 @@ static void
 gst_mi_host_pool_init (GstMiHostPool * self)
 {
   self->size = 0;
-  self->device = -1;
+  self->ndevices = 0;
+  self->next = 0;
+}
+
+GstBufferPool *
+gst_mi_host_pool_new_for_devices (const gint * devices, guint n)
+{
+  GstBufferPool *pool = g_object_new (GST_TYPE_MI_HOST_POOL, NULL);
+  GstMiHostPool *self = GST_MI_HOST_POOL (pool);
+  guint i;
+
+  for (i = 0; i < n && i < GST_MI_HOST_POOL_MAX_DEVICES; i++)
+    if (devices[i] >= 0)
+      self->devices[self->ndevices++] = devices[i];
+  gst_object_ref_sink (pool);
+  return pool;
 }
 
 GstBufferPool *
 gst_mi_host_pool_new (gint device)
 {
-  GstBufferPool *pool = g_object_new (GST_TYPE_MI_HOST_POOL, NULL);
-
-  GST_MI_HOST_POOL (pool)->device = device;
-  gst_object_ref_sink (pool);
-  return pool;
+  return gst_mi_host_pool_new_for_devices (&device, 1);
 }
 
 /* ---- the same memory as a GstAllocator ---------------------------------------------- */
@@ -164,7 +176,9 @@ gst_mi_host_pool_new (gint device)
 typedef struct
 {
   GstAllocator parent;
-  gint device;
+  gint devices[GST_MI_HOST_POOL_MAX_DEVICES];
+  guint ndevices;
+  volatile gint next;
 } GstMiHostAllocator;
 
 typedef struct
@@ -176,9 +190,9 @@ static GstMemory *
 gst_mi_host_allocator_alloc (GstAllocator * allocator, gsize size,
     GstAllocationParams * params)
 {
-  GstMemory *mem =
-      pinned_memory_new (((GstMiHostAllocator *) allocator)->device, size,
-      params);
+  GstMiHostAllocator *self = (GstMiHostAllocator *) allocator;
+  GstMemory *mem = pinned_memory_new (self->ndevices > 0
+      ? self->devices[(guint) g_atomic_int_add (&self->next, 1) % self->ndevices] : -1, size, params);
 
   if (mem == NULL)
     GST_ERROR_OBJECT (allocator, "hipHostMalloc of %" G_GSIZE_FORMAT
@@ -206,7 +220,8 @@ gst_mi_host_allocator_class_init (gpointer klass, gpointer data)
 static void
 gst_mi_host_allocator_init (GTypeInstance * instance, gpointer klass)
 {
-  ((GstMiHostAllocator *) instance)->device = -1;
+  ((GstMiHostAllocator *) instance)->ndevices = 0;
+  ((GstMiHostAllocator *) instance)->next = 0;
 }
 
 /* per-plugin type name, like the pool's */
@@ -235,12 +250,21 @@ gst_mi_host_allocator_get_type (void)
 }
 
 GstAllocator *
-gst_mi_host_allocator_new (gint device)
+gst_mi_host_allocator_new_for_devices (const gint * devices, guint n)
 {
   GstMiHostAllocator *self =
       g_object_new (gst_mi_host_allocator_get_type (), NULL);
+  guint i;
 
-  self->device = device;
+  for (i = 0; i < n && i < GST_MI_HOST_POOL_MAX_DEVICES; i++)
+    if (devices[i] >= 0)
+      self->devices[self->ndevices++] = devices[i];
   gst_object_ref_sink (self);
   return GST_ALLOCATOR_CAST (self);
+}
+
+GstAllocator *
+gst_mi_host_allocator_new (gint device)
+{
+  return gst_mi_host_allocator_new_for_devices (&device, 1);
 }

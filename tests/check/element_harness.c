@@ -24,9 +24,13 @@
  * released_at_flush_start=0|1: whether every input buffer pushed before the flush had been let go of by the element
  * when FLUSH_START returned (i.e. before FLUSH_STOP).  HARNESS_SET_MIDSTREAM="prop=value[,prop=value]" sets
  * properties on the element after the first buffer (they must not disturb the running stream: latched at start).
+ * HARNESS_RESTRIDE="nbefore:width:height:stride" (4-byte-per-pixel input, i.e. rgb2bayer): from frame <nbefore> on
+ * the input rows are <stride> bytes apart and the buffer says so in a GstVideoMeta -- a stride that changes
+ * mid-stream WITHOUT a caps event, as after a RECONFIGURE.
  */
 #include <gst/gst.h>
 #include <gst/check/gstharness.h>
+#include <gst/video/video.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -149,12 +153,30 @@ run_harness (int argc, char **argv, int flush_after)
     fprintf (stderr, "setup failed\n");
     return 2;
   }
+  int rs_before = -1, rs_w = 0, rs_h = 0, rs_stride = 0;
+
+  if (g_getenv ("HARNESS_RESTRIDE"))
+    sscanf (g_getenv ("HARNESS_RESTRIDE"), "%d:%d:%d:%d", &rs_before, &rs_w, &rs_h, &rs_stride);
   bus = attach_bus (h);
   gst_harness_set_src_caps_str (h, caps);
   while (fread (frame, 1, frame_bytes, in) == frame_bytes) {
-    GstBuffer *buf = gst_buffer_new_allocate (NULL, frame_bytes, NULL);
+    GstBuffer *buf;
 
-    gst_buffer_fill (buf, 0, frame, frame_bytes);
+    if (rs_before >= 0 && pushed >= rs_before) {
+      gsize offset[GST_VIDEO_MAX_PLANES] = { 0, };
+      gint stride[GST_VIDEO_MAX_PLANES] = { rs_stride, };
+      int y;
+
+      buf = gst_buffer_new_allocate (NULL, (gsize) rs_stride * rs_h, NULL);
+      gst_buffer_memset (buf, 0, 0xEE, (gsize) rs_stride * rs_h);
+      for (y = 0; y < rs_h; y++)
+        gst_buffer_fill (buf, (gsize) y * rs_stride, frame + (size_t) y * 4 * rs_w, (gsize) 4 * rs_w);
+      gst_buffer_add_video_meta_full (buf, GST_VIDEO_FRAME_FLAG_NONE, GST_VIDEO_FORMAT_ARGB, rs_w, rs_h, 1,
+          offset, stride);
+    } else {
+      buf = gst_buffer_new_allocate (NULL, frame_bytes, NULL);
+      gst_buffer_fill (buf, 0, frame, frame_bytes);
+    }
     GST_BUFFER_PTS (buf) = (GstClockTime) pushed * GST_SECOND / 30;
     if (flush_after > 0 && pushed < flush_after && pushed < 64)
       held[pushed] = gst_buffer_ref (buf);      /* to see when the element lets go of it */

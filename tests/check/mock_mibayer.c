@@ -110,6 +110,14 @@ mibayer_host_numa_node (const void *p)
   return node;
 }
 
+/* element-level tests read the placement counters from the process' last words */
+static void __attribute__ ((destructor))
+mock_numa_report (void)
+{
+  if (getenv ("MOCK_MIBAYER_NUMA_REPORT"))
+    fprintf (stdout, "numa_local=%d numa_remote=%d\n", g_numa_local, g_numa_remote);
+}
+
 /* frames converted on the node of their destination buffer / on another one (the driver prints both) */
 void
 mock_numa_counts (int *local, int *remote)

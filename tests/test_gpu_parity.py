@@ -6,6 +6,8 @@ variant."""
 import hashlib
 import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -926,3 +928,127 @@ def test_contexts_on_several_threads_share_the_device_queues(gpu_pkg, oracle, fl
     extra.join(60)
     assert not errors, errors
     assert not any(t.is_alive() for t in threads) and not extra.is_alive()
+
+
+def test_wait_deadline_on_a_stalled_device(gpu_pkg, oracle):
+    """A device that does not hand a frame back within the deadline: mibayer_wait returns MIBAYER_ERR_TIMEOUT (it
+    does not hang), the context is wedged from then on -- every later call returns at once -- and destroying it
+    does not block either.  The stall drill (csrc/mibayer_hooks.h) ends by itself; afterwards the device converts
+    bit-exactly again."""
+    import time
+    w, h = 640, 480
+    src = oracle.fill_synthetic(w, h, 1, seed=91)[0]
+    want = oracle.bayer2rgb(src, w, "rggb", 2, 1, 0)
+    L = gpu_pkg.lib()
+    ctx = gpu_pkg.Context(w, h, "rggb", "BGRx", inflight=2)
+    assert np.array_equal(ctx.process_host(src), want)         # ring allocated, device warm
+    ctx.set_wait_timeout(120)
+    ctx.stall(1500)
+    p_src, host_src = _pinned(L, src.size, src.shape)
+    host_src[...] = src
+    p_dst, host_dst = _pinned(L, want.size, want.shape)
+    t0 = time.monotonic()
+    ctx.submit(host_src, host_dst, 1)
+    with pytest.raises(gpu_pkg.MibayerError) as e:
+        ctx.wait()
+    dt = time.monotonic() - t0
+    assert e.value.status == gpu_pkg.ERR_TIMEOUT and 0.1 <= dt < 0.8, (e.value.status, dt)
+    t0 = time.monotonic()
+    with pytest.raises(gpu_pkg.MibayerError) as e:
+        ctx.wait()
+    assert e.value.status == gpu_pkg.ERR_TIMEOUT
+    with pytest.raises(gpu_pkg.MibayerError) as e:
+        ctx.submit(host_src, host_dst, 2)
+    assert e.value.status == gpu_pkg.ERR_TIMEOUT
+    ctx.close()
+    assert time.monotonic() - t0 < 0.3                          # nothing waited for the stalled device
+    time.sleep(1.6)                                             # the drill ends; the late DMA lands in host_dst
+    with gpu_pkg.Context(w, h, "rggb", "BGRx") as ctx2:
+        assert np.array_equal(ctx2.process_host(src), want)
+    L.mibayer_host_free(p_src)
+    L.mibayer_host_free(p_dst)
+
+
+POOL_STALL_SCRIPT = r"""
+import sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as entry
+pkg, oracle = entry.load_package(), entry.load_oracle()
+L = pkg.lib()
+w, h, n = 1280, 720, 24
+src = oracle.fill_synthetic(w, h, n, seed=92)
+want = oracle.bayer2rgb_batch(src, w, "grbg", 0, 1, 2, nthreads=2)
+def pinned(nbytes, shape):
+    import ctypes
+    p = L.mibayer_host_alloc(nbytes)
+    return np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(p)).reshape(shape)
+hs = pinned(src.size, src.shape); hs[...] = src
+hd = pinned(want.size, want.shape); hd[...] = 0
+with pkg.Pool([0, 0], w, h, "grbg", "RGBx", inflight=2) as pool:
+    pool.set_wait_timeout(150)
+    t0 = time.monotonic()
+    sub = got = 0
+    while got < n:
+        if sub == 6:
+            pool.inject_stall(0, 2500)
+        if sub < n:
+            try:
+                pool.submit(hs[sub], hd[sub], sub + 1)
+                sub += 1
+                continue
+            except pkg.MibayerError as e:
+                assert e.status == pkg.ERR_BUSY, e
+        tag = pool.wait()
+        assert tag == got + 1, (tag, got)
+        got += 1
+    dt = time.monotonic() - t0
+    nf, dev, alive, msg = pool.take_failure()
+    assert nf == 1 and alive == 1 and pool.alive() == 1, (nf, alive, msg)
+    assert "deadline" in msg or "did not" in msg, msg
+    assert dt < 1.5, dt          # the stream did not wait for the stalled shard (2.5 s)
+    t1 = time.monotonic()
+assert time.monotonic() - t1 < 0.5                            # nor did destroying the pool
+assert np.array_equal(hd, want)
+print("pool stall drill ok %.3f s: %s" % (dt, msg))
+"""
+
+
+def test_pool_drops_a_shard_that_stops_answering(gpu_pkg):
+    """devices=0,0 with private queues per context (MIBAYER_SHARED_QUEUES=0 -- on shared queues a stall of one
+    context IS a stall of its neighbours, as on a really wedged GPU): shard 0's compute queue is occupied for 2.5 s,
+    the pool's deadline is 150 ms.  Every frame still comes out once, in order, bit-exact; one failure is reported;
+    neither the stream nor mibayer_pool_destroy waits for the stalled shard."""
+    res = subprocess.run([sys.executable, "-c", POOL_STALL_SCRIPT, ROOT], capture_output=True, text=True,
+                         timeout=120, env=dict(os.environ, MIBAYER_SHARED_QUEUES="0"))
+    assert res.returncode == 0 and "pool stall drill ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+
+
+def test_destroying_a_context_does_not_wait_for_its_neighbours_on_the_shared_queues(gpu_pkg, oracle):
+    """Two contexts on one device share its three queues.  While one of them has a long batch (here: a 400 ms
+    stall + a 64-frame batch) on the compute queue, destroying -- or syncing -- the other returns at once: it waits
+    for its own frames' events only and hands its device frames to the per-device cache instead of hipFree (which
+    drains the device).  The batch still comes out bit-exact."""
+    import time
+    w, h, n = 1920, 1080, 64
+    a = gpu_pkg.Context(w, h, "rggb", "BGRx")
+    b = gpu_pkg.Context(w, h, "bggr", "RGBx")
+    one = oracle.fill_synthetic(w, h, 1, seed=93)[0]
+    assert np.array_equal(b.process_host(one), oracle.bayer2rgb(one, w, "bggr", 0, 1, 2))     # b owns a ring now
+    d_src = a.device_alloc(n * a.src_bytes)
+    d_dst = a.device_alloc(n * a.dst_bytes)
+    a.fill_synthetic(d_src, n, 5)
+    a.sync()
+    a.stall(400)
+    a.process_device(d_src, d_dst, n)
+    t0 = time.monotonic()
+    b.sync()
+    b.close()
+    dt = time.monotonic() - t0
+    a.sync()
+    total = time.monotonic() - t0
+    assert dt < 0.1 and total > 0.3, (dt, total)
+    _frames_equal_oracle(a, oracle, d_dst, [0, 31, 63], w, h, "rggb", "BGRx", 5)
+    a.device_free(d_src)
+    a.device_free(d_dst)
+    a.close()

@@ -160,6 +160,62 @@ def test_rgb2bayer_shares_the_same_logic(rig, tmp_path, launch):
     assert seq == list(range(n)) and fill == list(range(50, 50 + n))
 
 
+def test_stride_change_without_caps_event_finishes_the_frames_in_flight_first(rig, tmp_path):
+    """the mapped stride comes per buffer (GstVideoMeta) and can change with no CAPS event while
+    queued-mode frames are still in flight.  The element finishes those on the old pool, in order, before it
+    replaces it: every frame out once, in order, no error, no sanitizer report (the pending queue used to desync
+    from the new pool's fifo)."""
+    w, h, n, nb = 130, 21, 11, 5
+    inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
+    frames(n, 4 * w * h, first=60).tofile(inp)
+    for launch in ("rgb2bayer inflight=3", "rgb2bayer inflight=2 devices=0,0", "rgb2bayer"):
+        kv = run(rig, "convert", launch, R2B % (w, h), inp, 4 * w * h, outp,
+                 extra_env={"HARNESS_RESTRIDE": "%d:%d:%d:%d" % (nb, w, h, 4 * w + 48)})
+        assert kv["pushed"] == str(n) and kv["pulled"] == str(n) and kv["errors"] == "0", (launch, kv)
+        seq, fill = stamps(outp, n, 132 * h)
+        assert fill == list(range(60, 60 + n)), launch
+        assert seq == list(range(nb)) + list(range(n - nb)), launch      # a new pool from frame nb on
+
+
+def test_a_gpu_that_stops_answering_is_dropped_after_timeout_ms(rig, tmp_path):
+    """timeout-ms: with two shards the one that stops answering (MOCK_MIBAYER_HANG) leaves the rotation after the
+    deadline -- ONE warning, every frame out in order, EOS drains, nothing hangs; with a single device the stream
+    errors out instead of hanging.  The double aborts on any wait without a deadline on the hung context."""
+    w, h, n = 64, 48, 14
+    inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
+    frames(n, w * h, first=5).tofile(inp)
+    kv = run(rig, "convert", "bayer2rgb inflight=2 devices=0,0 timeout-ms=30", B2R % ("bggr", w, h), inp, w * h, outp,
+             extra_env={"MOCK_MIBAYER_HANG": "0:3"})
+    assert kv["pushed"] == str(n) and kv["pulled"] == str(n) and kv["warnings"] == "1" and kv["errors"] == "0"
+    _, fill = stamps(outp, n, 4 * w * h)
+    assert fill == list(range(5, 5 + n))
+    # flush while the hung device still holds frames: dropped, no hang
+    kv = run(rig, "flush", "bayer2rgb inflight=3 devices=0,0 timeout-ms=30", B2R % ("bggr", w, h), inp, w * h, outp, 6,
+             extra_env={"MOCK_MIBAYER_HANG": "1:2"})
+    assert kv["pushed"] == str(n) and kv["errors"] == "0"
+    exe, env, _ = rig
+    res = subprocess.run([exe, "convert", "bayer2rgb timeout-ms=30", B2R % ("bggr", w, h), str(inp), str(w * h),
+                          str(outp)], capture_output=True, text=True, env=dict(env, MOCK_MIBAYER_HANG="0:4"),
+                         timeout=60)
+    assert "AddressSanitizer" not in res.stdout + res.stderr and "errors=1" in res.stdout, res.stdout + res.stderr
+
+
+def test_pinned_pool_buffers_sit_next_to_the_gpu_that_converts_them(rig, tmp_path):
+    """devices=0,1,2,3 over two fake NUMA nodes: the element's pinned output pool places buffer k next to
+    devices[k % N], and the pool routes by the buffer's node, so (nearly) every frame is converted on the node
+    that holds its buffer; results in order."""
+    w, h, n = 64, 48, 40
+    inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
+    frames(n, w * h, first=1).tofile(inp)
+    env = {"MOCK_MIBAYER_DEVICES": "4", "MOCK_MIBAYER_NUMA_NODES": "2", "MOCK_MIBAYER_NUMA_REPORT": "1"}
+    kv = run(rig, "convert", "bayer2rgb inflight=2 devices=0,1,2,3", B2R % ("bggr", w, h), inp, w * h, outp,
+             extra_env=env)
+    assert kv["pushed"] == str(n) and kv["pulled"] == str(n)
+    _, fill = stamps(outp, n, 4 * w * h)
+    assert fill == list(range(1, 1 + n))
+    assert int(kv["numa_local"]) >= 0.9 * n, kv
+
+
 def test_out_of_domain_geometry_and_missing_device_are_errors(rig, tmp_path):
     exe, env, _ = rig
     inp = tmp_path / "in.raw"
