@@ -83,17 +83,87 @@ def aggregate_mpix_per_s(pixels_per_step_per_rank, world_size, steps, elapsed_s)
 # CPU baseline (oracle) -- reported beside the GPU number, never the thing optimised
 # ----------------------------------------------------------------------------------------------
 
-def stock_element_note():
-    """BASELINE.md section 4 "optional": where a stock gst-plugins-bad `bayer2rgb` (the literal ORC element) is installed on
-    the box it would be timed through `filesrc ! bayer2rgb ! fakesink`; this image ships GStreamer 1.14 without
-    gst-plugins-bad and without liborc, so the line only says so (the reference cannot travel to the GPU box)."""
+def _gst_tools():
+    """(gst-launch-1.0, gst-inspect-1.0, env) of the GStreamer this box has, or None."""
+    import shutil
     prefix = os.environ.get("GST_PREFIX", "/opt/conda")
-    for d in (os.path.join(prefix, "lib", "gstreamer-1.0"), "/usr/lib/x86_64-linux-gnu/gstreamer-1.0",
-              "/usr/lib64/gstreamer-1.0"):
-        if os.path.exists(os.path.join(d, "libgstbayer.so")):
-            return {"installed": True, "path": os.path.join(d, "libgstbayer.so"),
-                    "note": "present but not timed: no pipeline leg for it in this harness yet"}
-    return {"installed": False, "note": "no stock gst-plugins-bad bayer plugin (nor liborc) on this box"}
+    for bindir in (os.path.join(prefix, "bin"), "/usr/bin", "/usr/local/bin"):
+        launch, inspect = os.path.join(bindir, "gst-launch-1.0"), os.path.join(bindir, "gst-inspect-1.0")
+        if os.path.exists(launch) and os.path.exists(inspect):
+            env = dict(os.environ)
+            if bindir.startswith(prefix):       # a conda GStreamer does not find its own plugins by default
+                env.setdefault("GST_PLUGIN_SYSTEM_PATH_1_0", os.path.join(prefix, "lib", "gstreamer-1.0"))
+                env.setdefault("GST_PLUGIN_SCANNER", os.path.join(prefix, "libexec", "gstreamer-1.0",
+                                                                   "gst-plugin-scanner"))
+            env["GST_REGISTRY"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mibayer_bench_gst_registry.bin")
+            env.pop("GST_PLUGIN_PATH_1_0", None)    # never this repository's own plugin
+            env.pop("GST_PLUGIN_PATH", None)
+            return launch, inspect, env
+    if shutil.which("gst-launch-1.0") and shutil.which("gst-inspect-1.0"):
+        return shutil.which("gst-launch-1.0"), shutil.which("gst-inspect-1.0"), dict(os.environ)
+    return None
+
+
+def time_pipeline(launch, env, element, width, height, frames, path, repeats=2, timeout=120):
+    """Wall seconds of `filesrc ! video/x-bayer ! <element> ! fakesink` over `frames` frames of `path`, best of
+    `repeats` (the file stays in the page cache); None if the pipeline fails."""
+    caps = "video/x-bayer,format=rggb,width=%d,height=%d,framerate=30/1" % (width, height)
+    cmd = [launch, "-q", "filesrc", "location=" + path, "blocksize=%d" % (((width + 3) & ~3) * height), "!",
+           caps, "!"] + element.split() + ["!", "fakesink", "sync=false"]
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        el = time.perf_counter() - t0
+        if res.returncode != 0:
+            return None
+        best = el if best is None else min(best, el)
+    return best
+
+
+def stock_element_leg(sample_frames=24, budget_s=20.0):
+    """SURVEY.md section 8(d) / BASELINE.md section 4: where a STOCK gst-plugins-bad `bayer2rgb` -- the literal ORC
+    element, not this repository's -- is installed on the box, it is timed through
+    `filesrc ! video/x-bayer ! bayer2rgb ! fakesink` (call site gstbayer2rgb.c:456-487) on the same synthetic 4K
+    frames, with the same pipeline around `identity` subtracted (file read, caps, buffer hand-over), as in SURVEY.md
+    section 6.  This image ships GStreamer 1.14 without gst-plugins-bad and without liborc, and the reference cannot
+    travel to the GPU box, so there the leg reports that nothing is installed."""
+    tools = _gst_tools()
+    if tools is None:
+        return {"installed": False, "note": "no GStreamer tools on this box"}
+    launch, inspect, env = tools
+    try:
+        res = subprocess.run([inspect, "bayer2rgb"], env=env, capture_output=True, text=True, timeout=60)
+    except Exception as exc:       # noqa: BLE001
+        return {"installed": False, "note": "gst-inspect-1.0 failed: %s" % str(exc)[:100]}
+    if res.returncode != 0:
+        return {"installed": False, "note": "no stock gst-plugins-bad bayer plugin (nor liborc) on this box "
+                                            "(gst-inspect-1.0 bayer2rgb finds nothing outside this repository)"}
+    where = [ln.split()[-1] for ln in res.stdout.splitlines() if ln.strip().startswith("Filename")]
+    if where and os.path.abspath(where[0]).startswith(ROOT):
+        return {"installed": False, "note": "the only bayer2rgb in the registry is this repository's own"}
+    import numpy as np
+    import __graft_entry__ as entry
+    oracle = entry.load_oracle()
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "mibayer_bench_stock_%d.raw" % os.getpid())
+    try:
+        oracle.fill_synthetic(WIDTH, HEIGHT, sample_frames, SEED).tofile(path)
+        base = time_pipeline(launch, env, "identity", WIDTH, HEIGHT, sample_frames, path)
+        conv = time_pipeline(launch, env, "bayer2rgb ! video/x-raw,format=%s" % FORMAT, WIDTH, HEIGHT, sample_frames,
+                             path, timeout=max(60, int(budget_s * 6)))
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    if base is None or conv is None or conv <= base:
+        return {"installed": True, "path": where[0] if where else None,
+                "note": "present, but the timing pipeline did not run (identity %r s, bayer2rgb %r s)" % (base, conv)}
+    return {"installed": True, "path": where[0] if where else None, "cores": 1, "kind": "reference",
+            "value": round(WIDTH * HEIGHT * sample_frames / (conv - base) / 1e6, 1), "unit": "Mpix/s",
+            "pipeline_seconds": round(conv, 3), "identity_pipeline_seconds": round(base, 3),
+            "note": "stock ORC element through filesrc ! bayer2rgb ! fakesink, %d 4K frames (seed %d), identity "
+                    "pipeline subtracted, best of 2; single-threaded per stream" % (sample_frames, SEED)}
 
 
 def cpu_baseline(budget_s=12.0, sample_frames=32):
@@ -173,7 +243,7 @@ def cpu_baseline(budget_s=12.0, sample_frames=32):
                               "host core), several passes per thread creation, output pages first touched by the "
                               "thread that writes them" % (sample_frames, nbands, sample_frames * nbands, ncores)},
         "reference_c_path": ref,
-        "stock_orc_element": stock_element_note(),
+        "stock_orc_element": stock_element_leg(),
     }
 
 
@@ -262,14 +332,23 @@ def build_hash():
     return h.hexdigest()[:12]
 
 
-def profiled_traffic(band):
-    """The PMC-measured HBM bytes per launch of the block order this run used, from the last profiled pass
-    (profiles/traffic_latest.json): NOT a measurement of this run, hence not `traffic`."""
+def profiled_traffic(band, variant_name=None):
+    """The PMC-measured HBM bytes per launch of the geometry and block order this run used, from the last profiled
+    pass (profiles/traffic_latest.json, keyed "<W>x<H>x<N>/<plan>"; tools/summarize_geometry_counters.py): NOT a
+    measurement of this run, hence not `traffic`."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
             t = json.load(f)
         plan = "band1" if band == 1 else ("chunk" if band > 1 else "identity")
+        key = "%dx%dx%d/%s" % (WIDTH, HEIGHT, BATCH, plan)
+        entry = (t.get("by_geometry_and_plan") or {}).get(key)
+        if entry is not None:
+            return {"bytes": entry["hbm_bytes_per_launch"], "read_bytes": entry.get("read_bytes"),
+                    "write_bytes": entry.get("write_bytes"), "key": key, "kernel": entry.get("kernel"),
+                    "box_serial": t.get("by_geometry_box_serial"), "build": t.get("by_geometry_build"),
+                    "build_matches_this_run": t.get("by_geometry_build") == build_hash(),
+                    "file": "profiles/traffic_latest.json", "source": t.get("by_geometry_source")}
         entry = t["plans"][plan]
         return {"bytes": entry["hbm_bytes_per_launch"], "read_bytes": entry.get("read_bytes"),
                 "write_bytes": entry.get("write_bytes"), "plan": plan, "box_serial": t.get("box_serial"),
@@ -371,7 +450,20 @@ def run_stream(args):
     el_chain = timed(pkg.FLAG_HIPGRAPH, "chain")
     el_graph = timed(pkg.FLAG_HIPGRAPH)
     el = el_streams if args.no_graph else el_graph
+    # parity after the timed loops: one synthetic frame of this rank's share through the same host path
+    oracle = entry.load_oracle()
+    gframe = rank
+    one = oracle.fill_synthetic(WIDTH, HEIGHT, 1, SEED, first_frame=gframe)[0]
+    r, g, b = oracle.LAYOUTS[FORMAT]
+    with pkg.Context(WIDTH, HEIGHT, "rggb", FORMAT, device=local_rank, inflight=2,
+                     flags=0 if args.no_graph else pkg.FLAG_HIPGRAPH) as pctx:
+        got = pctx.process_host(one)
+    if not (got == oracle.bayer2rgb(one, WIDTH, "rggb", r, g, b)).all():
+        raise AssertionError("bench stream parity check failed on rank %d" % rank)
+    parity = "bit-exact vs oracle on global frame %d (rggb->%s, host path)" % (gframe, FORMAT)
+    per_gpu = None
     if dist is not None:
+        per_gpu = dist.gather_objects({"rank": rank, "device": local_rank, "frames": mine, "parity": parity})
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -387,6 +479,7 @@ def run_stream(args):
                                       "hipGraph-captured launch: one hipGraphLaunch per frame replays the slot's "
                                       "compute-queue segment (wait for the upload, kernel, signal the download), "
                                       "the copies stay on the copy queues")},
+            "per_gpu": per_gpu, "parity": parity,
             "mechanisms": {"streams_and_events_3_queues": round(px / el_streams / 1e6, 1),
                            "hipgraph_captured_launch": round(px / el_graph / 1e6, 1),
                            "hipgraph_whole_chain_per_slot": round(px / el_chain / 1e6, 1)},
@@ -505,7 +598,7 @@ def run(args):
     # `traffic` is a measurement of THIS run or null: PMC counters need a rocprofv3 wrapper around the process, so
     # the unwrapped bench line says null and carries the last profiled figure under its own name, with the
     # plan, the box and the build it was taken on (tools/summarize_profiles.py writes the file)
-    result["roofline"]["traffic_profiled"] = profiled_traffic(ctx0.launch_geometry(BATCH)["band"])
+    result["roofline"]["traffic_profiled"] = profiled_traffic(ctx0.launch_geometry(BATCH)["band"], ctx0.variant_name)
     if dist is not None:
         # per-GPU breakdown (SURVEY.md section 5 "metrics"): `roofline` above is rank 0's kernel, this is every rank's
         mine = {"rank": rank, "device": local_rank, "kernel_ms": round(kernel_ms, 4),

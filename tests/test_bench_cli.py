@@ -38,12 +38,40 @@ def test_profiled_traffic_is_labelled_with_its_box_and_build():
     with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
         t = json.load(f)
     assert {"plans", "box_serial", "build", "algorithmic_bytes_per_launch"} <= set(t)
+    geo = t.get("by_geometry_and_plan", {})
     for band, plan in ((1, "band1"), (544, "chunk"), (0, "identity")):
         tp = bench.profiled_traffic(band)
-        assert tp["plan"] == plan and tp["bytes"] == t["plans"][plan]["hbm_bytes_per_launch"]
-        assert tp["box_serial"] == t["box_serial"] and tp["build"] == t["build"]
-        assert tp["build_matches_this_run"] == (t["build"] == h)
-        assert 1.0 <= tp["bytes"] / t["algorithmic_bytes_per_launch"] < 1.2
+        key = "3840x2160x64/%s" % plan
+        if key in geo:                   # keyed by geometry AND plan (VERDICT r02 #6b)
+            assert tp["key"] == key and tp["bytes"] == geo[key]["hbm_bytes_per_launch"]
+            assert tp["box_serial"] == t.get("by_geometry_box_serial") and tp["build"] == t.get("by_geometry_build")
+            assert tp["build_matches_this_run"] == (t.get("by_geometry_build") == h)
+            assert 1.0 <= tp["bytes"] / geo[key]["algorithmic_bytes_per_launch"] < 1.2
+        else:
+            assert tp["plan"] == plan and tp["bytes"] == t["plans"][plan]["hbm_bytes_per_launch"]
+            assert 1.0 <= tp["bytes"] / t["algorithmic_bytes_per_launch"] < 1.2
+    # other geometries carry their own entries: generic sensor geometries, 8K, 1080p
+    assert any(k.startswith("4056x3040x32/") for k in geo) and any(k.startswith("7680x4320x64/") for k in geo)
+
+
+def test_stock_element_leg_times_a_pipeline_or_says_why_not(tmp_path, monkeypatch):
+    """SURVEY 8(d) / VERDICT r02 #6a: the literal ORC element is timed through filesrc ! bayer2rgb ! fakesink when a
+    stock plugin is installed; in this image none is, so the leg says so -- and the pipeline timer itself is
+    exercised on `identity`, the element it subtracts."""
+    import numpy as np
+    leg = bench.stock_element_leg(sample_frames=2)
+    assert leg["installed"] is False and "note" in leg          # no gst-plugins-bad (nor liborc) in this image
+    tools = bench._gst_tools()
+    if tools is None:
+        import pytest
+        pytest.skip("no GStreamer tools")
+    launch, inspect, env = tools
+    w, h, n = 640, 480, 6
+    path = str(tmp_path / "frames.raw")
+    np.zeros((n, h, w), np.uint8).tofile(path)
+    el = bench.time_pipeline(launch, env, "identity", w, h, n, path, repeats=1)
+    assert el is not None and 0 < el < 60
+    assert bench.time_pipeline(launch, env, "no_such_element_xyz", w, h, n, path, repeats=1) is None
 
 
 def test_cpu_baseline_has_the_simd_leg_and_uses_every_core(monkeypatch):

@@ -1070,3 +1070,43 @@ def test_destroying_a_context_does_not_wait_for_its_neighbours_on_the_shared_que
     a.device_free(d_src)
     a.device_free(d_dst)
     a.close()
+
+
+def _bench_two_ranks(extra, port):
+    """`bench.py --gpus 2` the way the driver launches it for a SCALE run (torch.distributed.run, one rank per GPU),
+    except that both ranks share the one GPU of this box and the control plane is gloo."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--share-gpu", "--backend", "gloo"] + extra
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-1500:] + res.stderr[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_batch_mode():
+    """the N > 1 flow of bench.py -- process-group set-up, frame sharding g -> rank g % N, barriers,
+    max-over-ranks, the per-GPU gather -- runs every round, not for the first time in a SCALE run."""
+    j = _bench_two_ranks(["--steps", "5", "--warmup", "2", "--no-cpu", "--no-host-path"], 29611)
+    assert j["n_gpus"] == 2 and j["steps"] == 5 and j["warmup"] == 2 and j["scaling"] == "weak"
+    assert j["unit"] == "Mpix/s" and j["dtype"] == "u8" and j["higher_is_better"] is True
+    assert len(j["per_gpu"]) == 2 and sorted(p["rank"] for p in j["per_gpu"]) == [0, 1]
+    assert all("bit-exact" in p["parity"] for p in j["per_gpu"])
+    # value = the pixels ALL ranks converted / the max-over-ranks time
+    want = 3840 * 2160 * 64 * 2 * 5 / (j["ms_per_step"] * 5 * 1e-3) / 1e6
+    assert abs(j["value"] - want) / want < 0.01, (j["value"], want)
+    assert j["config"]["control_plane"] == "gloo" and j["roofline"]["bound"] == "hbm"
+    assert 0.2 < j["roofline"]["frac"] < 1.0                    # two ranks share one GPU: about half each
+
+
+def test_bench_two_ranks_stream_mode():
+    """BASELINE.json configs[4] through two ranks: 1000 frames round-robin, per-rank breakdown and parity."""
+    j = _bench_two_ranks(["--mode", "stream"], 29612)
+    assert j["n_gpus"] == 2 and j["steps"] == 1000 and j["scaling"] == "strong"
+    assert len(j["per_gpu"]) == 2 and sorted(p["frames"] for p in j["per_gpu"]) == [500, 500]
+    assert all("bit-exact" in p["parity"] for p in j["per_gpu"])
+    want = 3840 * 2160 * 1000 / (j["ms_per_step"] * 1000 * 1e-3) / 1e6
+    assert abs(j["value"] - want) / want < 0.01
+    assert j["roofline"]["bound"] == "pcie" and 0 < j["roofline"]["frac"] < 1.2

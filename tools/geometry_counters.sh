@@ -8,6 +8,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${TAG}_geom
 mkdir -p $O
 export TMPDIR=/tmp
+(rocm-smi --showserial 2>&1 | grep "Serial Number:" | head -1) > $O/box.txt
+python -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.build_hash())" > $O/build_hash.txt
 cd /tmp
 run() {   # name W H N env...
   name=$1; W=$2; H=$3; N=$4; shift 4
@@ -32,4 +34,5 @@ run g7680x4320x64_band1 7680 4320 64 MIBAYER_XCD_BAND=1
 run g1920x1080x256_band1 1920 1080 256 MIBAYER_XCD_BAND=1
 run g3840x2160x64_band1 3840 2160 64 MIBAYER_XCD_BAND=1
 run g3840x2160x64_chunk 3840 2160 64 MIBAYER_XCD_BAND=-1
+run g3840x2160x64_identity 3840 2160 64 MIBAYER_XCD_BAND=0
 cd $R; find $O -name "*counter_collection.csv" | wc -l

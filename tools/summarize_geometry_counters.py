@@ -67,5 +67,10 @@ tl = os.path.join(ROOT, "profiles", "traffic_latest.json")
 cur = json.load(open(tl)) if os.path.exists(tl) else {}
 cur["by_geometry_and_plan"] = out
 cur["by_geometry_source"] = "profiles/%s_geometry_counters.md" % tag
+for key, name in (("by_geometry_box_serial", "box.txt"), ("by_geometry_build", "build_hash.txt")):
+    try:
+        cur[key] = open(os.path.join(src, name)).read().split()[-1]
+    except (OSError, IndexError):
+        cur[key] = None
 json.dump(cur, open(tl, "w"), indent=1)
 print("\n".join(lines))
