@@ -598,6 +598,7 @@ static int launch (const mibayer_ctx *c, const void *d_src,
     q.flat_px = c->r2b_flat_px;
     q.flat_ld = c->r2b_flat_ld;
     q.rows = c->r2b_rows;
+    q.nlist = 0;
     for (int k = 0; k < 2; k++) {
       q.sel_lo[k] = c->r2b_lo[k];
       q.sel_hi[k] = c->r2b_hi[k];
@@ -1638,12 +1639,53 @@ extern "C" int mibayer_process_device_list (mibayer_ctx *c,
   Range r ("mibayer:process_device_list");
   if ((hipStream_t) hip_stream == c->s_compute)
     c->dirty_compute = true;
-  if (c->inverse) {             /* no table in the rgb2bayer kernel: frame by frame */
-    for (int f = 0; f < nframes; f++) {
-      const int rc = launch (c, d_srcs[f], c->src_bytes, d_dsts[f],
-          c->dst_bytes, 1, (hipStream_t) hip_stream);
-      if (rc != MIBAYER_OK)
-        return rc;
+  if (c->inverse) {
+    /* the sibling direction (reference loop gst/bayer/gstrgb2bayer.c:254-268): up to kMaxList separately allocated
+     * frames per launch of the flat kernel; the tile kernel (MIBAYER_R2B_FLAT=0, tuning) has no table and goes
+     * frame by frame */
+    const mibayer_cfg &f = c->cfg;
+    for (int f0 = 0; f0 < nframes; f0 += kMaxList) {
+      const int n = nframes - f0 < kMaxList ? nframes - f0 : kMaxList;
+      if (c->r2b_flat_k <= 0 || (long long) f.height * (((f.width + 3) & ~3) / 4) > 0x7fffffffLL) {
+        for (int k = 0; k < n; k++) {
+          const int rc = launch (c, d_srcs[f0 + k], c->src_bytes, d_dsts[f0 + k],
+              c->dst_bytes, 1, (hipStream_t) hip_stream);
+          if (rc != MIBAYER_OK)
+            return rc;
+        }
+        continue;
+      }
+      R2BParams q;
+      q.src = nullptr;
+      q.dst = nullptr;
+      q.src_frame_bytes = 0;
+      q.dst_frame_bytes = 0;
+      q.width = f.width;
+      q.height = f.height;
+      q.src_stride = f.src_stride;
+      q.dst_stride = f.dst_stride;
+      q.out_dwords = ((f.width + 3) & ~3) / 4;
+      q.total_rows = f.height;
+      q.band = c->band_override != INT32_MIN ? c->band_override : 0;
+      q.start_sleep = c->start_sleep > 0 ? c->start_sleep : 0;
+      q.flat_k = c->r2b_flat_k;
+      q.flat_px = c->r2b_flat_px;
+      q.flat_ld = c->r2b_flat_ld;
+      q.rows = c->r2b_rows;
+      for (int k = 0; k < 2; k++) {
+        q.sel_lo[k] = c->r2b_lo[k];
+        q.sel_hi[k] = c->r2b_hi[k];
+      }
+      q.nlist = n;
+      bool src16 = true, dst8 = true;
+      for (int k = 0; k < n; k++) {
+        q.src_list[k] = (const uint8_t *) d_srcs[f0 + k];
+        q.dst_list[k] = (uint8_t *) d_dsts[f0 + k];
+        src16 = src16 && aligned16 (d_srcs[f0 + k]);
+        dst8 = dst8 && (((uintptr_t) d_dsts[f0 + k]) & 7u) == 0;
+      }
+      const bool vec16 = (f.width % 4 == 0) && (f.src_stride % 16 == 0) && src16;
+      HIP_TRY (launch_rgb2bayer_list (q, vec16, dst8, (hipStream_t) hip_stream));
     }
     return MIBAYER_OK;
   }

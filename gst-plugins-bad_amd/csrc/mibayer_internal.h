@@ -212,10 +212,20 @@ struct R2BParams {
   int flat_k, flat_px, flat_ld, rows;
   FastDiv div_out_dwords;       /* filled by launch_rgb2bayer (flat kernel) */
   uint32_t item0, item_end;     /* first / one-past-last 4-pixel item of this launch (flat kernel) */
+  /* list launch (flat kernel): frame f is read at src_list[f] and written at dst_list[f] -- frames that are
+   * separate allocations, one GstBuffer each.  Every frame takes a whole number of blocks (blocks_per_frame), so
+   * the frame index is block-uniform and the table look-up a scalar load from the kernel arguments */
+  int nlist;
+  FastDiv div_blocks_per_frame;
+  const uint8_t *src_list[kMaxList];
+  uint8_t *dst_list[kMaxList];
 };
 /* rows [row0, row0 + nrows) of the batch (nrows < 0: all); row0 must be a multiple of 16 */
 hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
     long long row0 = 0, long long nrows = -1);
+/* one launch over p.nlist (<= kMaxList) separately allocated frames (p.src_list / p.dst_list); needs the flat
+ * kernel (p.flat_k > 0); dst8: every destination 8-byte aligned (two items per store allowed) */
+hipError_t launch_rgb2bayer_list (const R2BParams &p, bool vec16, bool dst8, hipStream_t stream);
 
 /* a kernel that only waits, `ms` milliseconds (drills: mibayer_internal_stall) */
 hipError_t launch_stall (int ms, hipStream_t stream);

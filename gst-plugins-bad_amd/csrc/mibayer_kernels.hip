@@ -1167,6 +1167,18 @@ rgb2bayer_kernel (R2BParams p)
  * unconditionally.  VEC = 4: any other geometry -- full items still take one 16-byte load (at
  * dword alignment, which is all a gfx950 global load needs), the partial last item of a row is
  * read dword by dword */
+/* The frame index is block-uniform and the table sits in the kernel arguments: read it straight out of the kernarg
+ * segment (a scalar load at a run-time offset).  Indexing the by-value copy `p` instead made the compiler keep the
+ * whole 480-byte argument block in scratch memory in this kernel (488 bytes per lane, 20x slower): R2BParams is the
+ * kernel's only argument, so it starts at offset 0 of the segment. */
+template <typename T>
+__device__ __forceinline__ T kernarg_table_entry (size_t table_offset, uint32_t index)
+{
+  typedef const __attribute__ ((address_space (4))) char *kptr;
+  kptr base = (kptr) __builtin_amdgcn_kernarg_segment_ptr ();
+  return ((const __attribute__ ((address_space (4))) T *) (base + table_offset))[index];
+}
+
 template <int K, int PX, int LD, int VEC>
 __global__ void __launch_bounds__ (256)
 rgb2bayer_flat_kernel (R2BParams p)
@@ -1178,10 +1190,17 @@ rgb2bayer_flat_kernel (R2BParams p)
     return;
   for (int z = 0; z < p.start_sleep; z++)
     __builtin_amdgcn_s_sleep (1);
-  const uint32_t first = p.item0 + (tile.row * (uint32_t) (256 * K) + threadIdx.x) * IPG;
+  /* list launch: this block's frame (block-uniform) and its first item inside that frame */
+  const uint32_t lframe = p.nlist ? fastdiv (tile.row, p.div_blocks_per_frame) : 0u;
+  const uint32_t lblock = tile.row - lframe * p.div_blocks_per_frame.d;
+  const uint8_t *src_base = p.nlist
+      ? kernarg_table_entry<const uint8_t *> (offsetof (R2BParams, src_list), lframe) : p.src;
+  uint8_t *dst_base = p.nlist
+      ? kernarg_table_entry<uint8_t *> (offsetof (R2BParams, dst_list), lframe) : p.dst;
+  const uint32_t first = p.item0 + (lblock * (uint32_t) (256 * K) + threadIdx.x) * IPG;
   u32x4 px[K][IPG];
   uint32_t par[K];
-  size_t doff[K];               /* byte offset into p.dst (kept as an offset: the stores stay global_store) */
+  size_t doff[K];               /* byte offset into dst_base (kept as an offset: the stores stay global_store) */
   bool valid[K];
 #pragma unroll
   for (int k = 0; k < K; k++) {
@@ -1195,10 +1214,11 @@ rgb2bayer_flat_kernel (R2BParams p)
     if (valid[k]) {
       const uint32_t row = fastdiv (item, p.div_out_dwords);
       const uint32_t xd = item - row * p.div_out_dwords.d;
-      const uint32_t f = fastdiv (row, p.div_height);
+      /* list launch: items count inside the block's own frame, so row == y */
+      const uint32_t f = p.nlist ? 0u : fastdiv (row, p.div_height);
       const uint32_t y = row - f * p.div_height.d;
       par[k] = y & 1u;
-      const uint8_t *s = p.src + f * p.src_frame_bytes + (size_t) y * p.src_stride
+      const uint8_t *s = src_base + f * p.src_frame_bytes + (size_t) y * p.src_stride
           + (size_t) xd * 16;
       doff[k] = f * p.dst_frame_bytes + (size_t) y * p.dst_stride + (size_t) xd * 4;
 #pragma unroll
@@ -1243,7 +1263,7 @@ rgb2bayer_flat_kernel (R2BParams p)
         const uint32_t hi = __builtin_amdgcn_perm (px[k][h].w, px[k][h].z, sel_hi);
         out[h] = lo | hi;
       }
-      uint8_t *d = p.dst + doff[k];
+      uint8_t *d = dst_base + doff[k];
       if constexpr (IPG == 2) {
         u32x2 v;
         v.x = out[0];
@@ -1344,6 +1364,44 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
     default: R2B_LAUNCH (false, 16); break;
   }
 #undef R2B_LAUNCH
+  return hipGetLastError ();
+}
+
+/* reference loop per frame: gst/bayer/gstrgb2bayer.c:254-268; here up to kMaxList frames, each its own allocation,
+ * in one launch of the flat kernel */
+hipError_t launch_rgb2bayer_list (const R2BParams &p, bool vec16, bool dst8, hipStream_t stream)
+{
+  if (p.nlist <= 0 || p.height <= 0 || p.out_dwords <= 0)
+    return hipSuccess;
+  if (p.nlist > kMaxList || p.flat_k <= 0)
+    return hipErrorInvalidValue;
+  R2BParams q = p;
+  q.total_rows = p.height;
+  q.div_height = make_fastdiv ((uint32_t) p.height);
+  q.div_out_dwords = make_fastdiv ((uint32_t) p.out_dwords);
+  const long long items = (long long) p.height * p.out_dwords;
+  if (items > 0x7fffffffLL)
+    return hipErrorInvalidValue;
+  int px = q.flat_px == 8 ? 8 : 4;
+  if (px == 8 && ((p.out_dwords & 1) || (p.dst_stride & 7) || !dst8 || !vec16))
+    px = 4;
+  R2BFn fn = vec16 ? flat_kernel_for<16> (q.flat_k, px, q.flat_ld ? 1 : 0)
+      : flat_kernel_for<4> (q.flat_k, px, q.flat_ld ? 1 : 0);
+  if (!fn)
+    return hipErrorInvalidValue;
+  q.item0 = 0;
+  q.item_end = (uint32_t) items;
+  const long long per_block = 256LL * q.flat_k * (px / 4);
+  const long long bpf = (items + per_block - 1) / per_block;
+  q.div_blocks_per_frame = make_fastdiv ((uint32_t) bpf);
+  const long long nblocks = bpf * p.nlist;
+  if (q.band < 0)
+    q.band = (int) ((nblocks + kNumXcd - 1) / kNumXcd);
+  const long long grid = grid_blocks_for (1, nblocks, q.band);
+  if (grid > 0x7fffffffLL)
+    return hipErrorInvalidValue;
+  q.map = make_tile_map (1, 1, nblocks, q.band, 0);
+  hipLaunchKernelGGL (fn, dim3 ((unsigned) grid), dim3 (256), 0, stream, q);
   return hipGetLastError ();
 }
 

@@ -666,21 +666,35 @@ def test_list_launch_over_separately_allocated_frames(gpu_pkg, oracle):
                 assert np.array_equal(got, oracle.bayer2rgb(src[f], w, pat, r, g, b)), (w, h, pat, f)
             for p in d_srcs + d_dsts:
                 ctx.device_free(p)
-    # the inverse direction goes frame by frame through the same entry point
-    w, h, n = 640, 480, 3
-    rgb = np.random.default_rng(64).integers(0, 256, (n, h, 4 * w), dtype=np.uint8)
-    with gpu_pkg.Context(w, h, "rggb", (1, 2, 3), flags=gpu_pkg.FLAG_RGB2BAYER) as ctx:
-        d_srcs = [ctx.device_alloc(ctx.src_bytes) for _ in range(n)]
-        d_dsts = [ctx.device_alloc(ctx.dst_bytes) for _ in range(n)]
-        for f in range(n):
-            ctx.to_device(d_srcs[f], rgb[f])
-        ctx.process_device_list(d_srcs, d_dsts)
-        ctx.sync()
-        for f in range(n):
-            got = ctx.from_device(d_dsts[f], ctx.dst_bytes).reshape(h, w)
-            assert np.array_equal(got, oracle.rgb2bayer(rgb[f], w, "rggb", 1, 2, 3)[:, :w])
-        for p in d_srcs + d_dsts:
-            ctx.device_free(p)
+    # the inverse direction: the same entry point, up to 16 separately allocated frames per launch of the flat kernel
+    # (21 = 16 + 5), widths that are not a multiple of 4 (partial last item, mosaic rows padded to 4), one frame at a
+    # 4-byte-aligned address (the dword-wise arm), every Bayer order; MIBAYER_R2B_FLAT=0: frame by frame (tile kernel)
+    cases = ((640, 480, 21, "rggb", 0, None), (1918, 50, 5, "gbrg", 4, None), (3840, 2160, 3, "bggr", 0, None),
+             (130, 21, 17, "grbg", 8, None), (641, 37, 4, "rggb", 0, None), (640, 480, 3, "gbrg", 0, "0"))
+    for (w, h, n, pat, misalign, flat) in cases:
+        rgb = np.random.default_rng(64).integers(0, 256, (n, h, 4 * w), dtype=np.uint8)
+        if flat is not None:
+            os.environ["MIBAYER_R2B_FLAT"] = flat
+        try:
+            ctx_cm = gpu_pkg.Context(w, h, pat, (1, 2, 3), flags=gpu_pkg.FLAG_RGB2BAYER)
+        finally:
+            os.environ.pop("MIBAYER_R2B_FLAT", None)
+        with ctx_cm as ctx:
+            d_srcs = [ctx.device_alloc(ctx.src_bytes + 64) for _ in range(n)]
+            d_dsts = [ctx.device_alloc(ctx.dst_bytes + 64) for _ in range(n)]
+            offs = [misalign if f == n // 2 else 0 for f in range(n)]
+            for f in range(n):
+                ctx.to_device(d_srcs[f] + offs[f], rgb[f])
+                ctx.to_device(d_dsts[f], np.full(ctx.dst_bytes + 64, 0xC3, np.uint8))
+            ctx.process_device_list([p + o for p, o in zip(d_srcs, offs)], [p + o for p, o in zip(d_dsts, offs)])
+            ctx.sync()
+            for f in range(n):
+                raw = ctx.from_device(d_dsts[f], ctx.dst_bytes + 64)
+                got = raw[offs[f]:offs[f] + ctx.dst_bytes].reshape(h, ctx.dst_stride)
+                assert np.array_equal(got[:, :w], oracle.rgb2bayer(rgb[f], w, pat, 1, 2, 3)[:, :w]), (w, h, pat, f)
+                assert (raw[:offs[f]] == 0xC3).all() and (raw[offs[f] + ctx.dst_bytes:] == 0xC3).all(), (w, h, f)
+            for p in d_srcs + d_dsts:
+                ctx.device_free(p)
 
 
 def test_hipgraph_host_path_with_changing_pointers(gpu_pkg, oracle):

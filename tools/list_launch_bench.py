@@ -2,7 +2,8 @@
 """What hipbayer2rgb batch=N buys: 64 device-resident 4K frames, each its own allocation, converted
   (a) with one launch per frame (hipbayer2rgb batch=1),  (b) with list launches of 2 / 4 / 8 / 16 frames
   (mibayer_process_device_list),  (c) for reference, as one contiguous 64-frame batch (mibayer_process_device).
-HIP events on the context's compute stream.   Usage (GPU box): python tools/list_launch_bench.py"""
+Wall time per pass incl. launch issue.   Usage (GPU box): python tools/list_launch_bench.py [inverse]
+`inverse`: the sibling direction (rgb2bayer, MIBAYER_FLAG_RGB2BAYER), 4 B/px in, 1 B/px out."""
 import ctypes
 import os
 import sys
@@ -16,13 +17,16 @@ pkg = entry.load_package()
 L = pkg.lib()
 W, H, N, REPS = 3840, 2160, 64, 20
 vp = ctypes.c_void_p
-with pkg.Context(W, H, "rggb", "BGRx") as ctx:
+INVERSE = len(sys.argv) > 1 and sys.argv[1] == "inverse"
+with (pkg.Context(W, H, "rggb", (1, 2, 3), flags=pkg.FLAG_RGB2BAYER) if INVERSE
+      else pkg.Context(W, H, "rggb", "BGRx")) as ctx:
     srcs = [ctx.device_alloc(ctx.src_bytes) for _ in range(N)]
     dsts = [ctx.device_alloc(ctx.dst_bytes) for _ in range(N)]
-    for p in srcs:
-        ctx.fill_synthetic(p, 1, seed=2)
     big_src, big_dst = ctx.device_alloc(N * ctx.src_bytes), ctx.device_alloc(N * ctx.dst_bytes)
-    ctx.fill_synthetic(big_src, N, seed=2)
+    if not INVERSE:             # the content does not matter for the timing; the mosaic generator is bayer2rgb's
+        for p in srcs:
+            ctx.fill_synthetic(p, 1, seed=2)
+        ctx.fill_synthetic(big_src, N, seed=2)
     ctx.sync()
     ev0, ev1 = L.mibayer_dev_event_create(0), L.mibayer_dev_event_create(0)
 
@@ -46,6 +50,7 @@ with pkg.Context(W, H, "rggb", "BGRx") as ctx:
                 ctx.process_device_list(srcs[i:i + k], dsts[i:i + k])
         return fn
 
+    print("# direction: %s" % ("rgb2bayer (inverse)" if INVERSE else "bayer2rgb"))
     print("# 64 device-resident 4K frames per pass, wall time per pass incl. launch issue (python ctypes caller), %d passes" % REPS)
     for label, fn in [("one launch per frame (batch=1)", per_frame)] + \
                      [("list launches of %2d separately allocated frames" % k, lists(k)) for k in (2, 4, 8, 16)] + \
