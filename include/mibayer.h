@@ -255,16 +255,19 @@ int mibayer_time_device (mibayer_ctx *ctx, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     int warmup, int reps, float *ms_per_launch);
 
-/* Measured launch-plan selection for the device-resident path.  MI355X boxes
- * differ in which block->tile order streams best (DESIGN.md "XCD map"): this
- * call times the candidate plans (the three production tile shapes x {band 1,
- * one chunk per XCD, identity order}) on the caller's own buffers with HIP events on the
- * context's compute stream -- a common time-based warm-up (>= 60 ms of
- * launches), then five interleaved rounds of a few launches per candidate, the
- * MEDIAN round counts (about 400 launches in all) -- and keeps the fastest
- * for every later launch of this context.  The
- * kernel is idempotent, so d_dst holds the correct output afterwards.
- * Synchronous.  `report` (may be NULL) receives a one-line summary. */
+/* Measured launch-plan selection for the device-resident path.  MI355X boxes --
+ * and allocations -- differ in which block->tile order streams best (DESIGN.md
+ * "XCD map"): this call times the candidate plans on the caller's own buffers with
+ * HIP events on the context's compute stream and keeps the fastest for every later
+ * launch of this context.  Candidates: the three production tile shapes x {band 1,
+ * one chunk per XCD, identity order}; for generic geometries whose output rows sit
+ * off the 64-byte sector grid additionally x {streaming, write-back, hybrid}
+ * stores, plus the shifted arm (every wave-store on a 128-byte boundary) in the two
+ * narrow shapes.  A common time-based warm-up (>= 60 ms of launches), then five
+ * interleaved rounds of a few launches per candidate; with more than nine
+ * candidates only those within 6 % of the best of the first round stay in; the
+ * MEDIAN round counts.  The kernel is idempotent, so d_dst holds the correct output
+ * afterwards.  Synchronous.  `report` (may be NULL) receives a one-line summary. */
 int mibayer_autotune (mibayer_ctx *ctx, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     char *report, size_t report_len);
