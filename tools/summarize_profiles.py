@@ -140,11 +140,18 @@ if plans:
     bh = os.path.join(src, "build_hash.txt")
     if os.path.exists(bh):
         build = open(bh).read().strip()
-    with open(os.path.join(dst, "traffic_latest.json"), "w") as f:
-        json.dump({"plans": out, "algorithmic_bytes_per_launch": ALG_R + ALG_W, "box_serial": serial, "build": build,
-                   "source": "profiles/%s_summary.md (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + --pmc "
-                             "WRITE_SIZE, separate passes, mean over the timed bench launches, per block order)" % tag},
-                  f, indent=1)
+    tl = os.path.join(dst, "traffic_latest.json")
+    cur = {}
+    if os.path.exists(tl):        # the per-geometry entries (tools/summarize_geometry_counters.py) live in the same file
+        try:
+            cur = json.load(open(tl))
+        except ValueError:
+            cur = {}
+    cur.update({"plans": out, "algorithmic_bytes_per_launch": ALG_R + ALG_W, "box_serial": serial, "build": build,
+                "source": "profiles/%s_summary.md (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + --pmc "
+                          "WRITE_SIZE, separate passes, mean over the timed bench launches, per block order)" % tag})
+    with open(tl, "w") as f:
+        json.dump(cur, f, indent=1)
 with open(os.path.join(dst, "%s_summary.md" % tag), "w") as f:
     f.write("\n".join(lines) + "\n")
 print("\n".join(lines))
