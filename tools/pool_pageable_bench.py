@@ -27,8 +27,9 @@ def pinned(nbytes, shape):
     return p, np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape)
 
 
-def run(memory, helpers, inflight=2):
+def run(memory, helpers, inflight=2, threads="0"):
     os.environ["MIBAYER_POOL_HELPERS"] = helpers
+    os.environ["MIBAYER_POOL_THREADS"] = threads          # "1": a submit thread per shard, pinned frames included
     with pkg.Pool([i % ndev for i in range(SHARDS)], W, H, "rggb", "BGRx", inflight=inflight) as pool:
         cap = pool.capacity
         if memory == "pinned":
@@ -57,9 +58,12 @@ def run(memory, helpers, inflight=2):
 
 print("# 4K bayer2rgb host path through mibayer_pool, %d logical shard(s) on %d GPU(s), 2 frames in flight per shard, "
       "%d frames" % (SHARDS, ndev, FRAMES))
-for memory, helpers, label in (("pinned", "1", "pinned buffers (direct enqueue path)"),
-                               ("pageable", "0", "pageable buffers, copies on the calling thread (helpers off)"),
-                               ("pageable", "1", "pageable buffers, one helper thread per shard")):
-    fps = run(memory, helpers)
+for memory, helpers, threads, label in (
+        ("pinned", "1", "0", "pinned buffers, the calling thread enqueues for every shard"),
+        ("pinned", "1", "1", "pinned buffers, a submit thread per shard (MIBAYER_POOL_THREADS=1)"),
+        ("pageable", "0", "0", "pageable buffers, copies on the calling thread (helpers off)"),
+        ("pageable", "1", "0", "pageable buffers, one helper thread per shard"),
+        ("pageable", "1", "1", "pageable buffers, a submit thread per shard from the start")):
+    fps = run(memory, helpers, threads=threads)
     print("%-64s %7.1f fps  %8.1f Mpix/s  D2H %5.1f GB/s" % (label, fps, fps * W * H / 1e6, fps * 4 * W * H / 1e9),
           flush=True)
