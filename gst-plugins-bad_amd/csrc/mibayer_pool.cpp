@@ -46,7 +46,9 @@
  *
  *  - FAULT INJECTION for drills and tests: mibayer_pool_inject_fault() /
  *    MIBAYER_INJECT_FAULT=shard:frames make a shard report a device error after
- *    it has completed that many frames.
+ *    it has completed that many frames; mibayer_pool_inject_stall() /
+ *    MIBAYER_INJECT_STALL=shard:frames:ms occupy a shard's compute queue for `ms`
+ *    milliseconds once `frames` frames have been routed to it.
  */
 #include "mibayer_hooks.h"
 
@@ -90,6 +92,8 @@ struct Shard {
   int inflight = 0;             /* frames owned and not yet handed back (streaming thread) */
   int node = -1;                /* NUMA node next to the device; -1 unknown */
   long long assigned = 0;       /* frames routed here so far (balance of the NUMA-local routing) */
+  long long stall_after = -1;   /* MIBAYER_INJECT_STALL: stall the compute queue once this many frames were routed here */
+  int stall_ms = 0;
   std::atomic<long long> completions { 0 };
   std::atomic<long long> fail_after { -1 };     /* fault injection; -1 = never */
   /* helper thread */
@@ -399,6 +403,28 @@ extern "C" int mibayer_pool_create (const mibayer_pool_cfg *cfg,
       e = (*end == ',') ? end + 1 : end;
     }
   }
+  if (const char *e = getenv ("MIBAYER_INJECT_STALL")) {
+    /* "shard:frames:ms[,shard:frames:ms...]" */
+    while (*e) {
+      char *end = NULL;
+      const long s = strtol (e, &end, 10);
+      if (end == e || *end != ':')
+        break;
+      e = end + 1;
+      const long long n = strtoll (e, &end, 10);
+      if (end == e || *end != ':')
+        break;
+      e = end + 1;
+      const long ms = strtol (e, &end, 10);
+      if (end == e)
+        break;
+      if (s >= 0 && s < (long) pool->shards.size () && n >= 0 && ms > 0) {
+        pool->shards[(size_t) s]->stall_after = n;
+        pool->shards[(size_t) s]->stall_ms = (int) ms;
+      }
+      e = (*end == ',') ? end + 1 : end;
+    }
+  }
   *out = pool;
   return MIBAYER_OK;
 }
@@ -541,6 +567,11 @@ extern "C" int mibayer_pool_submit (mibayer_pool *pool, const uint8_t *src,
     Shard *sh = pool->shards[idx];
     if (sh->inflight >= pool->per_shard)
       return MIBAYER_ERR_BUSY;
+    if (sh->stall_ms > 0 && sh->assigned >= sh->stall_after) {  /* drill: MIBAYER_INJECT_STALL */
+      const int ms = sh->stall_ms;
+      sh->stall_ms = 0;
+      (void) mibayer_internal_stall (sh->ctx, ms);
+    }
     Frame f = { src, dst, tag, (int) idx, (int) idx, F_DIRECT, MIBAYER_OK };
     if (pool->use_helpers && (mibayer_internal_is_pageable (src) || mibayer_internal_is_pageable (dst))
         && !sh->pageable_seen) {

@@ -270,6 +270,32 @@ def test_a_failed_gpu_is_dropped_and_the_pipeline_carries_on(plugin, gpu_pkg, or
 
 @pytest.mark.gpu
 @needs_gst
+@pytest.mark.parametrize("props", ["timeout-ms=150", "inflight=3 timeout-ms=150", "inflight=2 devices=0,0 timeout-ms=150"])
+def test_a_gpu_that_stops_answering_ends_the_stream_instead_of_hanging_it(plugin, gpu_pkg, tmp_path, props):
+    """VERDICT r02 #4 at element level on real hardware: the compute queue of shard 0 is occupied for 3 s after five
+    frames (MIBAYER_INJECT_STALL, a kernel that only waits), `timeout-ms` is 150.  With one physical GPU there is no
+    survivor (logical shards of one device meet again in its DMA engines), so the element must post an ERROR that
+    names the deadline and the pipeline must END -- well before the stall does -- in the synchronous mode, the queued
+    mode and with two logical shards; the same pipeline without the drill reaches EOS."""
+    import time
+    pipe = ("videotestsrc num-buffers=60 ! video/x-bayer,format=bggr,width=1280,height=720 ! bayer2rgb %s ! fakesink"
+            % props)
+    env = gst_env(tmp_path)
+    env["MIBAYER_INJECT_STALL"] = "0:5:3000"
+    t0 = time.monotonic()
+    res = subprocess.run([GST_LAUNCH, "-q"] + pipe.split(), capture_output=True, text=True, env=env, timeout=60)
+    dt = time.monotonic() - t0
+    out = res.stdout + res.stderr
+    assert res.returncode != 0 and "GPU conversion failed" in out, out[-1500:]
+    assert "did not complete a frame within 150 ms" in out or "deadline" in out, out[-1500:]
+    assert dt < 2.5, dt                       # the stall lasts 3 s: nobody waited for it
+    time.sleep(max(0.0, 3.2 - dt))            # let the drill end before the next pipeline uses the device
+    res = launch(tmp_path, pipe)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-1500:]
+
+
+@pytest.mark.gpu
+@needs_gst
 def test_pinned_pools_are_proposed_and_used(plugin, gpu_pkg, oracle, tmp_path):
     """the element offers a hipHostMalloc pool upstream (videotestsrc takes it) and
     allocates its output from one when downstream brings none."""
