@@ -17,6 +17,7 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <limits.h>
 #include <mutex>
 #include <new>
@@ -293,6 +294,11 @@ struct mibayer_ctx {
 
 /* ---- bounded waits ---------------------------------------------------------- */
 
+/* Set once a wait has run into its deadline: from then on this process does not return pinned blocks to the runtime
+ * (mibayer_host_free) -- hipHostFree drains the device first, i.e. it would sit behind the very GPU that stopped
+ * answering, at the moment a pipeline is shutting down because of it.  The blocks stay allocated until exit. */
+static std::atomic<int> g_device_wedged { 0 };
+
 static double now_ms ()
 {
   timespec t;
@@ -324,6 +330,7 @@ static int wait_event (mibayer_ctx *c, hipEvent_t ev)
     const double dt = now_ms () - t0;
     if (dt >= (double) c->wait_timeout_ms) {
       c->wedged = true;
+      g_device_wedged.store (1);
       snprintf (t_hip_error, sizeof t_hip_error,
           "HIP device %d did not complete a frame within %d ms", c->device, c->wait_timeout_ms);
       return MIBAYER_ERR_TIMEOUT;
@@ -2061,7 +2068,7 @@ extern "C" int mibayer_host_numa_node (const void *p)
 
 extern "C" void mibayer_host_free (void *p)
 {
-  if (p)
+  if (p && g_device_wedged.load () == 0)
     (void) hipHostFree (p);
 }
 

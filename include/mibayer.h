@@ -280,6 +280,9 @@ int mibayer_copy_plan (mibayer_ctx *dst, const mibayer_ctx *src);
 
 /* Pinned (hipHostMalloc) memory for buffer pools feeding the host path. */
 void *mibayer_host_alloc (size_t bytes);
+/* (once a wait of this process has run into its deadline -- MIBAYER_ERR_TIMEOUT --
+ * blocks are no longer returned to the runtime: hipHostFree would wait for the
+ * device that stopped answering) */
 void mibayer_host_free (void *p);
 /* The same, placed on the NUMA node next to HIP device `device` (the thread's
  * memory policy is set around a hipHostMallocNumaUser allocation): a pool that
