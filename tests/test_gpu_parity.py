@@ -369,10 +369,13 @@ def _pinned(L, nbytes, shape):
     return p, np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape)
 
 
-@pytest.mark.parametrize("flags", [0, 1], ids=["streams", "hipgraph"])
-def test_pool_round_robin_shards_keep_order(gpu_pkg, oracle, flags):
+@pytest.mark.parametrize("flags,threads", [(0, "0"), (1, "0"), (0, "1"), (1, "1")],
+                         ids=["streams", "hipgraph", "streams_thread_per_shard", "hipgraph_thread_per_shard"])
+def test_pool_round_robin_shards_keep_order(gpu_pkg, oracle, flags, threads, monkeypatch):
     """Multi-GPU logic without 8 GPUs: N logical shards on the visible device(s) (ordinals repeat), frames
-    round-robin, results in submission order and bit-exact; with and without MIBAYER_FLAG_HIPGRAPH."""
+    round-robin, results in submission order and bit-exact; with and without MIBAYER_FLAG_HIPGRAPH; driven by the
+    calling thread alone or by a submit thread per shard (MIBAYER_POOL_THREADS=1, pinned frames)."""
+    monkeypatch.setenv("MIBAYER_POOL_THREADS", threads)
     w, h, n = 1920, 1080, 23
     ndev = gpu_pkg.device_count()
     devices = [i % ndev for i in range(4)]
