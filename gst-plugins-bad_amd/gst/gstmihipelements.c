@@ -791,10 +791,24 @@ typedef struct
 
 #define HB2R_MAX_BATCH 16       /* frames of one list launch (mibayer_process_device_list) */
 
+/* hiprgb2bayer, the sibling direction (the plugin's second element, reference gst/bayer/gstrgb2bayer.c), is the
+ * same element with the pad roles swapped: a subclass whose class carries `inverse` -- exactly how plugin `bayer`
+ * shares gstmibayerelement.c between bayer2rgb and rgb2bayer */
 typedef struct
 {
   GstBaseTransformClass parent_class;
+  gboolean inverse;             /* FALSE: hipbayer2rgb, TRUE: hiprgb2bayer */
+  const gchar *label;           /* element name used in messages */
 } GstMiHipBayer2RGBClass;
+
+#define HB2R_CLASS_OF(obj) ((GstMiHipBayer2RGBClass *) G_OBJECT_GET_CLASS (obj))
+#define HB2R_INVERSE(obj) (HB2R_CLASS_OF (obj)->inverse)
+#define HB2R_LABEL(obj) (HB2R_CLASS_OF (obj)->label)
+/* bytes of the element's input / output frame */
+#define HB2R_MOSAIC_BYTES(self) ((gsize) GST_ROUND_UP_4 ((self)->width) * (self)->height)
+#define HB2R_VIDEO_BYTES(self) ((gsize) 4 * (self)->width * (self)->height)
+#define HB2R_IN_BYTES(self) (HB2R_INVERSE (self) ? HB2R_VIDEO_BYTES (self) : HB2R_MOSAIC_BYTES (self))
+#define HB2R_OUT_BYTES(self) (HB2R_INVERSE (self) ? HB2R_MOSAIC_BYTES (self) : HB2R_VIDEO_BYTES (self))
 
 GType gst_mi_hip_bayer2rgb_get_type (void);
 G_DEFINE_TYPE (GstMiHipBayer2RGB, gst_mi_hip_bayer2rgb, GST_TYPE_BASE_TRANSFORM);
@@ -889,7 +903,7 @@ hb2r_transform_caps (GstBaseTransform * trans, GstPadDirection direction,
   for (i = 0; i < n; i++) {
     GstStructure *s = gst_caps_get_structure (result, i);
 
-    if (direction == GST_PAD_SINK) {
+    if ((direction == GST_PAD_SINK) != HB2R_INVERSE (trans)) {
       gst_structure_set_name (s, "video/x-raw");
       gst_structure_remove_field (s, "format");
     } else {
@@ -926,7 +940,8 @@ hb2r_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
 {
   static const gchar *orders[] = { "bggr", "gbrg", "grbg", "rggb" };     /* mibayer_pattern order */
   GstMiHipBayer2RGB *self = (GstMiHipBayer2RGB *) trans;
-  GstStructure *s = gst_caps_get_structure (incaps, 0);
+  const gboolean inverse = HB2R_INVERSE (self);
+  GstStructure *s = gst_caps_get_structure (inverse ? outcaps : incaps, 0);     /* the mosaic side */
   const gchar *order = gst_structure_get_string (s, "format");
   GstVideoInfo info;
   gint i;
@@ -938,7 +953,7 @@ hb2r_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
   if (i == 4)
     return FALSE;
   self->format = i;
-  if (!gst_video_info_from_caps (&info, outcaps))
+  if (!gst_video_info_from_caps (&info, inverse ? incaps : outcaps))
     return FALSE;
   self->info = info;
   self->r_off = GST_VIDEO_INFO_COMP_OFFSET (&info, 0);
@@ -946,8 +961,9 @@ hb2r_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
   self->b_off = GST_VIDEO_INFO_COMP_OFFSET (&info, 2);
 
   /* outside the domain in which the reference is well defined (see
-   * gstmibayerelement.c: set_caps): refuse the caps */
-  if (self->width < 4 || (self->width & 1) || self->height < 3) {
+   * gstmibayerelement.c: set_caps): refuse the caps.  rgb2bayer has no
+   * neighbourhood and takes any size */
+  if (!inverse && (self->width < 4 || (self->width & 1) || self->height < 3)) {
     GST_WARNING_OBJECT (self, "refusing %dx%d: needs an even width >= 4 and a "
         "height >= 3", self->width, self->height);
     return FALSE;
@@ -973,13 +989,14 @@ hb2r_device_of (GstMiHipBayer2RGB * self, GstBuffer * inbuf, gint * device)
 
   if (mem == NULL) {
     GST_ELEMENT_ERROR (self, CORE, NEGOTIATION,
-        ("hipbayer2rgb needs HIP device memory on both pads"), (NULL));
+        ("%s needs HIP device memory on both pads", HB2R_LABEL (self)), (NULL));
     return FALSE;
   }
   *device = ((GstMiHipMemory *) mem)->device;
   if (pinned >= 0 && pinned != *device) {
     GST_ELEMENT_ERROR (self, CORE, NEGOTIATION,
-        ("hipbayer2rgb: buffers live on another GPU than device-id=%d", pinned),
+        ("%s: buffers live on another GPU than device-id=%d", HB2R_LABEL (self),
+            pinned),
         ("input memory on HIP device %d; leave device-id at -1 to follow the "
             "frames, or set the same device-id on hipupload", *device));
     return FALSE;
@@ -1005,11 +1022,12 @@ hb2r_ensure_ctx (GstMiHipBayer2RGB * self, gint device)
   cfg.g_off = self->g_off;
   cfg.b_off = self->b_off;
   cfg.device = device;
+  cfg.flags = HB2R_INVERSE (self) ? MIBAYER_FLAG_RGB2BAYER : 0;
   rc = mibayer_create (&cfg, &self->ctx);
   if (rc != MIBAYER_OK) {
     self->ctx = NULL;
     GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
-        ("hipbayer2rgb: cannot create GPU context on device %d", device),
+        ("%s: cannot create GPU context on device %d", HB2R_LABEL (self), device),
         ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
     return FALSE;
   }
@@ -1038,14 +1056,14 @@ hb2r_prepare_output_buffer (GstBaseTransform * trans, GstBuffer * inbuf,
     if (caps == NULL)
       return GST_FLOW_NOT_NEGOTIATED;
     self->out_pool = configured_pool (gst_mi_hip_pool_new (device), caps,
-        (guint) ((gsize) 4 * self->width * self->height), 2);
+        (guint) HB2R_OUT_BYTES (self), 2);
     gst_caps_unref (caps);
     if (self->out_pool == NULL
         || !gst_buffer_pool_set_active (self->out_pool, TRUE)) {
       hb2r_drop_out_pool (self);
       GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
-          ("hipbayer2rgb: cannot set up a device-memory pool on device %d",
-              device), ("%s", mibayer_last_hip_error ()));
+          ("%s: cannot set up a device-memory pool on device %d",
+              HB2R_LABEL (self), device), ("%s", mibayer_last_hip_error ()));
       return GST_FLOW_ERROR;
     }
     self->out_pool_device = device;
@@ -1076,7 +1094,7 @@ hb2r_map_pair (GstMiHipBayer2RGB * self, GstBuffer * inbuf, GstBuffer * outbuf,
     return FALSE;
   if (!*out_mem || ((GstMiHipMemory *) * out_mem)->device != device) {
     GST_ELEMENT_ERROR (self, CORE, NEGOTIATION,
-        ("hipbayer2rgb: input and output frames must live on one GPU"),
+        ("%s: input and output frames must live on one GPU", HB2R_LABEL (self)),
         ("input memory on HIP device %d, output %s", device,
             *out_mem ? "on another device" : "not in HIP device memory"));
     return FALSE;
@@ -1091,15 +1109,13 @@ hb2r_map_pair (GstMiHipBayer2RGB * self, GstBuffer * inbuf, GstBuffer * outbuf,
     gst_memory_unmap (*in_mem, in_map);
     return FALSE;
   }
-  if (in_map->size < (gsize) GST_ROUND_UP_4 (self->width) * self->height
-      || out_map->size < (gsize) 4 * self->width * self->height) {
+  if (in_map->size < HB2R_IN_BYTES (self) || out_map->size < HB2R_OUT_BYTES (self)) {
     GST_ELEMENT_ERROR (self, STREAM, FORMAT,
-        ("hipbayer2rgb: device buffer smaller than a %dx%d frame", self->width,
-            self->height),
+        ("%s: device buffer smaller than a %dx%d frame", HB2R_LABEL (self),
+            self->width, self->height),
         ("input %" G_GSIZE_FORMAT " bytes (need %" G_GSIZE_FORMAT "), output %"
             G_GSIZE_FORMAT " bytes (need %" G_GSIZE_FORMAT ")", in_map->size,
-            (gsize) GST_ROUND_UP_4 (self->width) * self->height, out_map->size,
-            (gsize) 4 * self->width * self->height));
+            HB2R_IN_BYTES (self), out_map->size, HB2R_OUT_BYTES (self)));
     gst_memory_unmap (*out_mem, out_map);
     gst_memory_unmap (*in_mem, in_map);
     return FALSE;
@@ -1140,7 +1156,7 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
     rc = mibayer_sync (self->ctx);      /* no event: finish before anyone looks */
   if (rc != MIBAYER_OK) {
     GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
-        ("hipbayer2rgb: GPU conversion failed"),
+        ("%s: GPU conversion failed", HB2R_LABEL (self)),
         ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
     ret = GST_FLOW_ERROR;
   }
@@ -1211,7 +1227,7 @@ hb2r_convert_waiting (GstMiHipBayer2RGB * self)
     rc = mibayer_sync (self->ctx);      /* no event: finish before anyone looks */
   if (rc != MIBAYER_OK) {
     GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
-        ("hipbayer2rgb: GPU conversion failed"),
+        ("%s: GPU conversion failed", HB2R_LABEL (self)),
         ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
     ret = GST_FLOW_ERROR;
   }
@@ -1334,6 +1350,8 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
   GstElementClass *element_class = GST_ELEMENT_CLASS (klass);
   GstBaseTransformClass *transform_class = GST_BASE_TRANSFORM_CLASS (klass);
 
+  klass->inverse = FALSE;
+  klass->label = "hipbayer2rgb";
   object_class->set_property = hb2r_set_property;
   object_class->get_property = hb2r_get_property;
   object_class->finalize = hb2r_finalize;
@@ -1381,6 +1399,41 @@ gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
   g_queue_init (&self->ready);
 }
 
+/* ---- hiprgb2bayer: the same element, pad roles swapped ------------------------------ */
+
+typedef GstMiHipBayer2RGB GstMiHipRGB2Bayer;
+typedef GstMiHipBayer2RGBClass GstMiHipRGB2BayerClass;
+GType gst_mi_hip_rgb2bayer_get_type (void);
+G_DEFINE_TYPE (GstMiHipRGB2Bayer, gst_mi_hip_rgb2bayer,
+    gst_mi_hip_bayer2rgb_get_type ());
+
+/* the reference's rgb2bayer takes ARGB only (gst/bayer/gstrgb2bayer.c:59-63) */
+#define HR2B_SINK_CAPS GST_VIDEO_CAPS_MAKE_WITH_FEATURES ( \
+    GST_CAPS_FEATURE_MEMORY_HIP, "ARGB")
+#define HR2B_SRC_CAPS HIP_CAPS ("video/x-bayer") \
+  ",format=(string){bggr,grbg,gbrg,rggb}," \
+  "width=(int)[1,MAX],height=(int)[1,MAX],framerate=(fraction)[0/1,MAX]"
+
+static void
+gst_mi_hip_rgb2bayer_class_init (GstMiHipRGB2BayerClass * klass)
+{
+  GstElementClass *element_class = GST_ELEMENT_CLASS (klass);
+
+  klass->inverse = TRUE;
+  klass->label = "hiprgb2bayer";
+  xfer_add_templates (element_class, HR2B_SINK_CAPS, HR2B_SRC_CAPS);    /* replace the parent's */
+  gst_element_class_set_static_metadata (element_class,
+      "RGB to Bayer converter (HIP device memory)", "Filter/Converter/Video",
+      "Converts video/x-raw to video/x-bayer without leaving MI355X memory; "
+      "batch=N converts N buffers with one launch",
+      "gst-plugins-bad_amd");
+}
+
+static void
+gst_mi_hip_rgb2bayer_init (GstMiHipRGB2Bayer * self)
+{
+}
+
 /* ======================================================================== */
 
 #ifndef PACKAGE
@@ -1400,7 +1453,9 @@ plugin_init (GstPlugin * plugin)
       && gst_element_register (plugin, "hipdownload", GST_RANK_NONE,
       gst_mi_hip_download_get_type ())
       && gst_element_register (plugin, "hipbayer2rgb", GST_RANK_NONE,
-      gst_mi_hip_bayer2rgb_get_type ());
+      gst_mi_hip_bayer2rgb_get_type ())
+      && gst_element_register (plugin, "hiprgb2bayer", GST_RANK_NONE,
+      gst_mi_hip_rgb2bayer_get_type ());
 }
 
 GST_PLUGIN_DEFINE (GST_VERSION_MAJOR, GST_VERSION_MINOR, mihip,

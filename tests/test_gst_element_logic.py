@@ -249,6 +249,19 @@ def test_device_memory_elements_honour_the_last_access_event(rig, tmp_path):
     assert kv["cycles_ok"] == "3"
 
 
+def test_device_memory_rgb2bayer_shares_the_converter_logic(rig, tmp_path):
+    """hiprgb2bayer = hipbayer2rgb with the pad roles swapped (a subclass whose class carries the direction): frame
+    by frame and batched, every frame once, in order, mosaic-sized output, last-access events honoured."""
+    w, h, n = 130, 21, 12
+    inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
+    frames(n, 4 * w * h, first=70).tofile(inp)
+    for launch in ("hipupload ! hiprgb2bayer ! hipdownload", "hipupload ! hiprgb2bayer batch=4 ! hipdownload"):
+        kv = run(rig, "convert", launch, R2B % (w, h), inp, 4 * w * h, outp)
+        assert kv["pushed"] == str(n) and kv["pulled"] == str(n), launch
+        seq, fill = stamps(outp, n, 132 * h)
+        assert fill == list(range(70, 70 + n)) and seq == list(range(n)), launch
+
+
 def test_state_cycles(rig):
     kv = run(rig, "states", "videotestsrc num-buffers=9 ! video/x-bayer,format=rggb,width=64,height=48 ! "
              "bayer2rgb inflight=3 ! fakesink", 4)

@@ -22,8 +22,13 @@ def launch(tmp, pipeline, debug=None):
 def test_mihip_plugin_registers_three_elements(plugin, tmp_path):
     out = subprocess.run([GST_INSPECT, "mihip"], capture_output=True, text=True, env=gst_env(tmp_path),
                          timeout=120).stdout
-    for name in ("hipupload", "hipdownload", "hipbayer2rgb"):
+    for name in ("hipupload", "hipdownload", "hipbayer2rgb", "hiprgb2bayer"):
         assert name + ":" in out
+    out = subprocess.run([GST_INSPECT, "hiprgb2bayer"], capture_output=True, text=True, env=gst_env(tmp_path),
+                         timeout=120).stdout
+    # the sibling direction: ARGB in device memory in (the reference's rgb2bayer takes ARGB only), mosaic out
+    assert "video/x-raw(memory:HIPMemory)" in out and "ARGB" in out and "video/x-bayer(memory:HIPMemory)" in out
+    assert "batch" in out and "device-id" in out
     out = subprocess.run([GST_INSPECT, "hipbayer2rgb"], capture_output=True, text=True, env=gst_env(tmp_path),
                          timeout=120).stdout
     assert "video/x-bayer(memory:HIPMemory)" in out and "video/x-raw(memory:HIPMemory)" in out
@@ -46,6 +51,41 @@ def test_upload_convert_download_pipeline(plugin, gpu_pkg, oracle, tmp_path):
     got = np.fromfile(outp, np.uint8).reshape(n, h, 4 * w)
     want = oracle.bayer2rgb_batch(src, w, "rggb", 2, 1, 0, nthreads=2)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("props", ["", "batch=4", "batch=16"])
+def test_device_resident_rgb2bayer_and_round_trip(plugin, gpu_pkg, oracle, tmp_path, props):
+    """hiprgb2bayer, the device-resident sibling direction (reference loop gst/bayer/gstrgb2bayer.c:254-268): ARGB
+    frames uploaded once, converted in HBM -- frame by frame or N separately allocated buffers per list launch
+    (mibayer_process_device_list with MIBAYER_FLAG_RGB2BAYER) -- and downloaded: same bytes as the oracle; and
+    hiprgb2bayer ! hipbayer2rgb without leaving the GPU reproduces what the host elements give for the same chain."""
+    w, h, n = 1282, 721, 19            # width % 4 == 2: mosaic rows padded to 1284
+    inp, outp = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
+    res = launch(tmp_path,
+                 "videotestsrc num-buffers=%d pattern=snow ! video/x-raw,format=ARGB,width=%d,height=%d,framerate=30/1 "
+                 "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! hipupload ! hiprgb2bayer %s "
+                 "! hipdownload ! video/x-bayer,format=gbrg ! filesink location=%s" % (n, w, h, inp, props, outp))
+    assert res.returncode == 0, res.stderr[-2000:]
+    rgb = np.fromfile(inp, np.uint8).reshape(n, h, 4 * w)
+    stride = (w + 3) & ~3
+    got = np.fromfile(outp, np.uint8).reshape(n, h, stride)
+    for f in range(n):
+        assert np.array_equal(got[f][:, :w], oracle.rgb2bayer(rgb[f], w, "gbrg", 1, 2, 3)[:, :w]), f
+    # round trip on the GPU: ARGB -> mosaic -> BGRx, device memory all the way
+    w2, h2 = 1280, 720
+    out2 = str(tmp_path / "out2.raw")
+    res = launch(tmp_path,
+                 "videotestsrc num-buffers=%d pattern=snow ! video/x-raw,format=ARGB,width=%d,height=%d,framerate=30/1 "
+                 "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! hipupload ! hiprgb2bayer %s "
+                 "! video/x-bayer(memory:HIPMemory),format=rggb ! hipbayer2rgb %s ! hipdownload "
+                 "! video/x-raw,format=BGRx ! filesink location=%s" % (n, w2, h2, inp, props, props, out2))
+    assert res.returncode == 0, res.stderr[-2000:]
+    rgb = np.fromfile(inp, np.uint8).reshape(n, h2, 4 * w2)
+    got = np.fromfile(out2, np.uint8).reshape(n, h2, 4 * w2)
+    for f in range(n):
+        mosaic = oracle.rgb2bayer(rgb[f], w2, "rggb", 1, 2, 3)
+        assert np.array_equal(got[f], oracle.bayer2rgb(mosaic, w2, "rggb", 2, 1, 0)), f
 
 
 @pytest.mark.gpu
