@@ -52,6 +52,8 @@
  */
 #include "mibayer_hooks.h"
 
+#include <sched.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -144,8 +146,59 @@ void helper_give_up (Shard *sh, const char *why)
  * blocks while the runtime stages the upload -- that is the point of being on a
  * thread of its own) and retires the oldest frame whenever nothing can be
  * submitted. */
+/* A shard's thread runs on the CPUs of the NUMA node next to its GPU (hard part 7: "per-GPU
+ * threads, NUMA-local pinned buffers"): its staging copies and the runtime's submission path then touch memory of
+ * that socket only.  Best effort -- the node's CPU list comes from sysfs; nothing happens when the node is unknown,
+ * the list cannot be read, or none of its CPUs is in the thread's current mask.  MIBAYER_POOL_PIN_THREADS=0: off. */
+void pin_to_node (int node)
+{
+  if (node < 0)
+    return;
+  if (const char *e = getenv ("MIBAYER_POOL_PIN_THREADS"))
+    if (atoi (e) == 0)
+      return;
+  char path[96];
+  snprintf (path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+  FILE *f = fopen (path, "r");
+  if (!f)
+    return;
+  char list[4096];
+  const size_t n = fread (list, 1, sizeof list - 1, f);
+  fclose (f);
+  list[n] = 0;
+  cpu_set_t allowed, want;
+  CPU_ZERO (&want);
+  if (sched_getaffinity (0, sizeof allowed, &allowed) != 0)
+    return;
+  int count = 0;
+  for (char *q = list; *q;) {           /* "0-63,128-191" */
+    char *end = NULL;
+    const long a = strtol (q, &end, 10);
+    if (end == q)
+      break;
+    long b = a;
+    if (*end == '-') {
+      q = end + 1;
+      b = strtol (q, &end, 10);
+      if (end == q)
+        break;
+    }
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+      if (c >= 0 && CPU_ISSET ((int) c, &allowed)) {
+        CPU_SET ((int) c, &want);
+        count++;
+      }
+    q = (*end == ',') ? end + 1 : end;
+    if (*end != ',' )
+      break;
+  }
+  if (count > 0)
+    (void) sched_setaffinity (0, sizeof want, &want);
+}
+
 void helper_main (Shard *sh)
 {
+  pin_to_node (sh->node);
   std::unique_lock<std::mutex> lk (sh->mu);
   for (;;) {
     sh->cv_job.wait (lk, [sh] {
