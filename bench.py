@@ -289,7 +289,10 @@ def host_path_rate(pkg, device, frames=24, inflight=3, flags=0, graph_mode=None)
     with ctx_cm as ctx:
         srcs, dsts = [], []
         for _ in range(inflight):
-            ps, pd = L.mibayer_host_alloc(ctx.src_bytes), L.mibayer_host_alloc(ctx.dst_bytes)
+            # pinned staging on the NUMA node next to THIS rank's GPU (on a two-socket 8-GPU node half the ranks
+            # would otherwise copy across the socket link)
+            ps = L.mibayer_host_alloc_near(device, ctx.src_bytes)
+            pd = L.mibayer_host_alloc_near(device, ctx.dst_bytes)
             s = np.ctypeslib.as_array(ctypes.cast(ps, ctypes.POINTER(ctypes.c_uint8)), (ctx.src_bytes,))
             d = np.ctypeslib.as_array(ctypes.cast(pd, ctypes.POINTER(ctypes.c_uint8)), (ctx.dst_bytes,))
             s[:] = 0x55
