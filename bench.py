@@ -428,6 +428,25 @@ def setup_distributed(args):
     return world, rank, device, plane
 
 
+def pin_to_device_node(pkg, device):
+    """Host-fed ranks run on the CPUs of the NUMA node next to their GPU (best effort; returns the node or -1)."""
+    try:
+        node = pkg.lib().mibayer_device_numa_node(device)
+        if node < 0:
+            return -1
+        cpus = set()
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            for part in f.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= set(os.sched_getaffinity(0))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return node
+    except (OSError, ValueError, AttributeError):
+        return -1
+
+
 def run_stream(args):
     """BASELINE.json configs[4]: 3840x2160 steady-state stream, pinned double-buffered H2D/D2H + hipGraph launch,
     1000 frames sharded round-robin over the ranks.  PCIe/host-DRAM-bound by construction."""
@@ -435,6 +454,7 @@ def run_stream(args):
     import __graft_entry__ as entry
     pkg = entry.load_package()
     world, rank, local_rank, dist = setup_distributed(args)
+    node = pin_to_device_node(pkg, local_rank)
     total = 1000
     mine = len(shard_frames(total, world, rank))
     def timed(flags, graph_mode=None):
@@ -466,7 +486,8 @@ def run_stream(args):
     parity = "bit-exact vs oracle on global frame %d (rggb->%s, host path)" % (gframe, FORMAT)
     per_gpu = None
     if dist is not None:
-        per_gpu = dist.gather_objects({"rank": rank, "device": local_rank, "frames": mine, "parity": parity})
+        per_gpu = dist.gather_objects({"rank": rank, "device": local_rank, "numa_node": node, "frames": mine,
+                                       "parity": parity})
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
