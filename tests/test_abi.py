@@ -178,3 +178,22 @@ def test_auto_variant_minimises_wasted_lanes(pkg):
             2600: "lds_1x8"}
     for w, prefix in want.items():
         assert names[f(w)].startswith(prefix), (w, names[f(w)])
+
+
+def test_every_environment_knob_of_the_library_is_documented():
+    """Every MIBAYER_* variable the native sources read is named in DESIGN.md, INTEGRATION.md or the ABI header: a knob
+    nobody can find is not a knob."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "gst-plugins-bad_amd", "csrc")
+    used = set()
+    for name in os.listdir(csrc):
+        with open(os.path.join(csrc, name)) as f:
+            used |= set(re.findall(r'getenv \("(MIBAYER_[A-Z0-9_]+)"\)', f.read()))
+    docs = ""
+    for name in ("DESIGN.md", "INTEGRATION.md", os.path.join("include", "mibayer.h")):
+        with open(os.path.join(root, name)) as f:
+            docs += f.read()
+    assert len(used) >= 15
+    missing = sorted(v for v in used if v not in docs)
+    assert not missing, missing
