@@ -182,7 +182,6 @@ int resolve_variant (int id, int width);        /* 0 ("auto") -> a concrete id *
  * 64-byte sector; any other id is returned unchanged */
 int plain_store_twin (int id);
 int hybrid_store_twin (int id);                 /* 1 -> 22, 2 -> 23, 3 -> 24: the hybrid store policy */
-int phased_store_twin (int id);                 /* 1 -> 25, 2 -> 26, 3 -> 27: hybrid + 8-byte-phase rows shifted */
 int production_shape_of (int id);               /* the inverse of both: 20, 22 -> 1; 21, 23 -> 2; 4, 24 -> 3 */
 
 /* rgb2bayer (reference gst/bayer/gstrgb2bayer.c:230-278) */

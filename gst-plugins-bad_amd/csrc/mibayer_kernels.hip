@@ -205,7 +205,7 @@ __device__ __forceinline__ void store_pixels (uint8_t *p, u32x4 px,
 {
   constexpr int ST = STLD & 7;  /* bit 3 = nt hint on the tile's row loads, bit 4 = direct-to-LDS loads */
   if constexpr (!GENERIC) {
-    if constexpr (ST == 1 || ST == 5 || ST == 6)      /* 5, 6: policies of generic geometries; aligned rows stream */
+    if constexpr (ST == 1 || ST == 5)         /* 5: the hybrid policy of generic geometries; aligned rows stream */
       __builtin_nontemporal_store (px, (u32x4 *) p);
     else if constexpr (ST == 2)
       asm volatile ("global_store_dwordx4 %0, %1, off sc1" :: "v" (p), "v" (px) : "memory");
@@ -258,42 +258,6 @@ __device__ __forceinline__ void store_pixels_hybrid (uint8_t *p, u32x4 px,
     asm volatile ("global_store_dwordx4 %0, %1, off nt" :: "v" (p), "v" (px) : "memory");
   } else {
     asm volatile ("global_store_dwordx4 %0, %1, off" :: "v" (p), "v" (px) : "memory");
-  }
-}
-
-/* Store policy 6 ("phased"): policy 5, plus: an output row that starts 8 bytes off the 16-byte grid (every second row
- * of a width % 4 == 2 frame) makes each lane's 16-byte store straddle a 16-byte boundary (hybrid: 71.5 % of peak
- * against 75.8 % for the same rows 16 bytes off).  Such a row is written two pixels to the right: lane i
- * stores the last two pixels of lane i-1 and its own first two -- columns 4i-2 .. 4i+1, a 16-byte aligned address;
- * lane 0 has no lane below and stores its own four columns where they are (the two it shares with lane 1 carry the
- * same bytes); the last two columns of the wave go out as one 8-byte store.  Nothing crosses a wave: the Lines of
- * the source rows keep their column map, only finished pixels move, two DPP moves per row.
- * `on`: this lane has a pixel to store in this row.  Call with the whole wave converged (DPP reads lane i-1). */
-__device__ __forceinline__ void store_pixels_phased (uint8_t *p, u32x4 px,
-    int lastmode, int lane, int len, bool on)
-{
-  const uint32_t phase = __builtin_amdgcn_readfirstlane ((uint32_t) (uintptr_t) p) & 15u;     /* p differs by 16 * lane */
-  if (phase != 8u) {
-    if (on)
-      store_pixels_hybrid (p, px, lastmode, 16 * lane, len);
-    return;
-  }
-  u32x4 ch;
-  ch.x = from_lane_below (px.x, px.z);
-  ch.y = from_lane_below (px.y, px.w);
-  ch.z = lane == 0 ? px.z : px.x;
-  ch.w = lane == 0 ? px.w : px.y;
-  const int rel = lane == 0 ? 0 : 16 * lane - 8;      /* first byte of this lane's chunk, from the wave's first */
-  /* the wave's last lane holds four columns (not the two of a width % 4 == 2 row end): the upper two are the tail */
-  const int chunk_len = (len & 15) == 0 ? len - 8 : len;
-  if (on) {
-    store_pixels_hybrid (p + (rel - 16 * lane), ch, lane == 0 ? lastmode : 0, rel, chunk_len);
-    if (lane != 0 && (lastmode == 1 || (lane == 63 && lastmode == 0))) {
-      u32x2 two;
-      two.x = px.z;
-      two.y = px.w;
-      *(u32x2_a4 *) (p + 8) = two;
-    }
   }
 }
 
@@ -500,9 +464,7 @@ bayer2rgb_lds_kernel (KParams p)
     const Lines dn = lines_of (r0 + k + 2);
     const int type = (k & 1) ^ p.swap_rows;
     const u32x4 px = merge_rows<INTRIN> (up, cur, dn, type, p.sel);
-    if constexpr (GENERIC && (ST & 7) == 6) {
-      store_pixels_phased (out, px, lastmode, lane, wave_len, active && k < nrows);
-    } else if (active && k < nrows) {
+    if (active && k < nrows) {
       if constexpr (GENERIC && (ST & 7) == 5)
         store_pixels_hybrid (out, px, lastmode, 16 * lane, wave_len);
       else
@@ -1036,10 +998,6 @@ static const Variant kVariants[] = {
   LDS_VARIANT ("lds_4x2_r4_dpp_hy", 4, 2, 4, 0, 5, true),
   LDS_VARIANT ("lds_2x4_r4_dpp_hy", 2, 4, 4, 0, 5, true),
   LDS_VARIANT ("lds_1x8_r4_dpp_hy", 1, 8, 4, 0, 5, true),
-  /* 25-27: phased store policy (hybrid + rows at an 8-byte phase written two pixels to the right, 16-byte aligned) */
-  LDS_VARIANT ("lds_4x2_r4_dpp_ph", 4, 2, 4, 0, 6, true),
-  LDS_VARIANT ("lds_2x4_r4_dpp_ph", 2, 4, 4, 0, 6, true),
-  LDS_VARIANT ("lds_1x8_r4_dpp_ph", 1, 8, 4, 0, 6, true),
 };
 
 int variant_count ()
@@ -1081,24 +1039,13 @@ int hybrid_store_twin (int id)
   }
 }
 
-/* the phased-store arm of a production shape (store_pixels_phased), for output rows at an 8-byte phase */
-int phased_store_twin (int id)
-{
-  switch (id) {
-    case 1: return 25;          /* lds_4x2_r4_dpp_ph */
-    case 2: return 26;          /* lds_2x4_r4_dpp_ph */
-    case 3: return 27;          /* lds_1x8_r4_dpp_ph */
-    default: return id;
-  }
-}
-
-/* the production shape (ids 1-3) a plain- / hybrid- / phased-store twin stands for; any other id is returned unchanged */
+/* the production shape (ids 1-3) a plain-store or hybrid-store twin stands for; any other id is returned unchanged */
 int production_shape_of (int id)
 {
   switch (id) {
-    case 20: case 22: case 25: return 1;
-    case 21: case 23: case 26: return 2;
-    case 4: case 24: case 27: return 3;
+    case 20: case 22: return 1;
+    case 21: case 23: return 2;
+    case 4: case 24: return 3;
     default: return id;
   }
 }

@@ -784,13 +784,12 @@ def test_sector_aligned_store_arm(gpu_pkg, oracle, align, monkeypatch):
     names = gpu_pkg.variant_names()
     shapes = [0] + [names.index(n) for n in ("lds_4x2_r4_dpp_nt", "lds_2x4_r4_dpp_nt", "lds_1x8_r4_dpp_nt",
                                              "lds_1x8_r4_dpp", "lds_4x2_r4_dpp", "lds_2x4_r4_dpp",
-                                             "lds_4x2_r4_dpp_hy", "lds_4x2_r4_dpp_ph", "lds_2x4_r4_dpp_ph",
-                                             "lds_1x8_r4_dpp_ph")]
+                                             "lds_4x2_r4_dpp_hy", "lds_2x4_r4_dpp_hy", "lds_1x8_r4_dpp_hy")]
     # (w, h, extra destination pitch, destination offset inside the allocation, frames)
     cases = [(4056, 9, 0, 0, 1), (3838, 10, 0, 8, 1), (1366, 11, 0, 0, 3), (30, 7, 0, 40, 2), (6, 4, 0, 8, 3),
              (4, 3, 8, 24, 2), (270, 5, 24, 56, 1), (1026, 17, 8, 0, 2), (2050, 12, 40, 16, 1), (1030, 33, 0, 120, 2),
              (258, 35, 0, 0, 4), (1290, 8, 104, 72, 1), (14, 40, 0, 8, 1), (1024 + 18, 9, 0, 0, 1),
-             # rows of four-column lanes at an 8-byte phase (the phased policy's tail store), a wave of four columns
+             # rows of four-column lanes at an 8-byte phase, a wave of four columns
              (4056, 9, 8, 8, 2), (1024, 6, 8, 8, 1), (260, 7, 0, 8, 2), (516, 5, 24, 0, 1), (8, 6, 0, 8, 1)]
     for ci, (w, h, pad, off, n) in enumerate(cases):
         sstride = (w + 3) & ~3
