@@ -947,9 +947,9 @@ extern "C" void mibayer_destroy (mibayer_ctx *c)
   if (!c)
     return;
   DeviceGuard guard (c->device);
+  (void) wait_own_frames (c);           /* returns at once for a wedged context; may be what finds it wedged */
   const bool leak = c->wedged;
   if (!leak) {
-    (void) wait_own_frames (c);
     free_ring (c);
     free_slot (c, c->spare);
     for (hipEvent_t ev : { c->ev_t0, c->ev_t1, c->ev_fence })

@@ -985,6 +985,22 @@ def test_wait_deadline_on_a_stalled_device(gpu_pkg, oracle):
     time.sleep(1.6)                                             # the drill ends; the late DMA lands in host_dst
     with gpu_pkg.Context(w, h, "rggb", "BGRx") as ctx2:
         assert np.array_equal(ctx2.process_host(src), want)
+    # destroy itself is what finds the device stalled (a frame in flight, nobody waited for it): bounded, and the
+    # frames the device may still write are NOT handed to the next context of this geometry
+    ctx3 = gpu_pkg.Context(w, h, "rggb", "BGRx", inflight=2)
+    assert np.array_equal(ctx3.process_host(src), want)
+    ctx3.set_wait_timeout(100)
+    ctx3.stall(1200)
+    host_dst[...] = 0
+    ctx3.submit(host_src, host_dst, 3)
+    t0 = time.monotonic()
+    ctx3.close()
+    assert 0.08 <= time.monotonic() - t0 < 0.6
+    src_b = oracle.fill_synthetic(w, h, 1, seed=93)[0]
+    with gpu_pkg.Context(w, h, "rggb", "BGRx", inflight=2) as ctx4:     # queued behind the drill on the shared queues
+        ctx4.set_wait_timeout(5000)
+        assert np.array_equal(ctx4.process_host(src_b), oracle.bayer2rgb(src_b, w, "rggb", 2, 1, 0))
+    assert np.array_equal(host_dst, want)                       # the abandoned frame did land, late, where it belonged
     L.mibayer_host_free(p_src)
     L.mibayer_host_free(p_dst)
 
