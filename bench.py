@@ -48,9 +48,11 @@ def shard_frames(total_frames, world_size, rank):
     return list(range(rank, total_frames, world_size))
 
 
-def timed_region(step_fn, steps, warmup, sync_fn, dist=None):
+def timed_region(step_fn, steps, warmup, sync_fn, dist=None, info=None):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both
-    sides.  Returns the MAX over ranks of the elapsed seconds."""
+    sides.  Returns the MAX over ranks of the elapsed seconds.  `info` (a dict) receives `barrier_ms`: the wall time
+    of the closing barrier on this rank (it sits inside the timed region, as the contract asks, so a slow control
+    plane shows up in `value`; this is how much)."""
     for i in range(warmup):
         step_fn(i)
     sync_fn()
@@ -61,10 +63,14 @@ def timed_region(step_fn, steps, warmup, sync_fn, dist=None):
     for i in range(steps):
         step_fn(warmup + i)
     sync_fn()
+    tb = time.perf_counter()
     if dist is not None:
         dist.barrier()
     sync_fn()
-    elapsed = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if info is not None:
+        info["barrier_ms"] = (t1 - tb) * 1e3 if dist is not None else 0.0
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -361,13 +367,140 @@ def profiled_traffic(band, variant_name=None):
         return None
 
 
+def parse_pmc_csv(path, counter, kernel_substr="bayer2rgb", last=8):
+    """rocprofv3 `--pmc <counter> --output-format csv` counter_collection file -> (kernel name, mean counter value over
+    the last `last` dispatches of kernels whose name contains `kernel_substr`, dispatches used); (None, None, 0) when
+    the file holds no such row."""
+    import csv
+    rows = []
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") == counter and kernel_substr in r.get("Kernel_Name", ""):
+                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
+    if not rows:
+        return None, None, 0
+    # one row per dispatch (a counter may be reported per dimension: sum those of one dispatch)
+    per = {}
+    for did, name, val in rows:
+        per.setdefault(did, [name, 0.0])[1] += val
+    ids = sorted(per)[-last:]
+    return per[ids[-1]][0], sum(per[i][1] for i in ids) / len(ids), len(ids)
+
+
+# gfx950 corrections of MI355X_MICROARCH.md "HBM": FETCH_SIZE (KiB) reports half of a wide coalesced streaming read
+# -> x2; WRITE_SIZE (KiB) was calibrated 1:1 on a known byte count in this access pattern (tools/hbm_probe.hip,
+# profiles/r02_summary.md, r03_summary.md)
+PMC_TO_BYTES = {"FETCH_SIZE": 1024.0 * 2.0, "WRITE_SIZE": 1024.0}
+
+
+def find_rocprofv3():
+    import shutil
+    return shutil.which("rocprofv3") or (
+        "/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+
+
+def measure_traffic(plan, launches=8, timeout_s=120.0):
+    """HBM bytes per launch of the plan this run just timed, measured IN this run: bench.py re-launches itself as a
+    small child (`--traffic-pass`: the same 64-frame 4K batch, the same kernel plan, `launches` launches, no torch)
+    under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (separate passes; they do
+    not fit one), after the timed region.  plan = (variant name, band override, store alignment).  Returns the
+    `roofline.traffic` object, or (None, reason)."""
+    import shutil
+    import tempfile
+    rocprof = find_rocprofv3()
+    if rocprof is None:
+        return None, "rocprofv3 not on PATH"
+    t_start = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="mibayer_traffic_", dir=os.environ.get("TMPDIR", "/tmp"))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                        "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    env["TMPDIR"] = tmp
+    got, kernel, used, child = {}, None, 0, None
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "t",
+                   "--", sys.executable, os.path.abspath(__file__), "--traffic-pass", "%s:%d:%d" % plan,
+                   "--traffic-launches", str(launches)]
+            left = timeout_s - (time.perf_counter() - t_start)
+            if left < 5:
+                return None, "traffic pass ran out of its %.0f s budget before the %s pass" % (timeout_s, counter)
+            try:
+                res = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=left)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s did not finish within %.0f s" % (counter, left)
+            if res.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited %d: %s" % (counter, res.returncode,
+                                                                  (res.stderr or res.stdout)[-200:].replace("\n", " "))
+            for line in res.stdout.splitlines():
+                if line.startswith("{") and "traffic_pass" in line:
+                    child = json.loads(line)
+            files = []
+            for root, _, names in os.walk(out_dir):
+                files += [os.path.join(root, n) for n in names if n.endswith("counter_collection.csv")]
+            if not files:
+                return None, "rocprofv3 --pmc %s wrote no counter_collection.csv" % counter
+            kernel, mean, used = parse_pmc_csv(files[0], counter, last=launches)
+            if mean is None:
+                return None, "no bayer2rgb dispatch in the %s pass" % counter
+            got[counter] = mean * PMC_TO_BYTES[counter]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    alg = BYTES_PER_PIXEL * WIDTH * HEIGHT * BATCH
+    read, write = got["FETCH_SIZE"], got["WRITE_SIZE"]
+    return {"read": round(read), "write": round(write), "total": round(read + write),
+            "ratio": round((read + write) / alg, 4), "read_ratio": round(read / (WIDTH * HEIGHT * BATCH), 4),
+            "write_ratio": round(write / (4 * WIDTH * HEIGHT * BATCH), 4), "unit": "bytes per launch",
+            "kernel": kernel, "launches_averaged": used, "plan": "%s/band %d/align %d" % plan,
+            "child_kernel_variant": (child or {}).get("kernel_variant"),
+            "seconds": round(time.perf_counter() - t_start, 1),
+            "method": "this run re-launched itself under rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc "
+                      "WRITE_SIZE (separate passes) after the timed region, same batch and plan; FETCH_SIZE KiB x 2 "
+                      "(gfx950 correction), WRITE_SIZE KiB x 1"}, None
+
+
+def traffic_child(args):
+    """The profiled child of measure_traffic(): the bench workload under one explicit plan, no torch, no timing claims."""
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    vname, band, align = args.traffic_pass.rsplit(":", 2)
+    names = pkg.variant_names()
+    ctxs = {o: pkg.Context(WIDTH, HEIGHT, o, FORMAT, device=0) for o in ORDERS}
+    for c in ctxs.values():
+        c.set_plan(names.index(vname), int(band), int(align))
+    ctx0 = ctxs[ORDERS[0]]
+    d_src = ctx0.device_alloc(BATCH * ctx0.src_bytes)
+    d_dst = ctx0.device_alloc(BATCH * ctx0.dst_bytes)
+    ctx0.fill_synthetic(d_src, BATCH, SEED)
+    ctx0.sync()
+    for i in range(2 + args.traffic_launches):
+        c = ctxs[ORDERS[i % 4]]
+        c.process_device(d_src, d_dst, BATCH, stream=ctx0.stream)
+    ctx0.sync()
+    print(json.dumps({"traffic_pass": args.traffic_pass, "kernel_variant": ctx0.variant_name,
+                      "launch_plan": ctx0.launch_geometry(BATCH), "launches": args.traffic_launches}), flush=True)
+    ctx0.device_free(d_src)
+    ctx0.device_free(d_dst)
+    for c in ctxs.values():
+        c.close()
+
+
 class ControlPlane:
     """Barrier and max-over-ranks for the timed region: the only communication of this bench (the data path has no
     collective).  Same small surface as the torch.distributed module, bound to one process group."""
 
-    def __init__(self, dist_mod, group, backend, device):
+    def __init__(self, dist_mod, group, backend, device, fallback_reason=None):
         self._d, self._g, self._backend, self._device = dist_mod, group, backend, device
         self.ReduceOp = dist_mod.ReduceOp
+        self.fallback_reason = fallback_reason      # RCCL was asked for and did not come up: why
+
+    def max_over_ranks(self, value):
+        """MAX of one float over the ranks, on the plane's own transport (a device tensor over RCCL)."""
+        import torch
+        t = torch.tensor([value], dtype=torch.float64, device="cuda" if self._backend == "nccl" else "cpu")
+        self.all_reduce(t, op=self.ReduceOp.MAX)
+        return float(t.item())
 
     def get_backend(self):
         return self._backend
@@ -396,7 +529,9 @@ def setup_distributed(args):
     """(world, rank, device ordinal, control plane or None).  One rank per GPU; the ranks bootstrap over gloo and
     then bring up an RCCL ("nccl") group for the barriers and the max-reduction.  If the RCCL communicator cannot be
     brought up (e.g. --share-gpu puts two ranks on one GPU) the gloo group carries them instead -- the measured
-    region does not depend on it.  --backend gloo skips RCCL."""
+    region does not depend on it, and the JSON line says so at top level (`control_plane`, `control_plane_fallback`).
+    --backend gloo skips RCCL.  --force-dist: a single rank goes through exactly the same bring-up (world size 1),
+    so the RCCL branch is exercised on a one-GPU box."""
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -408,10 +543,15 @@ def setup_distributed(args):
     device = local_rank % torch.cuda.device_count() if args.share_gpu else local_rank
     torch.cuda.set_device(device)
     plane = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("gloo")
+        if "MASTER_PORT" not in os.environ:         # --force-dist outside a launcher
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+        dist_mod.init_process_group("gloo", rank=rank, world_size=world)
         plane = ControlPlane(dist_mod, None, "gloo", device)
         if args.backend == "nccl":
             try:
@@ -422,9 +562,13 @@ def setup_distributed(args):
                 if int(probe.item()) != world:
                     raise RuntimeError("all_reduce over RCCL returned %r for %d ranks" % (probe.item(), world))
                 plane = ControlPlane(dist_mod, group, "nccl", device)
-            except Exception as exc:        # noqa: BLE001 -- any RCCL bring-up failure: keep the gloo plane
-                sys.stderr.write("bench.py rank %d: RCCL control plane unavailable (%s: %s); barriers and the "
-                                 "max-reduction run over gloo\n" % (rank, type(exc).__name__, str(exc)[:200]))
+                plane.barrier()                     # the very call of the timed region, once outside it
+                torch.cuda.synchronize()
+            except Exception as exc:        # noqa: BLE001 -- any RCCL bring-up failure: keep the gloo plane, loudly
+                why = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+                sys.stderr.write("bench.py rank %d: RCCL CONTROL PLANE UNAVAILABLE (%s); barriers and the "
+                                 "max-reduction run over gloo\n" % (rank, why))
+                plane = ControlPlane(dist_mod, None, "gloo", device, fallback_reason=why)
     return world, rank, device, plane
 
 
@@ -504,6 +648,8 @@ def run_stream(args):
                                       "compute-queue segment (wait for the upload, kernel, signal the download), "
                                       "the copies stay on the copy queues")},
             "per_gpu": per_gpu, "parity": parity,
+            "control_plane": dist.get_backend() if dist is not None else "single process",
+            "control_plane_fallback": (dist.fallback_reason if dist is not None else None),
             "mechanisms": {"streams_and_events_3_queues": round(px / el_streams / 1e6, 1),
                            "hipgraph_captured_launch": round(px / el_graph / 1e6, 1),
                            "hipgraph_whole_chain_per_slot": round(px / el_chain / 1e6, 1)},
@@ -579,7 +725,8 @@ def run(args):
         if k == args.steps - 1:
             (step_events[args.steps] if step_events is not None else ev1).record()
 
-    elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, dist)
+    tinfo = {}
+    elapsed = timed_region(step, args.steps, args.warmup, torch.cuda.synchronize, dist, tinfo)
     if step_events is not None:
         kernel_ms = step_events[0].elapsed_time(step_events[args.steps]) / args.steps
         per_step = sorted(step_events[k].elapsed_time(step_events[k + 1]) for k in range(args.steps))
@@ -589,6 +736,9 @@ def run(args):
     pixels = WIDTH * HEIGHT * BATCH
     value = aggregate_mpix_per_s(pixels, world, args.steps, elapsed)
     achieved = BYTES_PER_PIXEL * pixels / (kernel_ms * 1e-3) / 1e9
+    # what the control plane cost: the slowest rank's kernel time alone, and the slowest closing barrier
+    kernel_ms_max = dist.max_over_ranks(kernel_ms) if dist is not None else kernel_ms
+    barrier_ms = dist.max_over_ranks(tinfo.get("barrier_ms", 0.0)) if dist is not None else 0.0
     # parity AFTER the timed region (host-side oracle work and 33 MB downloads would idle the GPU before it)
     parity = parity_spot_check(pkg, ctxs, d_src, d_dst, rank, world, stream)
 
@@ -602,6 +752,13 @@ def run(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic (counter-based PRNG frames generated in HBM, seed %d)" % SEED,
         "prewarm_ms": round(prewarm_ms, 1), "prewarm_launches": prewarm_launches,
+        # the control plane of the timed region, where a fallback or a slow barrier cannot hide: what carried the
+        # barriers / max-reduction, the wall time of the closing barrier (slowest rank; it is inside `value`), and
+        # the aggregate rate from the slowest rank's HIP-event kernel time alone (no barrier, no host)
+        "control_plane": dist.get_backend() if dist is not None else "single process",
+        "control_plane_fallback": (dist.fallback_reason if dist is not None else None),
+        "barrier_ms": round(barrier_ms, 4),
+        "value_kernel_only": round(pixels * world / (kernel_ms_max * 1e-3) / 1e6, 1),
         "config": {"workload": "3840x2160 x 64 frames per GPU, bggr/rggb/grbg/gbrg -> BGRx cycled per step "
                                "(BASELINE.json configs[2]), one launch per step, frames sharded round-robin "
                                "over ranks, no collective",
@@ -623,6 +780,15 @@ def run(args):
     # the unwrapped bench line says null and carries the last profiled figure under its own name, with the
     # plan, the box and the build it was taken on (tools/summarize_profiles.py writes the file)
     result["roofline"]["traffic_profiled"] = profiled_traffic(ctx0.launch_geometry(BATCH)["band"], ctx0.variant_name)
+    if rank == 0 and world == 1 and not args.no_traffic:
+        # measured in THIS run: a profiled child of this very script, same batch, same plan, after the timed region
+        torch.cuda.synchronize()
+        vid, band, align = ctx0.get_plan()
+        traffic, why = measure_traffic((pkg.variant_names()[vid], band, align), args.traffic_launches,
+                                       args.traffic_seconds)
+        result["roofline"]["traffic"] = traffic
+        if traffic is None:
+            result["roofline"]["traffic_note"] = why
     if dist is not None:
         # per-GPU breakdown (SURVEY.md section 5 "metrics"): `roofline` above is rank 0's kernel, this is every rank's
         mine = {"rank": rank, "device": local_rank, "kernel_ms": round(kernel_ms, 4),
@@ -659,6 +825,15 @@ def main():
                     help="untimed time-based GPU pre-warm before the W warm-up steps (reported as prewarm_ms)")
     ap.add_argument("--no-step-events", action="store_true",
                     help="two HIP events around the timed region instead of one per step")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the rocprofv3 PMC pass that fills roofline.traffic (N == 1 only)")
+    ap.add_argument("--traffic-launches", type=int, default=8)
+    ap.add_argument("--traffic-seconds", type=float, default=120.0, help="budget of the whole traffic pass")
+    ap.add_argument("--traffic-pass", default=None, metavar="VARIANT:BAND:ALIGN",
+                    help="internal: the profiled child of the traffic pass")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N == 1: bring the process groups up exactly as at N > 1 (gloo bootstrap + RCCL group of "
+                         "one rank) and run the barriers / max-reduction of the timed region over them")
     ap.add_argument("--mode", choices=("batch", "stream"), default="batch",
                     help="batch = the headline device-resident metric (default); stream = configs[4] host-fed stream")
     ap.add_argument("--no-graph", action="store_true", help="stream mode: streams+events instead of hipGraph")
@@ -673,7 +848,9 @@ def main():
                "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
                "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
-    if args.mode == "stream":
+    if args.traffic_pass:
+        traffic_child(args)
+    elif args.mode == "stream":
         run_stream(args)
     else:
         run(args)

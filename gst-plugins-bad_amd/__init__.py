@@ -23,6 +23,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("MIBAYER_LIB_PATH") or os.path.join(HERE, "libmibayer.so")   # override: A/B of two builds
+LAB_LIB_PATH = os.path.join(HERE, "libmibayer_lab.so")      # `make lab`: + experiment arms and tuning environment
 PLUGIN_PATH = os.path.join(HERE, "libgstbayer.so")
 HEADER_PATH = os.path.join(ROOT, "include", "mibayer.h")
 
@@ -35,6 +36,7 @@ FORMATS = {
     "RGBA": (0, 1, 2), "ARGB": (1, 2, 3), "BGRA": (2, 1, 0), "ABGR": (3, 2, 1),
 }
 
+PLAN_DEFAULT, PLAN_MEASURED, PLAN_CACHED, PLAN_SET = 0, 1, 2, 3
 OK = 0
 ERR_ARG, ERR_GEOMETRY, ERR_LAYOUT, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_BUSY, ERR_EMPTY, ERR_TIMEOUT = (
     -1, -2, -3, -4, -5, -6, -7, -8, -9)
@@ -71,6 +73,17 @@ class Cfg(ctypes.Structure):
 MAX_SHARDS = 16
 FLAG_HIPGRAPH = 1
 FLAG_RGB2BAYER = 2
+FLAG_HIPGRAPH_CHAIN = 4
+
+
+class HostStats(ctypes.Structure):
+    """struct mibayer_host_stats (include/mibayer.h)."""
+    _fields_ = [("submits", ctypes.c_uint64), ("waits", ctypes.c_uint64), ("polls", ctypes.c_uint64),
+                ("naps", ctypes.c_uint64), ("submit_cpu_ms", ctypes.c_double), ("wait_cpu_ms", ctypes.c_double),
+                ("wait_wall_ms", ctypes.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class PoolCfg(ctypes.Structure):
@@ -86,6 +99,7 @@ _lib = None
 # every symbol include/mibayer.h declares: name -> (restype, argtypes)
 ABI = {
     "mibayer_abi_version": (ctypes.c_int, []),
+    "mibayer_is_lab_build": (ctypes.c_int, []),
     "mibayer_device_count": (ctypes.c_int, []),
     "mibayer_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "mibayer_last_hip_error": (ctypes.c_char_p, []),
@@ -98,6 +112,14 @@ ABI = {
     "mibayer_pending": (ctypes.c_int, [_vp]),
     "mibayer_set_wait_timeout": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mibayer_pool_set_wait_timeout": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mibayer_set_wait_spin": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mibayer_pool_set_wait_spin": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mibayer_get_host_stats": (ctypes.c_int, [_vp, ctypes.POINTER(HostStats)]),
+    "mibayer_pool_get_host_stats": (ctypes.c_int, [_vp, ctypes.POINTER(HostStats)]),
+    "mibayer_pool_reclaim": (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
+    "mibayer_pool_lost": (ctypes.c_int, [_vp]),
+    "mibayer_deferred_frees": (ctypes.c_int, []),
+    "mibayer_wedged_contexts": (ctypes.c_int, []),
     "mibayer_pool_inject_stall": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "mibayer_pool_create": (ctypes.c_int, [ctypes.POINTER(PoolCfg), ctypes.POINTER(_vp)]),
     "mibayer_pool_destroy": (None, [_vp]),
@@ -119,7 +141,14 @@ ABI = {
                                            ctypes.POINTER(ctypes.c_float)]),
     "mibayer_autotune": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.c_int,
                                         ctypes.c_char_p, ctypes.c_size_t]),
+    "mibayer_autotune_list": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int,
+                                             ctypes.c_char_p, ctypes.c_size_t]),
     "mibayer_copy_plan": (ctypes.c_int, [_vp, _vp]),
+    "mibayer_get_plan": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                        ctypes.POINTER(ctypes.c_int)]),
+    "mibayer_set_plan": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mibayer_plan_source": (ctypes.c_int, [_vp]),
+    "mibayer_plan_cache_clear": (None, []),
     "mibayer_host_alloc": (_vp, [ctypes.c_size_t]),
     "mibayer_host_free": (None, [_vp]),
     "mibayer_host_alloc_near": (_vp, [ctypes.c_int, ctypes.c_size_t]),
@@ -161,8 +190,8 @@ ABI = {
 
 
 def build(quiet=True):
-    """Compile libmibayer.so (hipcc, gfx950) and, when GStreamer headers exist, libgstbayer.so."""
-    subprocess.run(["make", "-C", HERE, "all"], check=True,
+    """Compile libmibayer.so (hipcc, gfx950), the lab build beside it and, when GStreamer headers exist, libgstbayer.so."""
+    subprocess.run(["make", "-C", HERE, "all", "lab"], check=True,
                    stdout=subprocess.DEVNULL if quiet else None)
 
 
@@ -179,7 +208,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.mibayer_abi_version() != 3:
+        if L.mibayer_abi_version() != 4:
             raise MibayerErrorNoLib("libmibayer.so ABI version mismatch")
         _lib = L
     return _lib
@@ -187,6 +216,15 @@ def lib():
 
 class MibayerErrorNoLib(RuntimeError):
     pass
+
+
+class FrameLost(MibayerError):
+    """mibayer_pool_wait handed a frame back as lost (MIBAYER_ERR_TIMEOUT with its tag, devices left): the frame was in
+    flight on a device that ran into the wait deadline; its buffers stay the device's until Pool.reclaim()."""
+
+    def __init__(self, tag):
+        super().__init__(ERR_TIMEOUT, "mibayer_pool_wait (frame lost)")
+        self.tag = tag
 
 
 def device_count():
@@ -234,8 +272,31 @@ class Pool:
 
     def wait(self):
         tag = _vp()
-        _check(lib().mibayer_pool_wait(self._h, ctypes.byref(tag)), "mibayer_pool_wait")
+        rc = lib().mibayer_pool_wait(self._h, ctypes.byref(tag))
+        if rc == ERR_TIMEOUT and tag.value and self.alive() > 0:
+            raise FrameLost(tag.value)
+        _check(rc, "mibayer_pool_wait")
         return tag.value or 0
+
+    def reclaim(self):
+        """Tags of lost frames whose device has let go of their buffers since (non-blocking)."""
+        out = []
+        while True:
+            tag = _vp()
+            if lib().mibayer_pool_reclaim(self._h, ctypes.byref(tag)) != OK:
+                return out
+            out.append(tag.value or 0)
+
+    def lost(self):
+        return lib().mibayer_pool_lost(self._h)
+
+    def set_wait_spin(self, us):
+        _check(lib().mibayer_pool_set_wait_spin(self._h, us), "mibayer_pool_set_wait_spin")
+
+    def host_stats(self):
+        st = HostStats()
+        _check(lib().mibayer_pool_get_host_stats(self._h, ctypes.byref(st)), "mibayer_pool_get_host_stats")
+        return st.as_dict()
 
     def pending(self):
         return lib().mibayer_pool_pending(self._h)
@@ -341,6 +402,14 @@ class Context:
     def set_wait_timeout(self, ms):
         _check(lib().mibayer_set_wait_timeout(self._h, ms), "mibayer_set_wait_timeout")
 
+    def set_wait_spin(self, us):
+        _check(lib().mibayer_set_wait_spin(self._h, us), "mibayer_set_wait_spin")
+
+    def host_stats(self):
+        st = HostStats()
+        _check(lib().mibayer_get_host_stats(self._h, ctypes.byref(st)), "mibayer_get_host_stats")
+        return st.as_dict()
+
     def stall(self, ms):
         """Drill (csrc/mibayer_hooks.h): occupy the context's compute queue for `ms` milliseconds."""
         fn = lib().mibayer_internal_stall
@@ -408,6 +477,29 @@ class Context:
             dst_frame_bytes or self.dst_bytes, nframes, buf, len(buf)), "mibayer_autotune")
         self.variant_name = lib().mibayer_ctx_variant_name(self._h).decode()
         return buf.value.decode()
+
+    def autotune_list(self, d_srcs, d_dsts):
+        """mibayer_autotune_list over separately allocated frames; returns the one-line report."""
+        n = len(d_srcs)
+        a, b = (_vp * n)(*d_srcs), (_vp * n)(*d_dsts)
+        buf = ctypes.create_string_buffer(1024)
+        _check(lib().mibayer_autotune_list(self._h, a, b, n, buf, len(buf)), "mibayer_autotune_list")
+        self.variant_name = lib().mibayer_ctx_variant_name(self._h).decode()
+        return buf.value.decode()
+
+    def get_plan(self):
+        """(variant id, band override, store alignment)"""
+        v, b, a = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(lib().mibayer_get_plan(self._h, ctypes.byref(v), ctypes.byref(b), ctypes.byref(a)), "mibayer_get_plan")
+        return v.value, b.value, a.value
+
+    def set_plan(self, variant, band, align=0):
+        _check(lib().mibayer_set_plan(self._h, variant, band, align), "mibayer_set_plan")
+        self.variant_name = lib().mibayer_ctx_variant_name(self._h).decode()
+
+    @property
+    def plan_source(self):
+        return lib().mibayer_plan_source(self._h)
 
     def copy_plan_from(self, other):
         _check(lib().mibayer_copy_plan(self._h, other._h), "mibayer_copy_plan")

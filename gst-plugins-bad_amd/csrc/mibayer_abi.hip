@@ -29,6 +29,15 @@
 
 using namespace mibayer;
 
+/* Tuning / experiment knobs exist in the lab build only (`make lab`, -DMIBAYER_LAB: tools/, the sweep tests): the
+ * product library reads MIBAYER_ROCTX, MIBAYER_WAIT_TIMEOUT_MS, MIBAYER_WAIT_SPIN_US, MIBAYER_PLAN_CACHE and the
+ * pool's operational variables, nothing else. */
+#ifdef MIBAYER_LAB
+#define LAB_GETENV(name) getenv (name)
+#else
+#define LAB_GETENV(name) ((const char *) nullptr)
+#endif
+
 namespace {
 
 thread_local char t_hip_error[256] = "";
@@ -190,9 +199,11 @@ static DeviceQueues g_queues[64];
  * emptied when the last context of the device goes.  Guarded by g_queues_mu. */
 struct BufCache {
   std::vector<std::pair<void *, size_t>> bufs;
+  size_t bytes = 0;
   int contexts = 0;
 };
 constexpr size_t kCacheMax = 16;
+constexpr size_t kCacheMaxBytes = (size_t) 1 << 30;     /* per device */
 static BufCache g_cache[64];
 
 static hipError_t cached_malloc (int dev, void **p, size_t bytes)
@@ -204,6 +215,7 @@ static hipError_t cached_malloc (int dev, void **p, size_t bytes)
       if (v[i].second == bytes) {
         *p = v[i].first;
         v.erase (v.begin () + (long) i);
+        g_cache[dev].bytes -= bytes;
         return hipSuccess;
       }
   }
@@ -216,8 +228,9 @@ static void cached_free (int dev, void *p, size_t bytes)
     return;
   if (dev >= 0 && dev < 64) {
     std::lock_guard<std::mutex> lk (g_queues_mu);
-    if (g_cache[dev].bufs.size () < kCacheMax) {
+    if (g_cache[dev].bufs.size () < kCacheMax && g_cache[dev].bytes + bytes <= kCacheMaxBytes) {
       g_cache[dev].bufs.emplace_back (p, bytes);
+      g_cache[dev].bytes += bytes;
       return;
     }
   }
@@ -227,11 +240,13 @@ static void cached_free (int dev, void *p, size_t bytes)
 static bool shared_queues_enabled ()
 {
   static const bool on = [] {
-    const char *e = getenv ("MIBAYER_SHARED_QUEUES");
+    const char *e = LAB_GETENV ("MIBAYER_SHARED_QUEUES");
     return !(e && e[0] == '0');
   } ();
   return on;
 }
+
+struct Wedge;
 
 struct mibayer_ctx {
   mibayer_cfg cfg;
@@ -255,6 +270,8 @@ struct mibayer_ctx {
                                            wins; MIBAYER_ALIGN_STORES = 0 | 64 | 128 forces it (-1 in the
                                            environment keeps it out of the autotuner's candidates) */
   bool align_tunable = true;
+  bool band_forced = false;             /* the block order was pinned from outside (lab builds: MIBAYER_XCD_BAND) */
+  int plan_source = MIBAYER_PLAN_DEFAULT;  /* where var / band_override / align_stores came from (mibayer_plan_source) */
   int graph_mode = 0;                   /* MIBAYER_FLAG_HIPGRAPH: 0 = the compute-queue segment of a frame as
                                            a graph per slot (default), 1 = the whole upload -> kernel ->
                                            download chain as a graph per slot on the slot's own queue
@@ -279,8 +296,15 @@ struct mibayer_ctx {
    * a GPU that has stopped answering returns nothing, so an unbounded hipEventSynchronize would hang the streaming
    * thread for good.  0 = wait for ever.  MIBAYER_WAIT_TIMEOUT_MS / mibayer_set_wait_timeout(). */
   int wait_timeout_ms = 10000;
-  bool wedged = false;                  /* a wait ran into the deadline: nothing of this context is waited for again,
-                                           and its device-side resources are left alone (freeing would block) */
+  /* How long a host-side wait may spin on hipEventQuery before it starts to nap, in microseconds; -1 = automatic:
+   * up to kAutoSpinUs when the frame waited for is the only one in flight (the synchronous 1-in/1-out use: the caller
+   * can do nothing until it completes, and a nap's wake-up latency comes straight off the frame rate), none when
+   * other frames are queued behind it (their copies and kernels keep the device busy while this thread sleeps).
+   * MIBAYER_WAIT_SPIN_US / mibayer_set_wait_spin(). */
+  int wait_spin_us = -1;
+  mibayer_host_stats stats = {};        /* host CPU spent in submits and waits (mibayer_get_host_stats) */
+  bool wedged = false;                  /* a wait ran into the deadline: nothing of this context is waited for again */
+  Wedge *wedge = nullptr;               /* ... and this tells when the device has caught up with it (registry above) */
   bool counted = false;                 /* in g_cache[device].contexts */
   bool dirty_compute = false;           /* device-resident work was queued on s_compute through this context since
                                            the last mibayer_sync */
@@ -294,10 +318,96 @@ struct mibayer_ctx {
 
 /* ---- bounded waits ---------------------------------------------------------- */
 
-/* Set once a wait has run into its deadline: from then on this process does not return pinned blocks to the runtime
- * (mibayer_host_free) -- hipHostFree drains the device first, i.e. it would sit behind the very GPU that stopped
- * answering, at the moment a pipeline is shutting down because of it.  The blocks stay allocated until exit. */
-static std::atomic<int> g_device_wedged { 0 };
+/* A context whose wait ran into its deadline ("wedged").  The device may only be slow -- the stall drill ends by
+ * itself, a neighbour's long kernel ends, a reset completes -- so the state is neither global nor permanent: when the
+ * deadline hits, a fence is recorded behind everything the context had queued; once those fences have fired the device
+ * has caught up with the context ("settled").  Until then
+ *   - the buffers of its in-flight frames belong to the device (mibayer_internal_settled, mibayer_pool_reclaim),
+ *   - nothing of it is waited for or released by a call that could block behind the device: a context destroyed
+ *     meanwhile leaves its device frames, events and queues to the registry, which releases them when the fences fire,
+ *   - pinned blocks handed to mibayer_host_free go on a deferred list instead of hipHostFree (which waits for the
+ *     devices to drain) and are freed when no wedge is outstanding any more.
+ * The registry is polled -- hipEventQuery, never a blocking call -- from mibayer_host_free, mibayer_create,
+ * mibayer_destroy and mibayer_internal_settled. */
+struct Wedge {
+  int device = 0;
+  std::vector<hipEvent_t> fences;       /* behind everything the context had queued when the deadline hit */
+  bool settled = false;
+  bool orphan = false;                  /* its context has been destroyed: the registry owns what follows */
+  std::vector<void *> dev_mem;
+  std::vector<hipEvent_t> events;
+  std::vector<hipStream_t> streams;
+  std::vector<hipGraphExec_t> execs;
+  std::vector<hipGraph_t> graphs;
+};
+
+static std::mutex g_wedge_mu;
+static std::vector<Wedge *> g_wedges;
+static std::vector<void *> g_deferred_host;     /* pinned blocks whose hipHostFree is waiting for the wedges to settle */
+static std::atomic<int> g_wedges_open { 0 };    /* unsettled wedges: the fast path of mibayer_host_free */
+
+static void release_wedge_resources (Wedge *w)
+{
+  for (hipGraphExec_t e : w->execs)
+    (void) hipGraphExecDestroy (e);
+  for (hipGraph_t g : w->graphs)
+    (void) hipGraphDestroy (g);
+  for (hipEvent_t e : w->events)
+    (void) hipEventDestroy (e);
+  for (hipStream_t st : w->streams)
+    (void) hipStreamDestroy (st);
+  for (void *m : w->dev_mem)
+    (void) hipFree (m);
+  for (hipEvent_t e : w->fences)
+    (void) hipEventDestroy (e);
+  (void) hipGetLastError ();
+}
+
+/* g_wedge_mu held.  Non-blocking: one hipEventQuery per outstanding fence. */
+static void poll_wedges_locked ()
+{
+  for (size_t i = 0; i < g_wedges.size ();) {
+    Wedge *w = g_wedges[i];
+    if (!w->settled) {
+      int prev = -1;
+      (void) hipGetDevice (&prev);
+      if (prev != w->device)
+        (void) hipSetDevice (w->device);
+      bool done = true;
+      for (hipEvent_t e : w->fences)
+        if (hipEventQuery (e) == hipErrorNotReady)    /* an error state ends the wait too: the queue is dead */
+          done = false;
+      (void) hipGetLastError ();
+      if (done) {
+        w->settled = true;
+        g_wedges_open.fetch_sub (1);
+        if (w->orphan)
+          release_wedge_resources (w);
+      }
+      if (prev >= 0 && prev != w->device)
+        (void) hipSetDevice (prev);
+    }
+    if (w->settled && w->orphan) {
+      delete w;
+      g_wedges.erase (g_wedges.begin () + (long) i);
+      continue;
+    }
+    i++;
+  }
+  if (g_wedges_open.load () == 0 && !g_deferred_host.empty ()) {
+    for (void *p : g_deferred_host)
+      (void) hipHostFree (p);
+    g_deferred_host.clear ();
+  }
+}
+
+static void poll_wedges ()
+{
+  if (g_wedges_open.load () == 0 && g_deferred_host.empty ())
+    return;
+  std::lock_guard<std::mutex> lk (g_wedge_mu);
+  poll_wedges_locked ();
+}
 
 static double now_ms ()
 {
@@ -306,38 +416,107 @@ static double now_ms ()
   return (double) t.tv_sec * 1e3 + (double) t.tv_nsec * 1e-6;
 }
 
-/* Host wait for an event, bounded by the context's deadline: the event is polled (a tight loop for the first two
- * milliseconds -- a frame takes about one -- then in 50 us naps).  MIBAYER_ERR_TIMEOUT marks the context wedged.
- * Reference analogue of a bounded wait on a stream that may stall: gst/debugutils/gstwatchdog.c:21-123. */
-static int wait_event (mibayer_ctx *c, hipEvent_t ev)
+/* the wait deadline has hit: fences behind everything the context has queued (recording never blocks) */
+static void on_deadline (mibayer_ctx *c)
+{
+  c->wedged = true;
+  if (c->wedge)
+    return;
+  Wedge *w = new (std::nothrow) Wedge ();
+  if (!w)
+    return;
+  w->device = c->device;
+  std::vector<hipStream_t> queues = { c->s_h2d, c->s_compute, c->s_d2h };
+  for (Slot &sl : c->ring)
+    if (sl.s_graph)
+      queues.push_back (sl.s_graph);
+  for (hipStream_t q : queues) {
+    hipEvent_t ev = nullptr;
+    if (!q || hipEventCreateWithFlags (&ev, hipEventDisableTiming) != hipSuccess)
+      continue;
+    if (hipEventRecord (ev, q) != hipSuccess) {
+      (void) hipEventDestroy (ev);
+      continue;
+    }
+    w->fences.push_back (ev);
+  }
+  (void) hipGetLastError ();
+  c->wedge = w;
+  std::lock_guard<std::mutex> lk (g_wedge_mu);
+  g_wedges.push_back (w);
+  g_wedges_open.fetch_add (1);
+}
+
+/* has the device caught up with a context that ran into a deadline?  (true for one that never did) */
+static bool ctx_settled (mibayer_ctx *c)
+{
+  if (!c->wedged)
+    return true;
+  if (!c->wedge)
+    return false;
+  std::lock_guard<std::mutex> lk (g_wedge_mu);
+  poll_wedges_locked ();
+  return c->wedge->settled;
+}
+
+static double thread_cpu_ms ()
+{
+  timespec t;
+  clock_gettime (CLOCK_THREAD_CPUTIME_ID, &t);
+  return (double) t.tv_sec * 1e3 + (double) t.tv_nsec * 1e-6;
+}
+
+/* adds the calling thread's CPU time between construction and destruction to one of the context's counters */
+struct CpuMeter {
+  double *sink;
+  double t0;
+  explicit CpuMeter (double *s) : sink (s), t0 (thread_cpu_ms ()) {}
+  ~CpuMeter () { *sink += thread_cpu_ms () - t0; }
+};
+
+constexpr int kAutoSpinUs = 2000;       /* a 4K frame through the host path takes 0.6-0.8 ms */
+
+/* Host wait for an event, bounded by the context's deadline (0 = none).  The event is polled: a tight loop for the
+ * spin window (see mibayer_ctx::wait_spin_us; `alone` = nothing else of this context is queued behind what is waited
+ * for), then naps that double from 20 us to 250 us -- a thread that waits for a frame while the next ones are already
+ * queued costs a few wake-ups per frame instead of a core (profiles/r04_host_cpu.log).  MIBAYER_ERR_TIMEOUT marks the
+ * context wedged.  Reference analogue of a bounded wait on a stream that may stall:
+ * gst/debugutils/gstwatchdog.c:21-123. */
+static int wait_event (mibayer_ctx *c, hipEvent_t ev, bool alone)
 {
   if (c->wedged)
     return MIBAYER_ERR_TIMEOUT;
-  if (c->wait_timeout_ms <= 0) {
-    HIP_TRY (hipEventSynchronize (ev));
-    return MIBAYER_OK;
-  }
+  c->stats.waits++;
+  CpuMeter cpu (&c->stats.wait_cpu_ms);
+  const double spin_ms = (c->wait_spin_us >= 0 ? c->wait_spin_us : (alone ? kAutoSpinUs : 0)) * 1e-3;
   const double t0 = now_ms ();
+  long nap_ns = 20000;
   for (;;) {
     const hipError_t e = hipEventQuery (ev);
-    if (e == hipSuccess)
+    c->stats.polls++;
+    if (e == hipSuccess) {
+      c->stats.wait_wall_ms += now_ms () - t0;
       return MIBAYER_OK;
+    }
     if (e != hipErrorNotReady) {
       (void) hip_failed (e, "hipEventQuery");
       return MIBAYER_ERR_HIP;
     }
     (void) hipGetLastError ();
     const double dt = now_ms () - t0;
-    if (dt >= (double) c->wait_timeout_ms) {
-      c->wedged = true;
-      g_device_wedged.store (1);
+    if (c->wait_timeout_ms > 0 && dt >= (double) c->wait_timeout_ms) {
+      on_deadline (c);
+      c->stats.wait_wall_ms += dt;
       snprintf (t_hip_error, sizeof t_hip_error,
           "HIP device %d did not complete a frame within %d ms", c->device, c->wait_timeout_ms);
       return MIBAYER_ERR_TIMEOUT;
     }
-    if (dt > 2.0) {
-      const timespec nap = { 0, 50000 };
+    if (dt >= spin_ms) {
+      const timespec nap = { 0, nap_ns };
       nanosleep (&nap, NULL);
+      c->stats.naps++;
+      if (nap_ns < 250000)
+        nap_ns *= 2;
     }
   }
 }
@@ -355,7 +534,7 @@ static void fence_queues (mibayer_ctx *c)
       (void) hipGetLastError ();
       continue;
     }
-    if (wait_event (c, c->ev_fence) == MIBAYER_ERR_TIMEOUT)
+    if (wait_event (c, c->ev_fence, true) == MIBAYER_ERR_TIMEOUT)
       return;
   }
 }
@@ -368,7 +547,7 @@ static int wait_own_frames (mibayer_ctx *c)
   if (!c->ring.empty ()) {
     const int n = (int) c->ring.size ();
     for (int i = 0; i < c->pending && rc == MIBAYER_OK; i++)
-      rc = wait_event (c, c->ring[(size_t) ((c->tail + i) % n)].ev_out);
+      rc = wait_event (c, c->ring[(size_t) ((c->tail + i) % n)].ev_out, false);
   }
   return rc;
 }
@@ -510,7 +689,7 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
   /* pointers_aligned16 >= 0: a list launch, whose caller has looked at every
    * frame pointer itself (frame strides do not apply): 1 = all 16-byte aligned,
    * 2 = every destination 8-byte aligned, 0 = neither */
-  static const bool force_generic = getenv ("MIBAYER_FORCE_GENERIC") != NULL;   /* A/B: tools/sweep2.py */
+  static const bool force_generic = LAB_GETENV ("MIBAYER_FORCE_GENERIC") != NULL;   /* A/B: tools/sweep2.py */
   const bool fast = !force_generic && (f.width % 16 == 0) && (f.src_stride % 16 == 0)
       && (f.dst_stride % 16 == 0)
       && (pointers_aligned16 >= 0 ? pointers_aligned16 == 1
@@ -518,7 +697,7 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
               && (nframes == 1 || (src_frame_bytes % 16 == 0
                       && dst_frame_bytes % 16 == 0))));
   kern = fast ? c->var->fast : c->var->generic;
-  if (!fast && c->align_stores && c->var->aligned64) {
+  if (!fast && c->align_stores && (c->align_stores == 128 ? c->var->aligned128 : c->var->aligned64)) {
     /* output rows off the sector grid, all of them 8-byte aligned (even per-row shifts): the sector-aligned arm */
     const bool rows8 = (f.dst_stride % 8 == 0)
         && (pointers_aligned16 >= 0 ? pointers_aligned16 >= 1
@@ -527,7 +706,7 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
     const bool on_grid = (f.dst_stride % a == 0)
         && (pointers_aligned16 >= 0 ? false
             : ((((uintptr_t) d_dst) & (a - 1)) == 0 && (nframes == 1 || dst_frame_bytes % a == 0)));
-    static const bool force_arm = getenv ("MIBAYER_FORCE_ALIGNED_ARM") != NULL;     /* A/B: tools/sweep2.py */
+    static const bool force_arm = LAB_GETENV ("MIBAYER_FORCE_ALIGNED_ARM") != NULL;     /* A/B: tools/sweep2.py */
     if (rows8 && (!on_grid || force_arm))
       kern = c->align_stores == 128 ? c->var->aligned128 : c->var->aligned64;
   }
@@ -642,6 +821,15 @@ extern "C" int mibayer_abi_version (void)
   return MIBAYER_ABI_VERSION;
 }
 
+extern "C" int mibayer_is_lab_build (void)
+{
+#ifdef MIBAYER_LAB
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 extern "C" int mibayer_device_count (void)
 {
   return device_count_cached ();
@@ -707,7 +895,9 @@ static int validate (const mibayer_cfg *in, mibayer_cfg *out)
   mibayer_cfg f = *in;
   if (f.pattern < MIBAYER_BGGR || f.pattern > MIBAYER_RGGB)
     return MIBAYER_ERR_ARG;
-  if (f.flags & ~(uint32_t) (MIBAYER_FLAG_HIPGRAPH | MIBAYER_FLAG_RGB2BAYER))
+  if (f.flags & ~(uint32_t) (MIBAYER_FLAG_HIPGRAPH | MIBAYER_FLAG_RGB2BAYER | MIBAYER_FLAG_HIPGRAPH_CHAIN))
+    return MIBAYER_ERR_ARG;
+  if ((f.flags & MIBAYER_FLAG_HIPGRAPH_CHAIN) && !(f.flags & MIBAYER_FLAG_HIPGRAPH))
     return MIBAYER_ERR_ARG;
   if (f.flags & MIBAYER_FLAG_RGB2BAYER) {
     /* inverse direction: src = 4 B/pixel, dst = mosaic.  The reference loop
@@ -760,6 +950,7 @@ static int validate (const mibayer_cfg *in, mibayer_cfg *out)
 }
 
 static int choose_host_bands (const mibayer_ctx *c);
+static bool plan_cache_load (mibayer_ctx *c);
 extern "C" void mibayer_internal_private_queues (mibayer_ctx *c);
 
 extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
@@ -783,6 +974,7 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
     return MIBAYER_ERR_NO_DEVICE;
   f.device = dev;
 
+  poll_wedges ();
   mibayer_ctx *c = new (std::nothrow) mibayer_ctx ();
   if (!c)
     return MIBAYER_ERR_NOMEM;
@@ -810,28 +1002,35 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
       c->band_override = -1;
     }
   }
-  if (const char *e = getenv ("MIBAYER_XCD_BAND"))
+  /* a plan measured earlier in this process for this geometry on this device (mibayer_autotune) replaces the default */
+  (void) plan_cache_load (c);
+  if (const char *e = LAB_GETENV ("MIBAYER_XCD_BAND")) {
     c->band_override = atoi (e);
-  if (const char *e = getenv ("MIBAYER_START_SLEEP"))
+    c->band_forced = true;
+  }
+  if (const char *e = LAB_GETENV ("MIBAYER_START_SLEEP"))
     c->start_sleep = atoi (e) >= 0 ? atoi (e) : -1;
-  if (const char *e = getenv ("MIBAYER_ALIGN_STORES")) {
+  if (const char *e = LAB_GETENV ("MIBAYER_ALIGN_STORES")) {
     const int a = atoi (e);
     c->align_stores = (a == 64 || a == 128) ? a : 0;
     c->align_tunable = false;
   }
-  if (const char *e = getenv ("MIBAYER_R2B_FLAT"))
+  if (const char *e = LAB_GETENV ("MIBAYER_R2B_FLAT"))
     c->r2b_flat_k = atoi (e);
-  if (const char *e = getenv ("MIBAYER_R2B_PX"))
+  if (const char *e = LAB_GETENV ("MIBAYER_R2B_PX"))
     c->r2b_flat_px = atoi (e);
-  if (const char *e = getenv ("MIBAYER_R2B_LDNT"))
+  if (const char *e = LAB_GETENV ("MIBAYER_R2B_LDNT"))
     c->r2b_flat_ld = atoi (e);
-  if (const char *e = getenv ("MIBAYER_R2B_ROWS"))
+  if (const char *e = LAB_GETENV ("MIBAYER_R2B_ROWS"))
     c->r2b_rows = atoi (e);
   if (const char *e = getenv ("MIBAYER_WAIT_TIMEOUT_MS"))
     c->wait_timeout_ms = atoi (e) > 0 ? atoi (e) : 0;
-  if (const char *e = getenv ("MIBAYER_GRAPH_MODE"))
+  if (const char *e = getenv ("MIBAYER_WAIT_SPIN_US"))
+    c->wait_spin_us = atoi (e) >= 0 ? atoi (e) : -1;
+  c->graph_mode = (f.flags & MIBAYER_FLAG_HIPGRAPH_CHAIN) ? 1 : 0;
+  if (const char *e = LAB_GETENV ("MIBAYER_GRAPH_MODE"))
     c->graph_mode = (strcmp (e, "chain") == 0 || strcmp (e, "1") == 0) ? 1 : 0;
-  if (const char *e = getenv ("MIBAYER_PERSIST_WGS"))
+  if (const char *e = LAB_GETENV ("MIBAYER_PERSIST_WGS"))
     c->persist_wgs_per_cu = atoi (e) > 0 ? atoi (e) : 4;
   {
     int cus = 0;
@@ -902,10 +1101,48 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   return MIBAYER_OK;
 }
 
-static void free_slot (mibayer_ctx *c, Slot &s)
+/* how a slot's resources go: into the per-device frame cache (everything queued on them is known to have completed),
+ * straight back to the runtime (hipFree waits for the device: used when a wait of the context's own frames ended in
+ * a device error, so that nothing in flight can outlive the buffers), or to the wedge registry (the device has not
+ * answered: nothing may block behind it) */
+enum SlotRelease { RELEASE_CACHE, RELEASE_FREE, RELEASE_ORPHAN };
+
+static void free_slot (mibayer_ctx *c, Slot &s, SlotRelease how = RELEASE_CACHE)
 {
-  cached_free (c->device, s.d_src, c->src_bytes);
-  cached_free (c->device, s.d_dst, c->dst_bytes);
+  if (how == RELEASE_ORPHAN) {
+    Wedge *w = c->wedge;
+    for (void *m : { (void *) s.d_src, (void *) s.d_dst })
+      if (m)
+        w->dev_mem.push_back (m);
+    for (hipEvent_t ev : { s.ev_in, s.ev_kernel, s.ev_out })
+      if (ev)
+        w->events.push_back (ev);
+    for (int b = 0; b < kMaxHostBands; b++) {
+      if (s.ev_band_in[b])
+        w->events.push_back (s.ev_band_in[b]);
+      if (s.ev_band_kernel[b])
+        w->events.push_back (s.ev_band_kernel[b]);
+    }
+    for (hipGraphExec_t e : { s.cexec, s.exec })
+      if (e)
+        w->execs.push_back (e);
+    for (hipGraph_t g : { s.cgraph, s.graph })
+      if (g)
+        w->graphs.push_back (g);
+    if (s.s_graph)
+      w->streams.push_back (s.s_graph);
+    s = Slot ();
+    return;
+  }
+  if (how == RELEASE_FREE) {
+    if (s.d_src)
+      (void) hipFree (s.d_src);
+    if (s.d_dst)
+      (void) hipFree (s.d_dst);
+  } else {
+    cached_free (c->device, s.d_src, c->src_bytes);
+    cached_free (c->device, s.d_dst, c->dst_bytes);
+  }
   if (s.ev_in)
     (void) hipEventDestroy (s.ev_in);
   if (s.ev_kernel)
@@ -931,30 +1168,45 @@ static void free_slot (mibayer_ctx *c, Slot &s)
   s = Slot ();
 }
 
-static void free_ring (mibayer_ctx *c)
+static void free_ring (mibayer_ctx *c, SlotRelease how = RELEASE_CACHE)
 {
   for (Slot &s : c->ring)
-    free_slot (c, s);
+    free_slot (c, s, how);
   c->ring.clear ();
 }
 
 /* Waits for the context's OWN frames (their download events), never for the queues it may share with the other
  * contexts of the device, and hands its device frames to the per-device cache instead of hipFree (which drains the
- * whole device).  A wedged context (a wait ran into its deadline) waits for nothing and leaves its device-side
- * resources alone: every HIP call that releases them could block on the dead device. */
+ * whole device).  If that wait ends in a device error the frames go straight back to the runtime instead (nothing in
+ * flight may outlive them in the cache).  A context that ran into a wait deadline and whose device has not caught up
+ * since waits for nothing and releases nothing itself: its device-side resources go to the wedge registry. */
 extern "C" void mibayer_destroy (mibayer_ctx *c)
 {
   if (!c)
     return;
   DeviceGuard guard (c->device);
-  (void) wait_own_frames (c);           /* returns at once for a wedged context; may be what finds it wedged */
-  const bool leak = c->wedged;
-  if (!leak) {
-    free_ring (c);
-    free_slot (c, c->spare);
-    for (hipEvent_t ev : { c->ev_t0, c->ev_t1, c->ev_fence })
-      if (ev)
-        (void) hipEventDestroy (ev);
+  const int wrc = wait_own_frames (c);          /* returns at once for a wedged context; may be what finds it wedged */
+  SlotRelease how = RELEASE_CACHE;
+  if (c->wedged) {
+    how = ctx_settled (c) ? RELEASE_FREE : RELEASE_ORPHAN;
+    if (how == RELEASE_ORPHAN && !c->wedge)     /* no registry entry could be made: leave everything alone */
+      how = RELEASE_CACHE;
+  } else if (wrc != MIBAYER_OK) {
+    fence_queues (c);
+    how = c->wedged ? (c->wedge ? RELEASE_ORPHAN : RELEASE_CACHE) : RELEASE_FREE;
+  }
+  const bool leak = c->wedged && how != RELEASE_FREE;          /* nothing of the runtime is called on its behalf */
+  if (!(leak && how == RELEASE_CACHE)) {
+    free_ring (c, how);
+    free_slot (c, c->spare, how);
+  }
+  for (hipEvent_t ev : { c->ev_t0, c->ev_t1, c->ev_fence }) {
+    if (!ev)
+      continue;
+    if (how == RELEASE_ORPHAN)
+      c->wedge->events.push_back (ev);
+    else if (!leak)
+      (void) hipEventDestroy (ev);
   }
   std::vector<std::pair<void *, size_t>> trim;
   {
@@ -962,25 +1214,47 @@ extern "C" void mibayer_destroy (mibayer_ctx *c)
     if (c->shared_queues) {
       DeviceQueues &q = g_queues[c->device];
       if (--q.refs == 0) {
-        if (!leak) {
-          (void) hipStreamDestroy (q.h2d);
-          (void) hipStreamDestroy (q.compute);
-          (void) hipStreamDestroy (q.d2h);
+        for (hipStream_t st : { q.h2d, q.compute, q.d2h }) {
+          if (how == RELEASE_ORPHAN)
+            c->wedge->streams.push_back (st);
+          else if (!leak)
+            (void) hipStreamDestroy (st);
         }
         q = DeviceQueues ();
       }
     }
-    if (c->device < 64 && c->counted && --g_cache[c->device].contexts == 0 && !leak)
+    if (c->device < 64 && c->counted && --g_cache[c->device].contexts == 0 && !leak) {
       trim.swap (g_cache[c->device].bufs);
+      g_cache[c->device].bytes = 0;
+    }
   }
-  if (!c->shared_queues && !leak) {
-    for (hipStream_t st : { c->s_h2d, c->s_compute, c->s_d2h })
-      if (st)
+  if (!c->shared_queues) {
+    for (hipStream_t st : { c->s_h2d, c->s_compute, c->s_d2h }) {
+      if (!st)
+        continue;
+      if (how == RELEASE_ORPHAN)
+        c->wedge->streams.push_back (st);
+      else if (!leak)
         (void) hipStreamDestroy (st);
+    }
   }
   for (auto &b : trim)          /* the last context of the device: nothing of ours is queued there any more */
     (void) hipFree (b.first);
+  if (c->wedge) {
+    std::lock_guard<std::mutex> lk (g_wedge_mu);
+    if (c->wedge->settled) {
+      for (size_t i = 0; i < g_wedges.size (); i++)
+        if (g_wedges[i] == c->wedge)
+          g_wedges.erase (g_wedges.begin () + (long) i);
+      for (hipEvent_t e : c->wedge->fences)
+        (void) hipEventDestroy (e);
+      delete c->wedge;
+    } else {
+      c->wedge->orphan = true;  /* the registry releases what was handed over once the fences fire */
+    }
+  }
   delete c;
+  poll_wedges ();
 }
 
 extern "C" int mibayer_plan_selectors (const mibayer_cfg *cfg, uint32_t sel[4],
@@ -1174,7 +1448,7 @@ static int graph_submit (mibayer_ctx *c, Slot &s, const uint8_t *src,
 static int choose_host_bands (const mibayer_ctx *c)
 {
   int want = 4;
-  if (const char *e = getenv ("MIBAYER_HOST_BANDS"))
+  if (const char *e = LAB_GETENV ("MIBAYER_HOST_BANDS"))
     want = atoi (e);
   if (want > kMaxHostBands)
     want = kMaxHostBands;
@@ -1423,7 +1697,7 @@ static int wait_locked (mibayer_ctx *c, void **tag)
   Slot &s = c->ring[(size_t) c->tail];
   {
     Range r ("mibayer:wait");
-    const int rc = wait_event (c, s.ev_out);
+    const int rc = wait_event (c, s.ev_out, c->pending == 1);
     if (rc != MIBAYER_OK)
       return rc;                /* the frame stays where it is: its buffers are still the device's */
   }
@@ -1442,6 +1716,8 @@ extern "C" int mibayer_submit (mibayer_ctx *c, const uint8_t *src,
   DeviceGuard guard (c->device);
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
+  c->stats.submits++;
+  CpuMeter cpu (&c->stats.submit_cpu_ms);
   /* a ring of one frame is the synchronous 1-in/1-out use */
   return submit_locked (c, src, dst, tag, c->cfg.inflight == 1);
 }
@@ -1471,7 +1747,12 @@ extern "C" int mibayer_process_host (mibayer_ctx *c, const uint8_t *src,
   DeviceGuard guard (c->device);
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
-  int rc = submit_locked (c, src, dst, NULL, true);
+  int rc;
+  {
+    c->stats.submits++;
+    CpuMeter cpu (&c->stats.submit_cpu_ms);
+    rc = submit_locked (c, src, dst, NULL, true);
+  }
   if (rc != MIBAYER_OK)
     return rc;
   return wait_locked (c, NULL);
@@ -1504,7 +1785,7 @@ extern "C" int mibayer_internal_run_spare (mibayer_ctx *c, const uint8_t *src,
     return rc;
   }
   Range r ("mibayer:wait");
-  return wait_event (c, c->spare.ev_out);
+  return wait_event (c, c->spare.ev_out, true);
 }
 
 extern "C" int mibayer_internal_is_pageable (const void *p)
@@ -1571,14 +1852,25 @@ extern "C" int mibayer_host_is_pinned (const void *p)
   return attr.type == hipMemoryTypeHost ? 1 : 0;
 }
 
-extern "C" void mibayer_internal_abandon (mibayer_ctx *c)
+extern "C" int mibayer_internal_abandon (mibayer_ctx *c)
 {
-  if (!c || c->wedged)
-    return;                     /* a device that does not answer is not waited for again */
+  if (!c)
+    return MIBAYER_OK;
+  if (c->wedged)                /* a device that does not answer is not waited for again */
+    return ctx_settled (c) ? MIBAYER_OK : MIBAYER_ERR_TIMEOUT;
   DeviceGuard guard (c->device);
   (void) wait_own_frames (c);
   fence_queues (c);
   (void) hipGetLastError ();
+  return c->wedged ? MIBAYER_ERR_TIMEOUT : MIBAYER_OK;
+}
+
+extern "C" int mibayer_internal_settled (mibayer_ctx *c)
+{
+  if (!c)
+    return 1;
+  DeviceGuard guard (c->device);
+  return ctx_settled (c) ? 1 : 0;
 }
 
 extern "C" int mibayer_internal_stall (mibayer_ctx *c, int ms)
@@ -1589,6 +1881,22 @@ extern "C" int mibayer_internal_stall (mibayer_ctx *c, int ms)
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
   HIP_TRY (launch_stall (ms, c->s_compute));
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_set_wait_spin (mibayer_ctx *c, int spin_us)
+{
+  if (!c)
+    return MIBAYER_ERR_ARG;
+  c->wait_spin_us = spin_us < 0 ? -1 : (spin_us > 1000000 ? 1000000 : spin_us);
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_get_host_stats (const mibayer_ctx *c, mibayer_host_stats *out)
+{
+  if (!c || !out)
+    return MIBAYER_ERR_ARG;
+  *out = c->stats;
   return MIBAYER_OK;
 }
 
@@ -1747,11 +2055,36 @@ extern "C" int mibayer_sync (mibayer_ctx *c)
     if (c->wedged)
       return MIBAYER_ERR_TIMEOUT;
     HIP_TRY (hipEventRecord (c->ev_fence, c->s_compute));
-    rc = wait_event (c, c->ev_fence);
+    rc = wait_event (c, c->ev_fence, true);
     if (rc != MIBAYER_OK)
       return rc;
     c->dirty_compute = false;
   }
+  return MIBAYER_OK;
+}
+
+/* `reps` back-to-back calls of `launch_once` (which queues work on the context's compute queue) between two HIP events
+ * on that queue, after `warmup` untimed calls; mean milliseconds per call */
+template <typename F>
+static int time_launches (mibayer_ctx *c, F launch_once, int warmup, int reps, float *ms_per_launch)
+{
+  int rc;
+  for (int i = 0; i < warmup; i++) {
+    rc = launch_once ();
+    if (rc != MIBAYER_OK)
+      return rc;
+  }
+  HIP_TRY (hipEventRecord (c->ev_t0, c->s_compute));
+  for (int i = 0; i < reps; i++) {
+    rc = launch_once ();
+    if (rc != MIBAYER_OK)
+      return rc;
+  }
+  HIP_TRY (hipEventRecord (c->ev_t1, c->s_compute));
+  HIP_TRY (hipEventSynchronize (c->ev_t1));
+  float ms = 0.f;
+  HIP_TRY (hipEventElapsedTime (&ms, c->ev_t0, c->ev_t1));
+  *ms_per_launch = ms / (float) reps;
   return MIBAYER_OK;
 }
 
@@ -1764,26 +2097,86 @@ extern "C" int mibayer_time_device (mibayer_ctx *c, const void *d_src,
   DeviceGuard guard (c->device);
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
-  int rc;
-  for (int i = 0; i < warmup; i++) {
-    rc = mibayer_process_device (c, d_src, src_frame_bytes, d_dst,
-        dst_frame_bytes, nframes, c->s_compute);
-    if (rc != MIBAYER_OK)
-      return rc;
+  return time_launches (c, [&] {
+    return mibayer_process_device (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes, c->s_compute);
+  }, warmup, reps, ms_per_launch);
+}
+
+/* ---- process-wide plan cache ------------------------------------------------------------ */
+
+/* What mibayer_autotune measured, kept per (device, geometry): the next context of the same stream geometry on that
+ * device -- the second element instance, the context after a renegotiation, the other Bayer orders of one camera --
+ * starts from the measured plan instead of the static default, without measuring again.  Reference analogue
+ * (compile once per process, reuse): the once-guarded ORC program set-up, gst/bayer/gstbayerorc-dist.c:321-397. */
+namespace {
+struct PlanEntry {
+  int device, width, height, src_stride, dst_stride;
+  int variant, band, align;
+};
+std::mutex g_plan_mu;
+std::vector<PlanEntry> g_plans;
+
+bool plan_cache_enabled ()
+{
+  static const bool on = [] {
+    const char *e = getenv ("MIBAYER_PLAN_CACHE");
+    return !(e && e[0] == '0');
+  } ();
+  return on;
+}
+
+bool plan_key_is (const PlanEntry &e, const mibayer_ctx *c)
+{
+  return e.device == c->device && e.width == c->cfg.width && e.height == c->cfg.height
+      && e.src_stride == c->cfg.src_stride && e.dst_stride == c->cfg.dst_stride;
+}
+
+void plan_cache_store (const mibayer_ctx *c)
+{
+  if (!plan_cache_enabled () || c->inverse || c->cfg.variant != 0)
+    return;
+  std::lock_guard<std::mutex> lk (g_plan_mu);
+  PlanEntry *slot = nullptr;
+  for (PlanEntry &e : g_plans)
+    if (plan_key_is (e, c))
+      slot = &e;
+  if (!slot) {
+    if (g_plans.size () >= 256)
+      g_plans.erase (g_plans.begin ());
+    g_plans.push_back (PlanEntry ());
+    slot = &g_plans.back ();
   }
-  HIP_TRY (hipEventRecord (c->ev_t0, c->s_compute));
-  for (int i = 0; i < reps; i++) {
-    rc = mibayer_process_device (c, d_src, src_frame_bytes, d_dst,
-        dst_frame_bytes, nframes, c->s_compute);
-    if (rc != MIBAYER_OK)
-      return rc;
-  }
-  HIP_TRY (hipEventRecord (c->ev_t1, c->s_compute));
-  HIP_TRY (hipEventSynchronize (c->ev_t1));
-  float ms = 0.f;
-  HIP_TRY (hipEventElapsedTime (&ms, c->ev_t0, c->ev_t1));
-  *ms_per_launch = ms / (float) reps;
-  return MIBAYER_OK;
+  *slot = PlanEntry { c->device, c->cfg.width, c->cfg.height, c->cfg.src_stride, c->cfg.dst_stride,
+    (int) (c->var - &variant (0)), c->band_override, c->align_stores };
+}
+
+}  /* namespace */
+
+static bool plan_cache_load (mibayer_ctx *c)
+{
+  if (!plan_cache_enabled () || c->inverse || c->cfg.variant != 0)
+    return false;
+  std::lock_guard<std::mutex> lk (g_plan_mu);
+  for (const PlanEntry &e : g_plans)
+    if (plan_key_is (e, c)) {
+      c->var = &variant (e.variant);
+      c->band_override = e.band;
+      c->align_stores = e.align;
+      c->plan_source = MIBAYER_PLAN_CACHED;
+      return true;
+    }
+  return false;
+}
+
+extern "C" void mibayer_plan_cache_clear (void)
+{
+  std::lock_guard<std::mutex> lk (g_plan_mu);
+  g_plans.clear ();
+}
+
+extern "C" int mibayer_plan_source (const mibayer_ctx *c)
+{
+  return c ? c->plan_source : MIBAYER_ERR_ARG;
 }
 
 /* Measured plan selection.  The kernel is idempotent and deterministic, so the
@@ -1800,30 +2193,25 @@ struct Candidate {
 constexpr int kMaxCands = 48;
 }
 
-extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
-    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
-    char *report, size_t report_len)
+/* `launch_once` queues one conversion of the caller's buffers under the context's CURRENT plan on the compute queue;
+ * `generic_off_grid`: those launches take the generic kernel and the output rows sit off the sector grid */
+template <typename F>
+static int autotune_core (mibayer_ctx *c, F launch_once, bool generic_off_grid, char *report, size_t report_len)
 {
-  if (!c || !d_src || !d_dst || nframes < 1 || c->inverse)
-    return MIBAYER_ERR_ARG;
-  if (report && report_len)
-    report[0] = 0;
-  DeviceGuard guard (c->device);
-  if (!guard.ok)
-    return MIBAYER_ERR_HIP;
-
   /* Candidate plans.  Sector-aligned geometries (the 16-byte kernel): {configured shape, the other production
    * shapes under "auto"} x {band 1, one chunk per XCD, identity}; the band orders carry the automatic start delay.
    * Generic geometries whose rows sit off the sector grid add the store policy as a dimension -- streaming,
    * write-back, hybrid (mibayer_kernels.hip) -- and the shifted arm (every wave-store on a 128-byte boundary) in
    * the two narrow shapes: which of them wins depends on the row phase and on the box
    * (profiles/r03_generic_path.log). */
-  const bool band_forced = getenv ("MIBAYER_XCD_BAND") != NULL;
+  const bool band_forced = c->band_forced;
   static const int kBands[3] = { 1, -1, 0 };
   const int nbands = band_forced ? 1 : 3;
   Candidate cand[kMaxCands];
   int ncand = 0;
   auto add = [&](const Variant *v, int band, int align) {
+    if (align && !(align == 128 ? v->aligned128 : v->aligned64))
+      return;
     for (int i = 0; i < ncand; i++)
       if (cand[i].var == v && cand[i].band == band && cand[i].align == align)
         return;
@@ -1833,21 +2221,13 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
   const Variant *keep_var = c->var;
   const int keep_band = c->band_override;
   const int keep_align = c->align_stores;
-  bool generic_off_grid = false;
-  {
-    KParams p;
-    KernelFn kern;
-    unsigned grid;
-    const int prc = plan_launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes, p, kern, grid);
-    if (prc != MIBAYER_OK)
-      return prc;
-    generic_off_grid = kern != c->var->fast && c->rows_off_sector;
-  }
+  /* a forced store alignment (MIBAYER_ALIGN_STORES) is part of every candidate */
+  const int fixed_align = c->align_tunable ? 0 : keep_align;
   /* the configured plan first: it also wins ties */
-  add (c->var, band_forced ? keep_band : (keep_band == INT32_MIN ? kBands[0] : keep_band), 0);
+  add (c->var, band_forced ? keep_band : (keep_band == INT32_MIN ? kBands[0] : keep_band), fixed_align);
   if (c->cfg.variant != 0) {
     for (int bi = 0; bi < nbands; bi++)
-      add (c->var, band_forced ? keep_band : kBands[bi], 0);
+      add (c->var, band_forced ? keep_band : kBands[bi], fixed_align);
   } else {
     const int own_id = (int) (c->var - &variant (0));
     for (int v = 3; v >= 1; v--) {
@@ -1863,7 +2243,7 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
       }
       for (int k = 0; k < nids; k++)
         for (int bi = 0; bi < nbands; bi++)
-          add (&variant (ids[k]), band_forced ? keep_band : kBands[bi], 0);
+          add (&variant (ids[k]), band_forced ? keep_band : kBands[bi], fixed_align);
     }
     if (generic_off_grid && c->align_tunable) {
       add (&variant (3), band_forced ? keep_band : 0, 128);
@@ -1888,16 +2268,12 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
     return MIBAYER_ERR_NOMEM;
   int rc = MIBAYER_OK;
   float ms = 0.f;
-  c->align_stores = 0;
+  c->align_stores = fixed_align;
   {
-    timespec t0, t1;
-    clock_gettime (CLOCK_MONOTONIC, &t0);
+    const double t0 = now_ms ();
     do {
-      rc = mibayer_time_device (c, d_src, src_frame_bytes, d_dst,
-          dst_frame_bytes, nframes, 0, kWarm, &ms);
-      clock_gettime (CLOCK_MONOTONIC, &t1);
-    } while (rc == MIBAYER_OK && ((double) (t1.tv_sec - t0.tv_sec) * 1e3
-            + (double) (t1.tv_nsec - t0.tv_nsec) * 1e-6) < kWarmMs);
+      rc = time_launches (c, launch_once, 0, kWarm, &ms);
+    } while (rc == MIBAYER_OK && now_ms () - t0 < kWarmMs);
   }
   for (int round = 0; round < kRounds && rc == MIBAYER_OK; round++) {
     for (int i = 0; i < ncand && rc == MIBAYER_OK; i++) {
@@ -1906,8 +2282,7 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
       c->var = cand[i].var;
       c->band_override = cand[i].band;
       c->align_stores = cand[i].align;
-      rc = mibayer_time_device (c, d_src, src_frame_bytes, d_dst,
-          dst_frame_bytes, nframes, 1, kReps, &ms);
+      rc = time_launches (c, launch_once, 1, kReps, &ms);
       rm[i][round] = ms;
     }
     if (round == 0 && rc == MIBAYER_OK && ncand > kKeep) {
@@ -1955,6 +2330,89 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
   c->var = cand[best].var;
   c->band_override = cand[best].band;
   c->align_stores = cand[best].align;
+  c->plan_source = MIBAYER_PLAN_MEASURED;
+  plan_cache_store (c);
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
+    size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
+    char *report, size_t report_len)
+{
+  if (!c || !d_src || !d_dst || nframes < 1 || c->inverse)
+    return MIBAYER_ERR_ARG;
+  if (report && report_len)
+    report[0] = 0;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  bool generic_off_grid = false;
+  {
+    KParams p;
+    KernelFn kern;
+    unsigned grid;
+    const int prc = plan_launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes, p, kern, grid);
+    if (prc != MIBAYER_OK)
+      return prc;
+    generic_off_grid = kern != c->var->fast && c->rows_off_sector;
+  }
+  return autotune_core (c, [&] {
+    return mibayer_process_device (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes, c->s_compute);
+  }, generic_off_grid, report, report_len);
+}
+
+/* The same over frames that are separate device allocations (mibayer_process_device_list): what a device-resident
+ * element holds (one GstBuffer per frame). */
+extern "C" int mibayer_autotune_list (mibayer_ctx *c, const void *const *d_srcs, void *const *d_dsts, int nframes,
+    char *report, size_t report_len)
+{
+  if (!c || !d_srcs || !d_dsts || nframes < 1 || c->inverse)
+    return MIBAYER_ERR_ARG;
+  if (report && report_len)
+    report[0] = 0;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return MIBAYER_ERR_HIP;
+  bool all16 = true;
+  for (int f = 0; f < nframes; f++) {
+    if (!d_srcs[f] || !d_dsts[f])
+      return MIBAYER_ERR_ARG;
+    all16 = all16 && aligned16 (d_srcs[f]) && aligned16 (d_dsts[f]);
+  }
+  const mibayer_cfg &f = c->cfg;
+  const bool fast = all16 && (f.width % 16 == 0) && (f.src_stride % 16 == 0) && (f.dst_stride % 16 == 0);
+  return autotune_core (c, [&] {
+    return mibayer_process_device_list (c, d_srcs, d_dsts, nframes, c->s_compute);
+  }, !fast && c->rows_off_sector, report, report_len);
+}
+
+extern "C" int mibayer_get_plan (const mibayer_ctx *c, int *variant_id, int *band, int *align_stores)
+{
+  if (!c)
+    return MIBAYER_ERR_ARG;
+  if (variant_id)
+    *variant_id = (int) (c->var - &variant (0));
+  if (band)
+    *band = c->band_override;
+  if (align_stores)
+    *align_stores = c->align_stores;
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_set_plan (mibayer_ctx *c, int variant_id, int band, int align_stores)
+{
+  if (!c || c->inverse)
+    return MIBAYER_ERR_ARG;
+  if (variant_id < 1 || variant_id >= variant_count ())
+    return MIBAYER_ERR_ARG;
+  if (align_stores != 0 && align_stores != 64 && align_stores != 128)
+    return MIBAYER_ERR_ARG;
+  if (align_stores && !(align_stores == 128 ? variant (variant_id).aligned128 : variant (variant_id).aligned64))
+    return MIBAYER_ERR_ARG;
+  c->var = &variant (variant_id);
+  c->band_override = band;
+  c->align_stores = align_stores;
+  c->plan_source = MIBAYER_PLAN_SET;
   return MIBAYER_OK;
 }
 
@@ -1967,6 +2425,7 @@ extern "C" int mibayer_copy_plan (mibayer_ctx *dst, const mibayer_ctx *src)
   dst->var = src->var;
   dst->band_override = src->band_override;
   dst->align_stores = src->align_stores;
+  dst->plan_source = MIBAYER_PLAN_SET;
   return MIBAYER_OK;
 }
 
@@ -2066,10 +2525,38 @@ extern "C" int mibayer_host_numa_node (const void *p)
   return status;
 }
 
+/* hipHostFree waits for the devices to drain, i.e. it would sit behind a GPU that has stopped answering, typically
+ * while a pipeline is shutting down because of it: while a wedge is outstanding the block goes on the deferred list
+ * and is returned to the runtime once every wedged device has caught up (polled here and at create / destroy). */
 extern "C" void mibayer_host_free (void *p)
 {
-  if (p && g_device_wedged.load () == 0)
+  if (!p)
+    return;
+  if (g_wedges_open.load () == 0 && g_deferred_host.empty ()) {
     (void) hipHostFree (p);
+    return;
+  }
+  std::lock_guard<std::mutex> lk (g_wedge_mu);
+  poll_wedges_locked ();
+  if (g_wedges_open.load () == 0)
+    (void) hipHostFree (p);
+  else
+    g_deferred_host.push_back (p);
+}
+
+/* pinned blocks waiting on the deferred list / contexts whose device has not caught up yet (diagnostics, tests) */
+extern "C" int mibayer_deferred_frees (void)
+{
+  std::lock_guard<std::mutex> lk (g_wedge_mu);
+  poll_wedges_locked ();
+  return (int) g_deferred_host.size ();
+}
+
+extern "C" int mibayer_wedged_contexts (void)
+{
+  std::lock_guard<std::mutex> lk (g_wedge_mu);
+  poll_wedges_locked ();
+  return g_wedges_open.load ();
 }
 
 extern "C" void *mibayer_device_alloc (mibayer_ctx *c, size_t bytes)

@@ -1,7 +1,7 @@
 /* Internal seam between the frame-sharding pool (mibayer_pool.cpp: pure host
  * logic, no HIP call in it) and the per-device stream context
  * (mibayer_abi.hip).  The pool only ever talks to a device through the public
- * per-context ABI of include/mibayer.h plus the three entry points below, so the
+ * per-context ABI of include/mibayer.h plus the entry points below, so the
  * whole failover / ordering / helper-thread logic can be built against a test
  * double of the contexts and run on a machine without a GPU, under
  * AddressSanitizer and ThreadSanitizer (tests/check/mock_mibayer.c,
@@ -42,12 +42,20 @@ int mibayer_internal_is_pageable (const void *p);
  * Frames already queued finish where they are; safe at any time. */
 void mibayer_internal_private_queues (mibayer_ctx *ctx);
 
-/* Best-effort quiesce of a context whose device reported an error: waits -- with
- * the context's deadline -- for the frames it still has in flight and for what a
- * half-failed submit left on its queues; never fails.  Returns at once for a
- * context that already ran into a wait deadline (MIBAYER_ERR_TIMEOUT): a device
- * that does not answer is not waited for again. */
-void mibayer_internal_abandon (mibayer_ctx *ctx);
+/* Quiesce of a context whose device is being dropped: waits -- with the context's
+ * deadline -- for the frames it still has in flight and for what a half-failed
+ * submit left on its queues.  MIBAYER_OK: nothing of the context can touch the
+ * callers' buffers any more (its work completed, or the device reported an error
+ * and its queues are dead).  MIBAYER_ERR_TIMEOUT: the device did not answer within
+ * the deadline (or had not before -- a context that already ran into a deadline is
+ * not waited for again, the call returns at once): whatever it had queued may still
+ * run later, the buffers of its in-flight frames remain the device's. */
+int mibayer_internal_abandon (mibayer_ctx *ctx);
+
+/* 1 when nothing this context queued is outstanding as far as a wait deadline is
+ * concerned: it never ran into one, or the device has since caught up with
+ * everything the context had queued at that moment; 0 otherwise.  Never blocks. */
+int mibayer_internal_settled (mibayer_ctx *ctx);
 
 /* Drill: occupy the context's compute queue for `ms` milliseconds (1 .. 5000) with
  * a kernel that does nothing but wait -- what a wedged GPU looks like to the host,

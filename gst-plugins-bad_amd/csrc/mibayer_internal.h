@@ -181,8 +181,8 @@ int resolve_variant (int id, int width);        /* 0 ("auto") -> a concrete id *
 /* the plain-store (write-back) arm of a production shape (ids 1-3), for output rows that start off a
  * 64-byte sector; any other id is returned unchanged */
 int plain_store_twin (int id);
-int hybrid_store_twin (int id);                 /* 1 -> 22, 2 -> 23, 3 -> 24: the hybrid store policy */
-int production_shape_of (int id);               /* the inverse of both: 20, 22 -> 1; 21, 23 -> 2; 4, 24 -> 3 */
+int hybrid_store_twin (int id);                 /* 1 -> 7, 2 -> 8, 3 -> 9: the hybrid store policy */
+int production_shape_of (int id);               /* the inverse of both: 4, 7 -> 1; 5, 8 -> 2; 6, 9 -> 3 */
 
 /* rgb2bayer (reference gst/bayer/gstrgb2bayer.c:230-278) */
 struct R2BParams {

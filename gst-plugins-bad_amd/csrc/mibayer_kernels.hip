@@ -694,6 +694,7 @@ bayer2rgb_lds_aligned_kernel (KParams p)
   }
 }
 
+#ifdef MIBAYER_LAB
 /* ------------------------------------------------------------------------- */
 /* direct kernel: no LDS, every wave streams its own strip                     */
 /* ------------------------------------------------------------------------- */
@@ -929,14 +930,12 @@ bayer2rgb_persist_kernel (KParams p)
   }
 }
 
+#endif  /* MIBAYER_LAB */
+
 /* ------------------------------------------------------------------------- */
 /* variant table                                                               */
 /* ------------------------------------------------------------------------- */
 
-#define PERSIST_VARIANT(name, WX, WY, RPW, ST)                                 \
-  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1, 1,                   \
-    bayer2rgb_persist_kernel<WX, WY, RPW, ST>,                                 \
-    bayer2rgb_lds_kernel<WX, WY, RPW, 0, ST, true, true>, nullptr, nullptr }
 /* default block order per shape (measured on a dozen boxes, DESIGN.md "XCD map"):
  * 1024-px tiles -> band 1 (an XCD takes one full-width tile row at a time), the
  * only plan at 80-81.5 % of peak on EVERY box; narrower tiles -> identity */
@@ -944,17 +943,29 @@ bayer2rgb_persist_kernel (KParams p)
   { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), (WX) == 4 ? 1 : 0, 0,    \
     bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, false>,               \
     bayer2rgb_lds_kernel<WX, WY, RPW, NEIGH, ST, INTRIN, true>, nullptr, nullptr }
-/* production shapes and their plain-store twins: + the sector-aligned arms for generic geometries */
+/* production shapes and their plain-store twins: + the sector-aligned arms for generic geometries (the 64-byte
+ * flavour only in the lab build: the autotuner's candidates use the 128-byte one) */
+#ifdef MIBAYER_LAB
+#define ALIGNED64_ARM(WX, WY, RPW, ST) bayer2rgb_lds_aligned_kernel<WX, WY, RPW, ST, 64>
+#else
+#define ALIGNED64_ARM(WX, WY, RPW, ST) nullptr
+#endif
 #define LDS_VARIANT_AL(name, WX, WY, RPW, ST)                                  \
   { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), (WX) == 4 ? 1 : 0, 0,    \
     bayer2rgb_lds_kernel<WX, WY, RPW, 0, ST, true, false>,                     \
     bayer2rgb_lds_kernel<WX, WY, RPW, 0, ST, true, true>,                      \
-    bayer2rgb_lds_aligned_kernel<WX, WY, RPW, ST, 64>,                         \
+    ALIGNED64_ARM (WX, WY, RPW, ST),                                           \
     bayer2rgb_lds_aligned_kernel<WX, WY, RPW, ST, 128> }
+#ifdef MIBAYER_LAB
+#define PERSIST_VARIANT(name, WX, WY, RPW, ST)                                 \
+  { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1, 1,                   \
+    bayer2rgb_persist_kernel<WX, WY, RPW, ST>,                                 \
+    bayer2rgb_lds_kernel<WX, WY, RPW, 0, ST, true, true>, nullptr, nullptr }
 #define DIRECT_VARIANT(name, WX, WY, RPW, ST, INTRIN)                          \
   { name, 256 * (WX), (WY) * (RPW), 64 * (WX) * (WY), -1, 0,                   \
     bayer2rgb_direct_kernel<WX, WY, RPW, ST, INTRIN, false>,                   \
     bayer2rgb_direct_kernel<WX, WY, RPW, ST, INTRIN, true>, nullptr, nullptr }
+#endif
 
 /* Measured on MI355X (profiles/sweep_r01_*.log, interleaved A/B, 4K x 64 frames):
  * 4 rows per wave and 8 waves per workgroup is the sweet spot (83-84 % of the
@@ -964,12 +975,23 @@ bayer2rgb_persist_kernel (KParams p)
 static const Variant kVariants[] = {
   /* 0: "auto" -- resolved per stream width by resolve_variant() below */
   { "auto", 0, 0, 0, -1, 0, nullptr, nullptr, nullptr, nullptr },
-  /* 1-3: the production shapes (tile 1024x8, 512x16, 256x32; 512 threads) */
+  /* 1-3: the production shapes (tile 1024x8, 512x16, 256x32; 512 threads), streaming (nt) stores */
   LDS_VARIANT_AL ("lds_4x2_r4_dpp_nt", 4, 2, 4, 1),
   LDS_VARIANT_AL ("lds_2x4_r4_dpp_nt", 2, 4, 4, 1),
   LDS_VARIANT_AL ("lds_1x8_r4_dpp_nt", 1, 8, 4, 1),
-  /* 4.. : tuning / verification arms, all bit-exact (tests/test_gpu_parity.py) */
+  /* 4-6: the same shapes with plain (write-back) stores: for output rows that start off a 64-byte sector
+   * (width % 16 != 0) the L2 then completes the partial sectors two waves share before they go out */
+  LDS_VARIANT_AL ("lds_4x2_r4_dpp", 4, 2, 4, 0),
+  LDS_VARIANT_AL ("lds_2x4_r4_dpp", 2, 4, 4, 0),
   LDS_VARIANT_AL ("lds_1x8_r4_dpp", 1, 8, 4, 0),
+  /* 7-9: the hybrid store policy (generic geometries: nt for the lines a wave-store covers completely, write-back for
+   * its ragged ends; sector-aligned geometries: nt) */
+  LDS_VARIANT ("lds_4x2_r4_dpp_hy", 4, 2, 4, 0, 5, true),
+  LDS_VARIANT ("lds_2x4_r4_dpp_hy", 2, 4, 4, 0, 5, true),
+  LDS_VARIANT ("lds_1x8_r4_dpp_hy", 1, 8, 4, 0, 5, true),
+#ifdef MIBAYER_LAB
+  /* 10.. : tuning / verification arms of the lab build (`make lab`), all bit-exact (tests/test_gpu_parity.py);
+   * what each of them measured is in profiles/r01_sweep_*.log */
   LDS_VARIANT ("lds_1x8_r4_dpp_sc1", 1, 8, 4, 0, 2, true),
   LDS_VARIANT ("lds_1x8_r4_shfl_nt", 1, 8, 4, 1, 1, true),
   LDS_VARIANT ("lds_1x8_r4_ldsnb_nt", 1, 8, 4, 2, 1, true),
@@ -989,15 +1011,7 @@ static const Variant kVariants[] = {
   LDS_VARIANT ("lds_4x2_r4_dpp_nt_ldnt", 4, 2, 4, 0, 9, true),
   /* direct global -> LDS row loads (no staging registers, no ds_write pass) */
   LDS_VARIANT ("lds_4x2_r4_dpp_nt_glds", 4, 2, 4, 0, 17, true),
-  /* 20-21: plain (write-back) stores in the wide shapes: for output rows that start off a 64-byte sector
-   * (width % 16 != 0) the L2 then completes the partial sectors two waves share before they go out */
-  LDS_VARIANT_AL ("lds_4x2_r4_dpp", 4, 2, 4, 0),
-  LDS_VARIANT_AL ("lds_2x4_r4_dpp", 2, 4, 4, 0),
-  /* 22-24: hybrid store policy in the production shapes (generic geometries: nt for the lines a wave-store covers
-   * completely, write-back for its ragged ends; sector-aligned geometries: nt) */
-  LDS_VARIANT ("lds_4x2_r4_dpp_hy", 4, 2, 4, 0, 5, true),
-  LDS_VARIANT ("lds_2x4_r4_dpp_hy", 2, 4, 4, 0, 5, true),
-  LDS_VARIANT ("lds_1x8_r4_dpp_hy", 1, 8, 4, 0, 5, true),
+#endif
 };
 
 int variant_count ()
@@ -1016,38 +1030,23 @@ const Variant &variant (int id)
  * one by one; plain write-back stores let the L2 put them together first, provided both halves reach the SAME
  * L2, i.e. under the chunk-per-XCD order: 4056x3040 76.0 -> 78.9 %, 3838x2160 72.5 -> 78.5 %, 1366x768
  * 68.1 -> 73.3 % of peak (profiles/r02_generic_path.log); for sector-aligned rows nt + band 1 stays ahead
- * (80.8 vs 79.3 %). */
+ * (80.8 vs 79.3 %).  Ids: production shape s in 1..3 -> plain-store twin s + 3, hybrid-store twin s + 6. */
 int plain_store_twin (int id)
 {
-  switch (id) {
-    case 1: return 20;          /* lds_4x2_r4_dpp */
-    case 2: return 21;          /* lds_2x4_r4_dpp */
-    case 3: return 4;           /* lds_1x8_r4_dpp */
-    default: return id;
-  }
+  return (id >= 1 && id <= 3) ? id + 3 : id;
 }
 
 /* the hybrid-store arm of a production shape (store_pixels_hybrid: nt inside, write-back at the ragged ends of a
  * wave-store), for generic geometries whose output rows are 16-byte aligned but off the line grid */
 int hybrid_store_twin (int id)
 {
-  switch (id) {
-    case 1: return 22;          /* lds_4x2_r4_dpp_hy */
-    case 2: return 23;          /* lds_2x4_r4_dpp_hy */
-    case 3: return 24;          /* lds_1x8_r4_dpp_hy */
-    default: return id;
-  }
+  return (id >= 1 && id <= 3) ? id + 6 : id;
 }
 
 /* the production shape (ids 1-3) a plain-store or hybrid-store twin stands for; any other id is returned unchanged */
 int production_shape_of (int id)
 {
-  switch (id) {
-    case 20: case 22: return 1;
-    case 21: case 23: return 2;
-    case 4: case 24: return 3;
-    default: return id;
-  }
+  return (id >= 4 && id <= 9) ? (id - 1) % 3 + 1 : id;
 }
 
 /* variant 0.  Rows that fit into ONE tile take the narrowest production tile that covers them (256 / 512 / 1024 px),
@@ -1282,11 +1281,15 @@ template <int VEC>
 static R2BFn flat_kernel_for (int k, int px, int ld)
 {
 #define R2B_FLAT(K, PX, LD) if (k == K && px == PX && ld == LD) return rgb2bayer_flat_kernel<K, PX, LD, VEC>
+#ifndef MIBAYER_LAB
+  R2B_FLAT (2, 4, 1);           /* the production launch shape (profiles/r02_rgb2bayer_sweep.log) */
+#else
   R2B_FLAT (1, 4, 0); R2B_FLAT (1, 4, 1); R2B_FLAT (1, 8, 0); R2B_FLAT (1, 8, 1);
   R2B_FLAT (2, 4, 0); R2B_FLAT (2, 4, 1); R2B_FLAT (2, 8, 0); R2B_FLAT (2, 8, 1);
   R2B_FLAT (3, 4, 0); R2B_FLAT (3, 4, 1); R2B_FLAT (3, 8, 0); R2B_FLAT (3, 8, 1);
   R2B_FLAT (4, 4, 0); R2B_FLAT (4, 4, 1); R2B_FLAT (4, 8, 0); R2B_FLAT (4, 8, 1);
   R2B_FLAT (8, 4, 0); R2B_FLAT (8, 4, 1); R2B_FLAT (8, 8, 0); R2B_FLAT (8, 8, 1);
+#endif
 #undef R2B_FLAT
   return nullptr;
 }
@@ -1342,7 +1345,12 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
 
   /* ---- tile kernel ------------------------------------------------------------ */
   q.total_rows = row0 + nrows;  /* the kernel's "row < total_rows" guard ends the band */
+#ifdef MIBAYER_LAB
   const int R2B_ROWS = (q.rows == 4 || q.rows == 8 || q.rows == 16) ? q.rows : 2;
+#else
+  const int R2B_ROWS = 2;       /* the product build carries the tile kernel as the fallback for batches too long for
+                                   the flat kernel's 32-bit item index, in one shape */
+#endif
   const long long tile_rows = (nrows + R2B_ROWS - 1) / R2B_ROWS;
   const int tiles_x = (p.out_dwords + 255) / 256;
   if (q.band < 0)               /* one contiguous chunk of tile rows per XCD */
@@ -1355,6 +1363,9 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
       dim3 ((unsigned) grid), dim3 (256), 0, stream, q)
   switch (R2B_ROWS * 2 + (vec16 ? 1 : 0)) {
     case 2 * 2 + 1: R2B_LAUNCH (true, 2); break;
+#ifndef MIBAYER_LAB
+    default: R2B_LAUNCH (false, 2); break;
+#else
     case 2 * 2 + 0: R2B_LAUNCH (false, 2); break;
     case 4 * 2 + 1: R2B_LAUNCH (true, 4); break;
     case 4 * 2 + 0: R2B_LAUNCH (false, 4); break;
@@ -1362,6 +1373,7 @@ hipError_t launch_rgb2bayer (const R2BParams &p, bool vec16, hipStream_t stream,
     case 8 * 2 + 0: R2B_LAUNCH (false, 8); break;
     case 16 * 2 + 1: R2B_LAUNCH (true, 16); break;
     default: R2B_LAUNCH (false, 16); break;
+#endif
   }
 #undef R2B_LAUNCH
   return hipGetLastError ();

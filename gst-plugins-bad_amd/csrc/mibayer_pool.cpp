@@ -74,7 +74,10 @@ enum FrameState {
   F_RUNNING,    /* the helper thread has it (being submitted, or in the context's ring) */
   F_DONE,       /* converted by a helper thread (or by a synchronous re-do)       */
   F_FAILED,     /* the helper thread got a device error for it                    */
-  F_REDO        /* its device failed: convert again on a surviving device         */
+  F_REDO,       /* its device failed: convert again on a surviving device         */
+  F_LOST        /* it was in flight on a device that ran into the wait deadline: the
+                   device may still read / write its buffers, so it is neither converted
+                   again into them nor handed back as done (mibayer_pool_reclaim)      */
 };
 
 struct Frame {
@@ -85,6 +88,7 @@ struct Frame {
   int owner;    /* whose in-flight budget it uses */
   int state;    /* FrameState; helper-thread frames: under Shard::mu */
   int rc;
+  bool submitted;       /* handed to the context of `shard` (its ring may hold it) */
 };
 
 struct Shard {
@@ -110,6 +114,8 @@ struct Shard {
   int ring_room = 2;            /* stream.inflight                                     */
   bool quit = false;
   bool broken = false;
+  bool timed_out = false;       /* what broke it was a wait deadline */
+  int helper_lost = 0;          /* frames its helper thread marked F_LOST (for the failure note) */
   char errmsg[200] = "";
 
   /* true exactly once, when the shard has completed `fail_after` frames */
@@ -126,14 +132,18 @@ bool device_failure (int rc)
   return rc == MIBAYER_ERR_HIP || rc == MIBAYER_ERR_NOMEM || rc == MIBAYER_ERR_TIMEOUT;
 }
 
-/* everything the helper still holds is re-done elsewhere (mu held) */
-void helper_give_up (Shard *sh, const char *why)
+/* everything the helper still holds is re-done elsewhere (mu held) -- except, after a wait deadline, the frames
+ * the context already has: those are lost (F_LOST).  kill_shard() has the last word on which of the two it is. */
+void helper_give_up (Shard *sh, const char *why, bool timed_out = false)
 {
   sh->broken = true;
+  sh->timed_out = sh->timed_out || timed_out;
   if (why != sh->errmsg)
     snprintf (sh->errmsg, sizeof sh->errmsg, "%s", why ? why : "");
-  for (Frame *f : sh->ring)
-    f->state = F_REDO;
+  for (Frame *f : sh->ring) {
+    f->state = (sh->timed_out && f->submitted) ? F_LOST : F_REDO;
+    sh->helper_lost += f->state == F_LOST ? 1 : 0;
+  }
   sh->ring.clear ();
   for (Frame *f : sh->jobs)
     f->state = F_REDO;
@@ -214,17 +224,19 @@ void helper_main (Shard *sh)
       Frame *f = sh->jobs.front ();
       sh->jobs.pop_front ();
       f->state = F_RUNNING;
+      f->submitted = true;      /* from here on the context may hold it */
       sh->ring.push_back (f);
       lk.unlock ();
       const int rc = mibayer_submit (sh->ctx, f->src, f->dst, f);
       lk.lock ();
       if (rc != MIBAYER_OK) {
         f->rc = rc;
+        f->submitted = false;   /* a failed submit leaves nothing of the frame behind (mibayer_submit drains) */
         if (!sh->ring.empty () && sh->ring.back () == f)
           sh->ring.pop_back ();
         if (device_failure (rc)) {
           f->state = F_REDO;
-          helper_give_up (sh, mibayer_last_hip_error ());
+          helper_give_up (sh, mibayer_last_hip_error (), rc == MIBAYER_ERR_TIMEOUT);
         } else {
           f->state = F_FAILED;
           sh->cv_done.notify_all ();
@@ -247,7 +259,8 @@ void helper_main (Shard *sh)
         sh->cv_done.notify_all ();
       } else if (device_failure (rc)) {
         f->rc = rc;
-        helper_give_up (sh, mibayer_last_hip_error ());    /* f and everything behind it: F_REDO */
+        /* f and everything behind it: F_REDO -- after a deadline, what the context holds: F_LOST */
+        helper_give_up (sh, mibayer_last_hip_error (), rc == MIBAYER_ERR_TIMEOUT);
       } else {
         sh->ring.pop_front ();
         f->rc = rc;
@@ -270,6 +283,9 @@ struct mibayer_pool {
   bool numa_route = false;      /* the shards' devices span more than one NUMA node */
   bool inverse = false;         /* MIBAYER_FLAG_RGB2BAYER: the source is the 4 B/px side */
   std::unordered_map<const void *, int> node_of;        /* NUMA node of buffers seen so far (pools recycle them) */
+  /* frames lost on a device that ran into the wait deadline: their buffers are the device's until it settles */
+  struct Lost { void *tag; int shard; };
+  std::vector<Lost> lost;
   /* failure report */
   int unreported = 0;
   int failed_device = -1;
@@ -284,7 +300,11 @@ static int alive_count (const mibayer_pool *pool)
   return n;
 }
 
-/* drop shard `idx` from the rotation; everything it still holds is re-done */
+/* Drop shard `idx` from the rotation.  What it had not been given yet is converted on the others; what its context
+ * already held is converted again too IF the context could be quiesced (mibayer_internal_abandon: its copies have
+ * completed or its queues are dead).  After a wait deadline it cannot: the device may only be slow, its queued
+ * uploads may still read those frames' sources and its downloads write their destinations later -- they are LOST
+ * (handed back with MIBAYER_ERR_TIMEOUT, buffers quarantined until mibayer_pool_reclaim). */
 static void kill_shard (mibayer_pool *pool, int idx, int rc, const char *why)
 {
   Shard *sh = pool->shards[(size_t) idx];
@@ -297,6 +317,8 @@ static void kill_shard (mibayer_pool *pool, int idx, int rc, const char *why)
     snprintf (reason, sizeof reason, "%s", (why && why[0]) ? why : sh->errmsg);
     why = reason;
     sh->broken = true;
+    if (rc == MIBAYER_ERR_TIMEOUT)
+      sh->timed_out = true;
     for (Frame *f : sh->ring)
       f->state = F_REDO;
     sh->ring.clear ();
@@ -308,14 +330,28 @@ static void kill_shard (mibayer_pool *pool, int idx, int rc, const char *why)
   for (Frame &f : pool->fifo)
     if (f.shard == idx && f.state == F_DIRECT)
       f.state = F_REDO;
+  /* after this nothing of that context touches the callers' buffers any more -- or the frames it held are lost */
+  const bool held = mibayer_internal_abandon (sh->ctx) != MIBAYER_OK;
+  int nlost = 0;
+  {
+    std::lock_guard<std::mutex> lk (sh->mu);
+    for (Frame &f : pool->fifo)
+      if (f.shard == idx && f.submitted && (f.state == F_REDO || f.state == F_LOST)) {
+        nlost += (held && f.state == F_REDO) ? 1 : 0;
+        f.state = held ? F_LOST : F_REDO;
+      }
+    nlost += held ? sh->helper_lost : 0;
+    sh->cv_done.notify_all ();
+  }
   pool->unreported++;
   pool->failed_device = sh->device;
+  char lost_note[64] = "";
+  if (nlost > 0)
+    snprintf (lost_note, sizeof lost_note, "; %d frame(s) in flight on it lost", nlost);
   snprintf (pool->failure_msg, sizeof pool->failure_msg,
-      "shard %d (HIP device %d) dropped from the rotation: %.60s%s%.150s; %d device(s) left",
+      "shard %d (HIP device %d) dropped from the rotation: %.60s%s%.120s%s; %d device(s) left",
       idx, sh->device, mibayer_strerror (rc), why && why[0] ? " -- " : "",
-      why ? why : "", alive_count (pool));
-  /* after this nothing of that context touches the callers' buffers any more */
-  mibayer_internal_abandon (sh->ctx);
+      why ? why : "", lost_note, alive_count (pool));
 }
 
 /* the helper thread of a live shard has seen a device error that the streaming
@@ -324,13 +360,14 @@ static void kill_shard (mibayer_pool *pool, int idx, int rc, const char *why)
 static bool reap_if_broken (mibayer_pool *pool, int idx)
 {
   Shard *sh = pool->shards[(size_t) idx];
-  bool broken;
+  bool broken, timed_out;
   {
     std::lock_guard<std::mutex> lk (sh->mu);
     broken = sh->broken;
+    timed_out = sh->timed_out;
   }
   if (broken && sh->alive)
-    kill_shard (pool, idx, MIBAYER_ERR_HIP, NULL);
+    kill_shard (pool, idx, timed_out ? MIBAYER_ERR_TIMEOUT : MIBAYER_ERR_HIP, NULL);
   return broken;
 }
 
@@ -369,7 +406,7 @@ static void enter_helper_mode (mibayer_pool *pool, int idx, bool pageable)
   sh->helper_mode = true;
   for (Frame &f : pool->fifo)
     if (f.shard == idx && f.state == F_DIRECT) {
-      f.state = F_RUNNING;
+      f.state = F_RUNNING;      /* (submitted stays true: the context holds it) */
       sh->ring.push_back (&f);
     }
   sh->cv_job.notify_one ();
@@ -625,7 +662,7 @@ extern "C" int mibayer_pool_submit (mibayer_pool *pool, const uint8_t *src,
       sh->stall_ms = 0;
       (void) mibayer_internal_stall (sh->ctx, ms);
     }
-    Frame f = { src, dst, tag, (int) idx, (int) idx, F_DIRECT, MIBAYER_OK };
+    Frame f = { src, dst, tag, (int) idx, (int) idx, F_DIRECT, MIBAYER_OK, false };
     if (pool->use_helpers && (mibayer_internal_is_pageable (src) || mibayer_internal_is_pageable (dst))
         && !sh->pageable_seen) {
       sh->pageable_seen = true;
@@ -642,6 +679,7 @@ extern "C" int mibayer_pool_submit (mibayer_pool *pool, const uint8_t *src,
       }
       if (rc != MIBAYER_OK)
         return rc;
+      f.submitted = true;
       pool->fifo.push_back (f);
     }
     sh->inflight++;
@@ -685,11 +723,26 @@ extern "C" int mibayer_pool_wait (mibayer_pool *pool, void **tag)
     }
     if (state == F_FAILED)
       return f.rc;              /* not a device failure (those become F_REDO): the caller's to handle */
+    if (state == F_LOST) {
+      /* in flight on a device that ran into the deadline: handed back as lost, in order; its buffers stay the
+       * device's until mibayer_pool_reclaim() says otherwise */
+      pool->lost.push_back (mibayer_pool::Lost { f.tag, f.shard });
+      if (tag)
+        *tag = f.tag;
+      pool->shards[(size_t) f.owner]->inflight--;
+      pool->fifo.pop_front ();
+      return MIBAYER_ERR_TIMEOUT;
+    }
     /* F_REDO: once more on a device that is still in the rotation.  First the shard it came from: if its helper
      * thread saw the failure, the shard is still "alive" to this thread and its context still has the frame's
      * copies queued -- take it out and abandon it BEFORE the frame is converted elsewhere and handed back, or a late
      * DMA of the dead context lands in a buffer the caller has already released. */
     (void) reap_if_broken (pool, f.shard);
+    {
+      std::lock_guard<std::mutex> lk (sh->mu);
+      if (f.state == F_LOST)    /* the quiesce ran into the deadline: not converted again after all */
+        continue;
+    }
     size_t idx = n;
     for (size_t k = 0; k < n; k++) {
       const size_t i = (pool->redo_rr + k) % n;
@@ -705,11 +758,14 @@ extern "C" int mibayer_pool_wait (mibayer_pool *pool, void **tag)
     pool->redo_rr = (idx + 1) % n;
     Shard *to = pool->shards[idx];
     f.shard = (int) idx;
+    f.submitted = false;
     if (to->helper_mode) {
       /* its helper thread owns the context: an ordinary job for it */
       queue_to_helper (to, &f);
       continue;
     }
+    f.submitted = true;         /* while the spare slot of `to` works on it */
+    f.state = F_REDO;
     int rc = mibayer_internal_run_spare (to->ctx, f.src, f.dst);
     if (rc == MIBAYER_OK && to->fault_due ())
       rc = MIBAYER_ERR_HIP;
@@ -717,11 +773,61 @@ extern "C" int mibayer_pool_wait (mibayer_pool *pool, void **tag)
       break;
     if (!device_failure (rc))
       return rc;
-    kill_shard (pool, (int) idx, rc, mibayer_last_hip_error ());
+    kill_shard (pool, (int) idx, rc, mibayer_last_hip_error ());       /* F_REDO again, or F_LOST after a deadline */
   }
   if (tag)
     *tag = f.tag;
   pool->shards[(size_t) f.owner]->inflight--;
   pool->fifo.pop_front ();
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_pool_lost (const mibayer_pool *pool)
+{
+  return pool ? (int) pool->lost.size () : MIBAYER_ERR_ARG;
+}
+
+extern "C" int mibayer_pool_reclaim (mibayer_pool *pool, void **tag)
+{
+  if (!pool)
+    return MIBAYER_ERR_ARG;
+  for (size_t i = 0; i < pool->lost.size (); i++) {
+    const mibayer_pool::Lost l = pool->lost[i];
+    if (mibayer_internal_settled (pool->shards[(size_t) l.shard]->ctx)) {
+      if (tag)
+        *tag = l.tag;
+      pool->lost.erase (pool->lost.begin () + (long) i);
+      return MIBAYER_OK;
+    }
+  }
+  return MIBAYER_ERR_EMPTY;
+}
+
+extern "C" int mibayer_pool_set_wait_spin (mibayer_pool *pool, int spin_us)
+{
+  if (!pool)
+    return MIBAYER_ERR_ARG;
+  for (Shard *sh : pool->shards)
+    (void) mibayer_set_wait_spin (sh->ctx, spin_us);
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_pool_get_host_stats (const mibayer_pool *pool, mibayer_host_stats *out)
+{
+  if (!pool || !out)
+    return MIBAYER_ERR_ARG;
+  memset (out, 0, sizeof *out);
+  for (const Shard *sh : pool->shards) {
+    mibayer_host_stats one;
+    if (mibayer_get_host_stats (sh->ctx, &one) != MIBAYER_OK)
+      continue;
+    out->submits += one.submits;
+    out->waits += one.waits;
+    out->polls += one.polls;
+    out->naps += one.naps;
+    out->submit_cpu_ms += one.submit_cpu_ms;
+    out->wait_cpu_ms += one.wait_cpu_ms;
+    out->wait_wall_ms += one.wait_wall_ms;
+  }
   return MIBAYER_OK;
 }

@@ -26,7 +26,11 @@
  *     queues sit behind `flow_lock`);
  *   - a device that fails is dropped from the rotation by the pool, its frames are
  *     converted again on the survivors, and the element posts ONE warning per
- *     dropped device; the stream errors out only when no device is left.
+ *     dropped device; the stream errors out only when no device is left.  Frames
+ *     that were in flight on a device that stopped ANSWERING (timeout-ms) are
+ *     dropped instead, and their buffers stay quarantined -- mapped, referenced,
+ *     out of every buffer pool -- until the device has caught up: its queued
+ *     copies may still run (mibayer.h, mibayer_pool_reclaim).
  * Geometry the HIP path cannot reproduce bit-exactly (odd width, width < 4,
  * height < 3: the reference itself reads stale scratch / out of bounds there,
  * gstbayer2rgb.c:365-380, :430-447) is refused in set_caps -> not-negotiated,
@@ -50,6 +54,8 @@
   GST_CAT_DEBUG_OBJECT (ELEMENT_CLASS_OF (obj)->cat, obj, __VA_ARGS__)
 #define EL_WARNING(obj, ...) \
   GST_CAT_WARNING_OBJECT (ELEMENT_CLASS_OF (obj)->cat, obj, __VA_ARGS__)
+#define EL_INFO(obj, ...) \
+  GST_CAT_INFO_OBJECT (ELEMENT_CLASS_OF (obj)->cat, obj, __VA_ARGS__)
 
 #define ELEMENT(obj) ((GstMiBayerElement *) (obj))
 #define ELEMENT_CLASS_OF(obj) \
@@ -174,14 +180,43 @@ element_post_notes (GstMiBayerElement * self)
   if (note != NULL) {
     GST_ELEMENT_WARNING (self, RESOURCE, FAILED,
         ("%s: a GPU failed and was dropped from the rotation; its frames were "
-            "converted again on the remaining device(s)", LABEL (self)),
+            "converted again on the remaining device(s) (frames in flight on a "
+            "GPU that stopped answering are dropped)", LABEL (self)),
         ("%s", note));
     g_free (note);
   }
 }
 
+/* lost frames whose device has caught up since (flow_lock held): their buffers are ours again */
+static void
+element_reclaim_locked (GstMiBayerElement * self)
+{
+  void *tag = NULL;
+
+  while (self->pool != NULL && !g_queue_is_empty (&self->quarantine)
+      && mibayer_pool_reclaim (self->pool, &tag) == MIBAYER_OK) {
+    if (g_queue_remove (&self->quarantine, tag))
+      pending_release ((PendingFrame *) tag, FALSE);
+  }
+}
+
+/* the pool is about to go (flow_lock held): whatever is still quarantined can never be handed back -- the device may
+ * still write into it -- and is leaked on purpose, mapped and referenced */
+static void
+element_abandon_quarantine_locked (GstMiBayerElement * self)
+{
+  element_reclaim_locked (self);
+  if (!g_queue_is_empty (&self->quarantine)) {
+    EL_WARNING (self, "%u frame(s) lost on a GPU that never answered again: their buffers are leaked",
+        g_queue_get_length (&self->quarantine));
+    g_queue_clear (&self->quarantine);
+  }
+}
+
 /* oldest frame (flow_lock held): wait for the GPU, unmap, hand the output buffer
- * back.  *owned tells whether the caller now holds the only reference. */
+ * back.  *owned tells whether the caller now holds the only reference.  A frame that
+ * was in flight on a device that ran into the deadline comes back lost: no output
+ * (GST_FLOW_OK, *outbuf == NULL), its buffers go into quarantine. */
 static GstFlowReturn
 element_collect_locked (GstMiBayerElement * self, GstBuffer ** outbuf,
     gboolean * owned, int *gpu_rc)
@@ -196,6 +231,22 @@ element_collect_locked (GstMiBayerElement * self, GstBuffer ** outbuf,
     return GST_FLOW_OK;
   rc = self->pool ? mibayer_pool_wait (self->pool, NULL) : MIBAYER_OK;
   element_note_failures (self);
+  element_reclaim_locked (self);
+  if (rc == MIBAYER_ERR_TIMEOUT) {
+    /* the device may still read the input and write the output: nothing of this frame is released.  In the
+     * synchronous mode the base class owns the output buffer and lets go of it when the transform returns: keep
+     * a reference of our own, so that it does not go back to its pool */
+    if (!p->owns_outbuf) {
+      gst_buffer_ref (p->outbuf);
+      p->owns_outbuf = TRUE;
+    }
+    g_queue_push_tail (&self->quarantine, p);
+    self->frames_lost++;
+    if (mibayer_pool_alive (self->pool) > 0)
+      return GST_FLOW_OK;       /* the stream carries on without this frame */
+    *gpu_rc = rc;
+    return GST_FLOW_ERROR;
+  }
   if (rc != MIBAYER_OK) {
     pending_release (p, FALSE);
     *gpu_rc = rc;
@@ -244,12 +295,29 @@ element_drain (GstMiBayerElement * self, gboolean push)
   return ret;
 }
 
+/* what the GPU path cost the host since the pool was created (flow_lock held): GST_DEBUG=<element>:4 */
+static void
+element_log_host_stats (GstMiBayerElement * self)
+{
+  mibayer_host_stats st;
+
+  if (self->pool == NULL || mibayer_pool_get_host_stats (self->pool, &st) != MIBAYER_OK || st.submits == 0)
+    return;
+  EL_INFO (self, "host stats: frames=%" G_GUINT64_FORMAT " submit_cpu_us_per_frame=%.1f wait_cpu_us_per_frame=%.1f "
+      "wait_wall_us_per_frame=%.1f polls_per_frame=%.1f naps_per_frame=%.1f lost=%u", st.submits,
+      st.submit_cpu_ms * 1e3 / (double) st.submits, st.wait_cpu_ms * 1e3 / (double) st.submits,
+      st.wait_wall_ms * 1e3 / (double) st.submits, (double) st.polls / (double) st.submits,
+      (double) st.naps / (double) st.submits, self->frames_lost);
+}
+
 static void
 element_drop_pool (GstMiBayerElement * self)
 {
   element_drain (self, FALSE);
   g_mutex_lock (&self->flow_lock);
   if (self->pool) {
+    element_log_host_stats (self);
+    element_abandon_quarantine_locked (self);
     mibayer_pool_destroy (self->pool);
     self->pool = NULL;
   }
@@ -341,6 +409,8 @@ element_ensure_pool (GstMiBayerElement * self, gint video_stride)
       g_queue_push_tail (&self->ready, done);
   }
   if (self->pool) {
+    element_log_host_stats (self);
+    element_abandon_quarantine_locked (self);
     mibayer_pool_destroy (self->pool);
     self->pool = NULL;
   }
@@ -841,6 +911,8 @@ element_transform (GstBaseTransform * base, GstBuffer * inbuf,
   }
   if (rc != MIBAYER_OK)
     post_gpu_failure (self, rc);
+  if (ret == GST_FLOW_OK && done == NULL)
+    return GST_BASE_TRANSFORM_FLOW_DROPPED;     /* lost on a GPU that stopped answering: no output for this input */
   return ret;
 }
 
@@ -995,6 +1067,7 @@ element_start (GstBaseTransform * base)
   GST_OBJECT_UNLOCK (self);
   g_atomic_int_set (&self->flushing, 0);
   self->prerolled = FALSE;
+  self->frames_lost = 0;
   return TRUE;
 }
 
@@ -1107,4 +1180,5 @@ gst_mi_bayer_element_instance_setup (GstMiBayerElement * self)
   g_mutex_init (&self->flow_lock);
   g_queue_init (&self->pending);
   g_queue_init (&self->ready);
+  g_queue_init (&self->quarantine);
 }

@@ -66,6 +66,9 @@ struct _GstMiBayerElement
   gint capacity;                /* frames the pool may hold in flight (shrinks when a device is dropped) */
   GQueue pending;               /* PendingFrame*, oldest first */
   GQueue ready;                 /* GstBuffer*: finished outputs collected early (the pool shrank), oldest first */
+  GQueue quarantine;            /* PendingFrame*: frames lost on a GPU that ran into the wait deadline; both buffers
+                                   stay mapped and referenced until the pool says the device has let go of them */
+  guint frames_lost;            /* since start */
   GMutex flow_lock;             /* pool / pending / ready: the streaming thread vs. FLUSH_START, which
                                    arrives on another thread */
   volatile gint flushing;       /* between FLUSH_START and FLUSH_STOP: nothing is submitted or pushed */

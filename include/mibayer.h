@@ -45,7 +45,11 @@ extern "C" {
 /* 3: additive over 2 -- deadlines on every host-side wait (MIBAYER_ERR_TIMEOUT,
  * mibayer_set_wait_timeout, mibayer_pool_set_wait_timeout); mibayer_sync /
  * mibayer_destroy wait for the context's own frames only. */
-#define MIBAYER_ABI_VERSION 3
+/* 4: additive over 3 -- the launch plan as a value (mibayer_get_plan / mibayer_set_plan /
+ * mibayer_plan_source), the process-wide plan cache behind mibayer_autotune and
+ * mibayer_create (mibayer_plan_cache_clear), mibayer_autotune_list, the host-wait
+ * policy (mibayer_set_wait_spin), MIBAYER_FLAG_HIPGRAPH_CHAIN, mibayer_is_lab_build. */
+#define MIBAYER_ABI_VERSION 4
 
 /* Bayer order; numbering identical to the reference's anonymous enum
  * GST_BAYER_2_RGB_FORMAT_*, gstbayer2rgb.c:95-101. */
@@ -115,11 +119,23 @@ typedef struct mibayer_cfg {
  * variant must be 0; mibayer_autotune / mibayer_fill_synthetic do not apply. */
 #define MIBAYER_FLAG_RGB2BAYER 2u
 
+/* With MIBAYER_FLAG_HIPGRAPH: the WHOLE upload -> kernel -> download chain of a
+ * ring slot as one graph on the slot's own queue (the host pointers are patched
+ * into the instantiated graph per frame) instead of the compute-queue segment
+ * only.  Measured slower at 4K (the copies of consecutive frames serialise per
+ * slot); kept as the A/B arm bench.py reports. */
+#define MIBAYER_FLAG_HIPGRAPH_CHAIN 4u
+
 typedef struct mibayer_ctx mibayer_ctx;
 
 /* ---- global ------------------------------------------------------------- */
 
 int mibayer_abi_version (void);
+/* 1 = this library was built with -DMIBAYER_LAB (`make lab`): the experiment
+ * kernel arms and the tuning environment variables of DESIGN.md are compiled in.
+ * 0 = the product build: the three production tile shapes with their store-policy
+ * twins, and no tuning environment. */
+int mibayer_is_lab_build (void);
 /* number of HIP devices, 0 if none (never negative) */
 int mibayer_device_count (void);
 const char *mibayer_strerror (int status);
@@ -160,6 +176,28 @@ int mibayer_pending (const mibayer_ctx *ctx);
  * A wait that runs into the deadline returns MIBAYER_ERR_TIMEOUT and leaves the
  * frame where it is -- its buffers still belong to the device. */
 int mibayer_set_wait_timeout (mibayer_ctx *ctx, int ms);
+/* How a host-side wait spends its time.  The completion event is polled: a tight
+ * loop for `spin_us` microseconds, then naps that double from 20 us to 250 us.
+ * spin_us < 0 (the default; also MIBAYER_WAIT_SPIN_US) = automatic: spin (up to
+ * 2 ms) only while the frame waited for is the only one in flight -- the
+ * synchronous 1-in/1-out use, where a nap's wake-up latency comes straight off
+ * the frame rate -- and nap from the start when other frames are queued behind
+ * it (they keep the device busy while the thread sleeps): a few wake-ups per
+ * frame instead of a core per streaming thread. */
+int mibayer_set_wait_spin (mibayer_ctx *ctx, int spin_us);
+/* Host CPU the context has cost its callers so far: calls and CPU time
+ * (CLOCK_THREAD_CPUTIME_ID of the calling threads) inside submit and inside the
+ * waits, the waits' wall time, hipEventQuery polls and naps. */
+typedef struct mibayer_host_stats {
+  uint64_t submits;
+  uint64_t waits;
+  uint64_t polls;
+  uint64_t naps;
+  double submit_cpu_ms;
+  double wait_cpu_ms;
+  double wait_wall_ms;
+} mibayer_host_stats;
+int mibayer_get_host_stats (const mibayer_ctx *ctx, mibayer_host_stats *out);
 
 /* ---- multi-GPU frame sharding (host path) ------------------------------------ */
 
@@ -221,6 +259,23 @@ int mibayer_pool_inject_fault (mibayer_pool *pool, int shard,
  * does not complete a frame within `ms` milliseconds is dropped from the rotation
  * like one that reported an error, and is never waited for again. */
 int mibayer_pool_set_wait_timeout (mibayer_pool *pool, int ms);
+int mibayer_pool_set_wait_spin (mibayer_pool *pool, int spin_us);
+/* sum over the shards */
+int mibayer_pool_get_host_stats (const mibayer_pool *pool, mibayer_host_stats *out);
+/* Frames that were IN FLIGHT on a device when it ran into the wait deadline are
+ * not converted again behind the device's back: the device may only be slow, its
+ * queued copies may still read the frame's source and write its destination
+ * later.  mibayer_pool_wait() hands such a frame back -- in order, with its tag --
+ * with MIBAYER_ERR_TIMEOUT: the frame is LOST (drop it), the stream carries on on
+ * the remaining devices (mibayer_pool_alive() == 0: it has failed), and both
+ * buffers of the frame stay the device's: do not free, unmap or reuse them until
+ * mibayer_pool_reclaim() hands the tag back -- it does once the device has caught
+ * up with everything it had queued (non-blocking; MIBAYER_ERR_EMPTY = none ready).
+ * mibayer_pool_lost() = lost frames not reclaimed yet.  Buffers still lost when
+ * the pool is destroyed must be leaked.  Frames the dropped device had not been
+ * given yet are converted on the others as after a device error. */
+int mibayer_pool_reclaim (mibayer_pool *pool, void **tag);
+int mibayer_pool_lost (const mibayer_pool *pool);
 /* Stall drill: the compute queue of shard `shard` is occupied for `ms`
  * milliseconds (1 .. 5000) by a kernel that only waits -- a device that has
  * stopped answering, as far as the host can tell. */
@@ -245,7 +300,12 @@ int mibayer_process_device_list (mibayer_ctx *ctx, const void *const *d_srcs,
     void *const *d_dsts, int nframes, void *hip_stream);
 /* the context's compute stream (a hipStream_t), created non-blocking */
 void *mibayer_ctx_stream (mibayer_ctx *ctx);
-/* waits for the context's own streams */
+/* Waits (with the context's deadline) for what THIS context has in flight: its
+ * pending host-path frames and the device-resident work queued through
+ * mibayer_process_device[_list] / mibayer_fill_synthetic on mibayer_ctx_stream().
+ * Work a caller put on that stream by other means (its own kernels, copies) is
+ * NOT covered -- the queue may be shared with the other contexts of the device --
+ * and neither is work on a caller-supplied stream: synchronise those yourself. */
 int mibayer_sync (mibayer_ctx *ctx);
 
 /* Times `reps` back-to-back launches of mibayer_process_device on the context's
@@ -272,18 +332,53 @@ int mibayer_autotune (mibayer_ctx *ctx, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     char *report, size_t report_len);
 
+/* The same over frames that are SEPARATE device allocations, timed through
+ * mibayer_process_device_list (what a device-resident element holds: one GstBuffer
+ * per frame). */
+int mibayer_autotune_list (mibayer_ctx *ctx, const void *const *d_srcs,
+    void *const *d_dsts, int nframes, char *report, size_t report_len);
+
 /* Copies the launch plan chosen by mibayer_autotune() to another context of the
  * same width/height (e.g. the same camera geometry in another Bayer order). */
 int mibayer_copy_plan (mibayer_ctx *dst, const mibayer_ctx *src);
+
+/* The launch plan as a value: kernel variant id (1 .. mibayer_variant_count()-1),
+ * block order (tile rows per XCD band: 1, N; 0 = identity; -1 = one chunk of the
+ * batch per XCD; INT32_MIN = the variant's default) and the store alignment of the
+ * shifted arm for generic geometries (0 = off, 64, 128).  Any out pointer may be
+ * NULL.  Every plan is bit-exact; a plan only changes speed. */
+int mibayer_get_plan (const mibayer_ctx *ctx, int *variant, int *band,
+    int *align_stores);
+int mibayer_set_plan (mibayer_ctx *ctx, int variant, int band, int align_stores);
+
+/* Process-wide plan cache.  mibayer_autotune / mibayer_autotune_list record what
+ * they measured under (device, width, height, src_stride, dst_stride);
+ * mibayer_create of a stream with that geometry on that device (cfg.variant == 0)
+ * starts from the recorded plan instead of the static default -- the second element
+ * instance, the context after a renegotiation, the other three Bayer orders of one
+ * camera do not measure again.  MIBAYER_PLAN_CACHE=0 in the environment turns
+ * look-ups and recording off.  Reference analogue (set up once per process, reuse):
+ * the once-guarded ORC programs, gst/bayer/gstbayerorc-dist.c:321-397. */
+#define MIBAYER_PLAN_DEFAULT 0  /* the static per-geometry default of mibayer_create */
+#define MIBAYER_PLAN_MEASURED 1 /* mibayer_autotune[_list] ran on this context       */
+#define MIBAYER_PLAN_CACHED 2   /* taken from the process plan cache at create       */
+#define MIBAYER_PLAN_SET 3      /* mibayer_set_plan / mibayer_copy_plan               */
+int mibayer_plan_source (const mibayer_ctx *ctx);
+void mibayer_plan_cache_clear (void);
 
 /* ---- memory helpers --------------------------------------------------------- */
 
 /* Pinned (hipHostMalloc) memory for buffer pools feeding the host path. */
 void *mibayer_host_alloc (size_t bytes);
-/* (once a wait of this process has run into its deadline -- MIBAYER_ERR_TIMEOUT --
- * blocks are no longer returned to the runtime: hipHostFree would wait for the
- * device that stopped answering) */
+/* (while a context of this process is wedged -- a wait ran into its deadline and
+ * the device has not caught up since -- the block goes on a deferred list instead
+ * of hipHostFree, which would wait for that device; the list is returned to the
+ * runtime as soon as no wedge is outstanding) */
 void mibayer_host_free (void *p);
+/* diagnostics: blocks on the deferred list / contexts whose device has not caught
+ * up after a wait deadline (both poll, neither blocks) */
+int mibayer_deferred_frees (void);
+int mibayer_wedged_contexts (void);
 /* The same, placed on the NUMA node next to HIP device `device` (the thread's
  * memory policy is set around a hipHostMallocNumaUser allocation): a pool that
  * feeds GPU k should not sit behind the socket link.  Falls back to

@@ -22,6 +22,12 @@
  * "placed" a block.  A failed context that still holds frames and was NOT abandoned writes them LATE, when it is
  * destroyed -- the DMA that a dead device's queue may still carry out -- so a pool that hands a re-done frame back
  * before abandoning the context it came from is a sanitizer report (the driver frees every frame on delivery).
+ * A context that stopped answering KEEPS the frames it holds (mibayer_internal_abandon returns
+ * MIBAYER_ERR_TIMEOUT for it) and carries them out late as well: when mibayer_internal_settled has been asked
+ * MOCK_MIBAYER_RESUME_POLLS times (default 3; -1 = never) the "device" resumes, reads their sources and writes their
+ * destinations, and only then reports settled -- or at destroy time at the latest.  A pool that converts such a
+ * frame again into the same buffers and hands it back, or a caller that releases the buffers of a lost frame before
+ * mibayer_pool_reclaim returned its tag, is a sanitizer report or a wrong stamp.
  */
 #include "mibayer.h"
 
@@ -68,6 +74,7 @@ struct mibayer_ctx
   int hung;
   int timeout_ms;               /* mibayer_set_wait_timeout; 0 = none */
   int abandoned;
+  int settle_polls;             /* mibayer_internal_settled calls since it stopped answering */
 };
 
 /* fake NUMA placement: blocks handed out by mibayer_host_alloc_near */
@@ -368,13 +375,60 @@ mibayer_internal_private_queues (mibayer_ctx * c)
   (void) c;                     /* the double has no queues */
 }
 
-void
+/* what a device that only stalled does when it comes back: the copies it had queued run after all */
+static void
+mock_late_writes (mibayer_ctx * c)
+{
+  while (c->count > 0) {
+    mock_frame fr = c->ring[c->head];
+
+    c->head = (c->head + 1) % MOCK_MAX_PENDING;
+    c->count--;
+    mock_convert (c, &fr);
+  }
+}
+
+int
 mibayer_internal_abandon (mibayer_ctx * c)
 {
-  if (c) {
-    c->count = 0;               /* whatever the dead device held is never written */
-    c->abandoned = 1;
-  }
+  if (!c)
+    return MIBAYER_OK;
+  c->abandoned = 1;
+  if (c->hung)
+    return c->count > 0 ? MIBAYER_ERR_TIMEOUT : MIBAYER_OK;    /* it keeps what it holds */
+  c->count = 0;                 /* whatever a dead device held is never written */
+  return MIBAYER_OK;
+}
+
+int
+mibayer_internal_settled (mibayer_ctx * c)
+{
+  const char *e = getenv ("MOCK_MIBAYER_RESUME_POLLS");
+  const int after = e ? atoi (e) : 3;
+
+  if (!c || !c->hung || c->count == 0)
+    return 1;
+  if (after < 0 || ++c->settle_polls < after)
+    return 0;
+  mock_late_writes (c);         /* the device resumes: into buffers the caller must still hold */
+  return 1;
+}
+
+int
+mibayer_set_wait_spin (mibayer_ctx * c, int spin_us)
+{
+  (void) spin_us;
+  return c ? MIBAYER_OK : MIBAYER_ERR_ARG;
+}
+
+int
+mibayer_get_host_stats (const mibayer_ctx * c, mibayer_host_stats * out)
+{
+  if (!c || !out)
+    return MIBAYER_ERR_ARG;
+  memset (out, 0, sizeof *out);
+  out->submits = (uint64_t) c->completed;
+  return MIBAYER_OK;
 }
 
 int
@@ -553,6 +607,8 @@ mibayer_destroy (mibayer_ctx * c)
     fprintf (stderr, "mock_mibayer: destroy would block for ever on a device that never answers\n");
     abort ();
   }
+  if (c->hung)
+    mock_late_writes (c);       /* a stalled device comes back when it likes: at the latest now */
   /* a failed device whose context was never abandoned still carries out what it had queued: late writes */
   while (c->dead && !c->abandoned && c->count > 0) {
     mock_frame fr = c->ring[c->head];

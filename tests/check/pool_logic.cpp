@@ -10,9 +10,12 @@
  * element's pinned pool does -- so the NUMA-local routing has something to look at; POOL_LOGIC_TIMEOUT_MS sets the
  * pool's wait deadline; POOL_LOGIC_STALL="shard" calls mibayer_pool_inject_stall on that shard after a few frames.
  * Every frame's buffers are freed the moment it has been delivered and checked: anything that touches them later
- * (a DMA of a context that should have been abandoned first) is a sanitizer report.
+ * (a DMA of a context that should have been abandoned first) is a sanitizer report.  A frame handed back as LOST
+ * (MIBAYER_ERR_TIMEOUT: it was in flight on a device that ran into the wait deadline) keeps its buffers until
+ * mibayer_pool_reclaim returns its tag -- the double's stalled device writes them late -- and the ones still lost
+ * at the end are released only after the pool is gone.
  *
- * Prints: delivered=<n> dropped_devices=<n> alive=<n> capacity=<n> rc=<last status> local=<n> remote=<n>
+ * Prints: delivered=<n> lost=<n> reclaimed=<n> dropped_devices=<n> alive=<n> capacity=<n> rc=<last status> local=<n> remote=<n>
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -93,9 +96,36 @@ main (int argc, char **argv)
   }
 
   int submitted = 0, delivered = 0, dropped = 0, last = MIBAYER_OK;
+  int handed = 0;               /* frames handed back so far, delivered or lost: the next tag is handed + 1 */
+  int lost = 0, reclaimed = 0;
   bool dead = false;
+  auto release = [&](int f) {
+    if (near_alloc) {
+      mibayer_host_free (srcs[(size_t) f]);
+      mibayer_host_free (dsts[(size_t) f]);
+    } else {
+      free (srcs[(size_t) f]);
+      free (dsts[(size_t) f]);
+    }
+    srcs[(size_t) f] = dsts[(size_t) f] = NULL;
+  };
+  auto reclaim = [&]() {
+    void *t = NULL;
+    while (mibayer_pool_reclaim (pool, &t) == MIBAYER_OK) {
+      const int f = (int) (intptr_t) t - 1;
+      if (f < 0 || f >= nframes || srcs[(size_t) f] == NULL)
+        exit (15);              /* a tag that was never lost, or twice */
+      /* the stalled device has written it after all: the stamp of ITS source */
+      for (size_t k = 4; k < dst_bytes; k++)
+        if (dsts[(size_t) f][k] != (uint8_t) (1 + f % 250))
+          exit (16);
+      release (f);
+      reclaimed++;
+    }
+  };
   auto collect = [&]() -> bool {
     void *tag = NULL;
+    reclaim ();
     const int r = mibayer_pool_wait (pool, &tag);
     char msg[300];
     int dev = -1, alive = -1;
@@ -106,26 +136,30 @@ main (int argc, char **argv)
       if (alive != mibayer_pool_alive (pool))
         exit (10);
     }
+    if (r == MIBAYER_ERR_TIMEOUT && tag != NULL && mibayer_pool_alive (pool) > 0) {
+      /* lost on a device that stopped answering: in order like any other frame, buffers kept */
+      if ((intptr_t) tag != handed + 1)
+        exit (11);
+      if (mibayer_pool_lost (pool) < 1)
+        exit (17);
+      handed++;
+      lost++;
+      return true;
+    }
     if (r != MIBAYER_OK) {
       last = r;
       return false;
     }
     /* oldest first, and converted from its own source */
-    if ((intptr_t) tag != delivered + 1)
+    if ((intptr_t) tag != handed + 1)
       exit (11);
-    const uint8_t *d = dsts[(size_t) delivered];
+    const uint8_t *d = dsts[(size_t) handed];
     for (size_t k = 4; k < dst_bytes; k++)
-      if (d[k] != (uint8_t) (1 + delivered % 250))
+      if (d[k] != (uint8_t) (1 + handed % 250))
         exit (12);
     /* handed back: the caller may release the buffers now */
-    if (near_alloc) {
-      mibayer_host_free (srcs[(size_t) delivered]);
-      mibayer_host_free (dsts[(size_t) delivered]);
-    } else {
-      free (srcs[(size_t) delivered]);
-      free (dsts[(size_t) delivered]);
-    }
-    srcs[(size_t) delivered] = dsts[(size_t) delivered] = NULL;
+    release (handed);
+    handed++;
     delivered++;
     return true;
   };
@@ -159,21 +193,18 @@ main (int argc, char **argv)
     int dev, alive;
     dropped += mibayer_pool_take_failure (pool, &dev, &alive, msg, sizeof msg);
   }
+  for (int k = 0; k < 8; k++)
+    reclaim ();                 /* the double's stalled devices resume after a few polls */
   int local = 0, remote = 0;
   mock_numa_counts (&local, &remote);
-  printf ("delivered=%d dropped_devices=%d alive=%d capacity=%d rc=%d local=%d remote=%d\n", delivered, dropped,
-      mibayer_pool_alive (pool), mibayer_pool_capacity (pool), last, local, remote);
-  mibayer_pool_destroy (pool);
-  for (int f = 0; f < nframes; f++) {
-    if (near_alloc) {
-      mibayer_host_free (srcs[(size_t) f]);
-      mibayer_host_free (dsts[(size_t) f]);
-    } else {
-      free (srcs[(size_t) f]);
-      free (dsts[(size_t) f]);
-    }
-  }
+  printf ("delivered=%d lost=%d reclaimed=%d dropped_devices=%d alive=%d capacity=%d rc=%d local=%d remote=%d\n",
+      delivered, lost, reclaimed, dropped, mibayer_pool_alive (pool), mibayer_pool_capacity (pool), last, local,
+      remote);
+  mibayer_pool_destroy (pool);  /* a device that never resumed does so now, at the latest: into buffers still held */
+  for (int f = 0; f < nframes; f++)
+    if (srcs[(size_t) f] != NULL)
+      release (f);
   if (expect_dead)
     return (dead && (last == MIBAYER_ERR_HIP || last == MIBAYER_ERR_TIMEOUT)) ? 0 : 20;
-  return (!dead && delivered == nframes) ? 0 : 21;
+  return (!dead && delivered + lost == nframes) ? 0 : 21;
 }

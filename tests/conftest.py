@@ -40,6 +40,35 @@ def gpu_pkg(pkg):
 
 
 @pytest.fixture(scope="session")
+def lab_pkg():
+    """The same harness over libmibayer_lab.so (`make lab`, -DMIBAYER_LAB): the experiment kernel arms and the tuning
+    environment variables that the product build does not carry."""
+    p = entry.load_package(lab=True)
+    if not os.path.exists(p.LIB_PATH):
+        p.build()
+    assert p.lib().mibayer_is_lab_build() == 1
+    return p
+
+
+@pytest.fixture(scope="session")
+def gpu_lab_pkg(lab_pkg):
+    if lab_pkg.device_count() < 1:
+        pytest.fail("GPU test selected but no HIP device is visible: the HIP path has no CPU fallback")
+    return lab_pkg
+
+
+@pytest.fixture(autouse=True)
+def _fresh_plan_cache():
+    """A plan one test measured (mibayer_autotune -> the process-wide plan cache) must not become another test's
+    default."""
+    for name in (entry.PKG_NAME, entry.PKG_NAME + "_lab"):
+        mod = sys.modules.get(name)
+        if mod is not None and getattr(mod, "_lib", None) is not None:
+            mod._lib.mibayer_plan_cache_clear()
+    yield
+
+
+@pytest.fixture(scope="session")
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "bayer2rgb_small.npz"))

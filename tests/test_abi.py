@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(pkg):
 
 def test_version_strerror_variants(pkg):
     L = pkg.lib()
-    assert L.mibayer_abi_version() == 3
+    assert L.mibayer_abi_version() == 4
     for code in range(-8, 1):
         assert L.mibayer_strerror(code)
     names = pkg.variant_names()
@@ -182,18 +182,43 @@ def test_auto_variant_minimises_wasted_lanes(pkg):
 
 def test_every_environment_knob_of_the_library_is_documented():
     """Every MIBAYER_* variable the native sources read is named in DESIGN.md, INTEGRATION.md or the ABI header: a knob
-    nobody can find is not a knob."""
+    nobody can find is not a knob.  Two lists: what the PRODUCT library reads -- operational
+    variables only -- and the tuning knobs that exist in the lab build alone (LAB_GETENV compiles to nothing without
+    -DMIBAYER_LAB)."""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "gst-plugins-bad_amd", "csrc")
-    used = set()
+    product, lab = set(), set()
     for name in os.listdir(csrc):
         with open(os.path.join(csrc, name)) as f:
-            used |= set(re.findall(r'getenv \("(MIBAYER_[A-Z0-9_]+)"\)', f.read()))
+            text = f.read()
+        product |= set(re.findall(r'(?<!LAB_)\bgetenv \("(MIBAYER_[A-Z0-9_]+)"\)', text))
+        lab |= set(re.findall(r'LAB_GETENV \("(MIBAYER_[A-Z0-9_]+)"\)', text))
     docs = ""
     for name in ("DESIGN.md", "INTEGRATION.md", os.path.join("include", "mibayer.h")):
         with open(os.path.join(root, name)) as f:
             docs += f.read()
-    assert len(used) >= 15
-    missing = sorted(v for v in used if v not in docs)
+    assert product == {"MIBAYER_ROCTX", "MIBAYER_WAIT_TIMEOUT_MS", "MIBAYER_WAIT_SPIN_US", "MIBAYER_PLAN_CACHE",
+                       "MIBAYER_POOL_THREADS", "MIBAYER_POOL_HELPERS", "MIBAYER_POOL_NUMA", "MIBAYER_POOL_PIN_THREADS",
+                       "MIBAYER_INJECT_FAULT", "MIBAYER_INJECT_STALL"}, sorted(product)
+    assert len(lab) >= 12 and not (lab & product), sorted(lab & product)
+    missing = sorted(v for v in product | lab if v not in docs)
     assert not missing, missing
+
+
+def test_product_and_lab_builds(pkg, lab_pkg):
+    """the default library is the lean one -- the three production tile shapes with their plain-store
+    and hybrid-store twins, under 300 KB -- and `make lab` adds the experiment arms behind the same ABI; the first ten
+    variant ids mean the same in both."""
+    L, LL = pkg.lib(), lab_pkg.lib()
+    if os.environ.get("MIBAYER_LIB_PATH"):
+        pytest.skip("MIBAYER_LIB_PATH overrides the product library")
+    assert L.mibayer_is_lab_build() == 0 and LL.mibayer_is_lab_build() == 1
+    names, lab_names = pkg.variant_names(), lab_pkg.variant_names()
+    assert len(names) == 10 and len(lab_names) > 20 and lab_names[:10] == names
+    assert names[1:4] == ["lds_4x2_r4_dpp_nt", "lds_2x4_r4_dpp_nt", "lds_1x8_r4_dpp_nt"]
+    assert names[4:7] == ["lds_4x2_r4_dpp", "lds_2x4_r4_dpp", "lds_1x8_r4_dpp"]
+    assert names[7:10] == ["lds_4x2_r4_dpp_hy", "lds_2x4_r4_dpp_hy", "lds_1x8_r4_dpp_hy"]
+    assert os.path.getsize(pkg.LIB_PATH) < 300 * 1024, os.path.getsize(pkg.LIB_PATH)
+    for name in pkg.ABI:
+        assert hasattr(LL, name), name

@@ -117,12 +117,14 @@ def test_strides_and_padding(gpu_pkg, oracle):
 
 
 @pytest.mark.parametrize("bands", ["", "1", "3", "8"], ids=["default", "1", "3", "8"])
-def test_banded_synchronous_host_path(gpu_pkg, oracle, bands, monkeypatch):
+def test_banded_synchronous_host_path(gpu_lab_pkg, oracle, bands, monkeypatch):
     """Frames of 16 MB and more go through the synchronous host path in horizontal bands (upload of band b+1, kernel
     of band b and download of band b-1 overlap inside one frame).  Every band count gives the reference's bytes: the
     halo rows across band boundaries, the top row (up(0) = 1) and the bottom rows (dn(H-1) = H-4) included; heights
     that are no multiple of the tile height; padded destination rows (2-D download); the queued use of the same
-    context (which does not band) in between."""
+    context (which does not band) in between.  (MIBAYER_HOST_BANDS is a knob of the lab build; the product build runs
+    the "default" arm, covered by the full-size tests.)"""
+    gpu_pkg = gpu_lab_pkg
     if bands:
         monkeypatch.setenv("MIBAYER_HOST_BANDS", bands)
     else:
@@ -619,7 +621,7 @@ def test_config5_4k_stream_pinned_double_buffered_ring(gpu_pkg, oracle, mechanis
     w, h, n, chunk = 3840, 2160, 72, 12
     flags = 0 if mechanism == "streams" else gpu_pkg.FLAG_HIPGRAPH
     if mechanism == "hipgraph_chain":
-        monkeypatch.setenv("MIBAYER_GRAPH_MODE", "chain")
+        flags |= gpu_pkg.FLAG_HIPGRAPH_CHAIN
     L = gpu_pkg.lib()
     r, g, b = gpu_pkg.FORMATS["BGRx"]
     srcs = [_pinned(L, w * h, (h, w)) for _ in range(2)]
@@ -647,7 +649,7 @@ def test_config5_4k_stream_pinned_double_buffered_ring(gpu_pkg, oracle, mechanis
         L.mibayer_host_free(p)
 
 
-def test_list_launch_over_separately_allocated_frames(gpu_pkg, oracle):
+def test_list_launch_over_separately_allocated_frames(gpu_pkg, gpu_lab_pkg, oracle):
     """mibayer_process_device_list: one launch per 16 frames that are separate device allocations (hipbayer2rgb
     batch=N).  21 frames (split 16 + 5), every Bayer order; then with one pointer only 4-byte aligned (the generic
     kernel takes the launch) and for a width that always needs the generic kernel."""
@@ -678,8 +680,9 @@ def test_list_launch_over_separately_allocated_frames(gpu_pkg, oracle):
         rgb = np.random.default_rng(64).integers(0, 256, (n, h, 4 * w), dtype=np.uint8)
         if flat is not None:
             os.environ["MIBAYER_R2B_FLAT"] = flat
-        try:
-            ctx_cm = gpu_pkg.Context(w, h, pat, (1, 2, 3), flags=gpu_pkg.FLAG_RGB2BAYER)
+        try:                # (the tile-kernel arm is a knob of the lab build)
+            ctx_cm = (gpu_lab_pkg if flat is not None else gpu_pkg).Context(w, h, pat, (1, 2, 3),
+                                                                             flags=gpu_pkg.FLAG_RGB2BAYER)
         finally:
             os.environ.pop("MIBAYER_R2B_FLAT", None)
         with ctx_cm as ctx:
@@ -772,12 +775,15 @@ def test_guard_bands_around_the_destination_stay_intact(gpu_pkg, oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("align", ["0", "64", "128"])
-def test_sector_aligned_store_arm(gpu_pkg, oracle, align, monkeypatch):
+def test_sector_aligned_store_arm(gpu_lab_pkg, oracle, align, monkeypatch):
     """Generic geometries whose output rows start off the 64-byte sector grid (width % 16 != 0, padded pitches,
     destinations at odd offsets): the per-row lane shift of bayer2rgb_lds_aligned_kernel -- every wave-store on a
     64- / 128-byte boundary, the columns in front of the first boundary as the row's head -- against the oracle, with
     guard bands, for every production shape and its plain-store twin, single frames, batches whose frame pitch moves
-    the phase from frame to frame, and list launches.  MIBAYER_ALIGN_STORES=0 is the unshifted generic arm."""
+    the phase from frame to frame, and list launches.  MIBAYER_ALIGN_STORES=0 is the unshifted generic arm.  (Lab build:
+    the forced alignment is a tuning knob; the product build reaches the 128-byte arm through mibayer_set_plan and
+    the autotuner, test_shifted_arm_through_set_plan below.)"""
+    gpu_pkg = gpu_lab_pkg
     monkeypatch.setenv("MIBAYER_ALIGN_STORES", align)
     rng = np.random.default_rng(314)
     guard = 4096
@@ -832,6 +838,44 @@ def test_sector_aligned_store_arm(gpu_pkg, oracle, align, monkeypatch):
                     assert (out[:guard + off] == 0xC3).all() and (out[guard + off + total:] == 0xC3).all(), key
                 ctx.device_free(d_src)
                 ctx.device_free(d_all)
+
+
+@pytest.mark.gpu
+def test_shifted_arm_through_set_plan(gpu_pkg, oracle):
+    """The product build's way to the sector-aligned arm (no tuning environment): mibayer_set_plan (variant, band,
+    128) -- what mibayer_autotune picks among and what the plan cache hands to later contexts -- on generic geometries
+    with guard bands; plans that do not exist (64-byte flavour, shapes without the arm) are refused."""
+    rng = np.random.default_rng(2718)
+    names = gpu_pkg.variant_names()
+    guard = 2048
+    for (w, h, pad, off, n) in ((4056, 9, 0, 0, 2), (3838, 10, 0, 8, 1), (1366, 11, 0, 0, 3), (1030, 33, 0, 120, 2),
+                                (258, 35, 0, 0, 4)):
+        sstride, dstride = (w + 3) & ~3, 4 * w + pad
+        src = rng.integers(0, 256, (n, h, sstride), dtype=np.uint8)
+        want = np.stack([oracle.bayer2rgb(src[f], w, "grbg", 2, 1, 0) for f in range(n)])
+        for vname in ("lds_2x4_r4_dpp_nt", "lds_1x8_r4_dpp_nt"):
+            for band in (0, 1):
+                with gpu_pkg.Context(w, h, "grbg", "BGRx", src_stride=sstride, dst_stride=dstride) as ctx:
+                    ctx.set_plan(names.index(vname), band, 128)
+                    assert ctx.get_plan() == (names.index(vname), band, 128) and ctx.plan_source == gpu_pkg.PLAN_SET
+                    total = n * ctx.dst_bytes
+                    d_src = ctx.device_alloc(n * ctx.src_bytes)
+                    d_all = ctx.device_alloc(total + 2 * guard + 128)
+                    ctx.to_device(d_src, src)
+                    ctx.to_device(d_all, np.full(total + 2 * guard + 128, 0xC3, np.uint8))
+                    ctx.process_device(d_src, d_all + guard + off, n)
+                    ctx.sync()
+                    out = ctx.from_device(d_all, total + 2 * guard + 128)
+                    assert (out[:guard + off] == 0xC3).all() and (out[guard + off + total:] == 0xC3).all()
+                    body = out[guard + off: guard + off + total].reshape(n, h, dstride)
+                    assert np.array_equal(body[:, :, :4 * w], want), (w, h, vname, band)
+                    ctx.device_free(d_src)
+                    ctx.device_free(d_all)
+    with gpu_pkg.Context(4056, 16, "grbg", "BGRx") as ctx:
+        for bad in ((names.index("lds_1x8_r4_dpp_nt"), 0, 64), (names.index("lds_1x8_r4_dpp_hy"), 0, 128),
+                    (0, 0, 0), (len(names), 0, 0), (1, 0, 32)):
+            with pytest.raises(gpu_pkg.MibayerError):
+                ctx.set_plan(*bad)
 
 
 GRAPH_SCRIPT = r"""
@@ -989,7 +1033,17 @@ assert status_of(ctx.wait) == pkg.ERR_TIMEOUT
 assert status_of(ctx.submit, host_src, host_dst, 2) == pkg.ERR_TIMEOUT
 ctx.close()
 assert time.monotonic() - t0 < 0.3                          # nothing waited for the stalled device
+# per-device, not for ever (ADVICE r03): while the device has not caught up, ONE wedge is outstanding and a pinned
+# block handed back is parked on the deferred list instead of hipHostFree (which would wait for that device)
+assert L.mibayer_wedged_contexts() == 1
+p_tmp, _ = pinned(4096, (4096,))
+t0 = time.monotonic()
+L.mibayer_host_free(p_tmp)
+assert time.monotonic() - t0 < 0.2 and L.mibayer_deferred_frees() == 1
 time.sleep(1.6)                                             # the drill ends; the late DMA lands in host_dst
+# the device has caught up: the wedge settles by itself, the orphaned ring of the destroyed context and the parked
+# block are released (polled from here, from create / destroy / host_free; nothing blocks)
+assert L.mibayer_wedged_contexts() == 0 and L.mibayer_deferred_frees() == 0
 with pkg.Context(w, h, "rggb", "BGRx") as ctx2:
     assert np.array_equal(ctx2.process_host(src), want)
 # destroy itself is what finds the device stalled (a frame in flight, nobody waited for it): bounded, and the
@@ -1008,8 +1062,10 @@ with pkg.Context(w, h, "rggb", "BGRx", inflight=2) as ctx4:     # queued behind 
     ctx4.set_wait_timeout(5000)
     assert np.array_equal(ctx4.process_host(src_b), oracle.bayer2rgb(src_b, w, "rggb", 2, 1, 0))
 assert np.array_equal(host_dst, want)                       # the abandoned frame did land, late, where it belonged
+assert L.mibayer_wedged_contexts() == 0
 L.mibayer_host_free(p_src)
 L.mibayer_host_free(p_dst)
+assert L.mibayer_deferred_frees() == 0                      # really freed: no wedge is outstanding any more
 print("wait deadline drill ok")
 """
 
@@ -1019,8 +1075,8 @@ def test_wait_deadline_on_a_stalled_device(gpu_pkg):
     does not hang), the context is wedged from then on -- every later call returns at once -- and destroying it
     does not block either.  The stall drill (csrc/mibayer_hooks.h) ends by itself; afterwards the device converts
     bit-exactly again."""
-    # in a process of its own: once a wait has hit its deadline the library stops returning pinned blocks to the
-    # runtime for the rest of the process (mibayer_host_free), which the other tests of this run should not inherit
+    # in a process of its own: a context that is still wedged when the process ends leaves its ring to the wedge
+    # registry, which the other tests of this run should not inherit
     res = subprocess.run([sys.executable, "-c", WAIT_DEADLINE_SCRIPT, ROOT], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0 and "wait deadline drill ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
 
@@ -1044,6 +1100,7 @@ hd = pinned(want.size, want.shape); hd[...] = 0
 def stream(stall_at):
     sub = got = 0
     status = pkg.OK
+    lost = []
     with pkg.Pool([0, 0], w, h, "grbg", "RGBx", inflight=2) as pool:
         pool.set_wait_timeout(150)
         t0 = time.monotonic()
@@ -1060,28 +1117,42 @@ def stream(stall_at):
                     except pkg.MibayerError as e:
                         if e.status != pkg.ERR_BUSY:
                             raise
-                tag = pool.wait()
+                try:
+                    tag = pool.wait()
+                except pkg.FrameLost as e:      # in flight on the stalled shard: dropped, in order, buffers quarantined
+                    tag = e.tag
+                    lost.append(tag)
                 assert tag == got + 1, (tag, got)
                 got += 1
         except pkg.MibayerError as e:
             status = e.status
         dt = time.monotonic() - t0
         nf, dev, alive, msg = pool.take_failure()
+        still_lost = pool.lost()
         t1 = time.monotonic()
-    return got, status, dt, time.monotonic() - t1, nf, alive, msg
-got, status, dt, dt_destroy, nf, alive, msg = stream(6)
+    return got, status, dt, time.monotonic() - t1, nf, alive, msg, lost, still_lost
+got, status, dt, dt_destroy, nf, alive, msg, lost, still_lost = stream(6)
 # ONE device: the stalled shard's copies sit at the head of the device's DMA engines, so its twin stalls with it --
 # what this run must show is that nothing hangs: the stream ends with a status, in bounded time
 assert dt < 1.5 and dt_destroy < 0.5, (dt, dt_destroy)
 assert status in (pkg.OK, pkg.ERR_HIP, pkg.ERR_TIMEOUT), status
 assert nf >= 1 and ("did not" in msg or "deadline" in msg), (nf, msg)
-assert np.array_equal(hd[:got], want[:got])
+delivered = [f for f in range(got) if f + 1 not in lost]
+assert all(np.array_equal(hd[f], want[f]) for f in delivered)
+assert still_lost == len(lost)                      # nothing was handed back while the device held it
+assert L.mibayer_wedged_contexts() >= 1
 time.sleep(2.7)                                     # the drill ends; late DMAs land in hd, which is still ours
+assert L.mibayer_wedged_contexts() == 0             # ... and the wedges settle by themselves
+# ADVICE r03: frames that were in flight on the stalled device were NOT converted again behind its back and handed
+# back; their quarantined destinations now hold what the late download wrote -- their own frame
+for tag in lost:
+    assert np.array_equal(hd[tag - 1], want[tag - 1]), tag
 hd[...] = 0
-got2, status2, dt2, _, nf2, alive2, _ = stream(-1)
-assert got2 == n and status2 == pkg.OK and nf2 == 0
+got2, status2, dt2, _, nf2, alive2, _, lost2, _ = stream(-1)
+assert got2 == n and status2 == pkg.OK and nf2 == 0 and not lost2
 assert np.array_equal(hd, want)
-print("pool stall drill ok: %d frames before the stall took the device, status %d after %.3f s (%s)" % (got, status, dt, msg))
+print("pool stall drill ok: %d frames handed back (%d lost) before the stall took the device, status %d after %.3f s (%s)"
+      % (got, len(lost), status, dt, msg))
 """
 
 
@@ -1091,10 +1162,13 @@ def test_pool_never_hangs_on_a_shard_that_stops_answering(gpu_pkg):
     its twin's copies queue behind it (two logical shards meet again in the DMA engines and hardware queues; two
     real GPUs do not, and the survivor logic is exercised on the context double under ASan / TSan,
     tests/test_pool_logic.py).  What must hold on real HIP calls: every wait is bounded, the stream ends with a
-    status instead of hanging, the frames delivered before are bit-exact and in order, mibayer_pool_destroy does not
-    block on the wedged contexts, and once the stall is over a new pool converts everything."""
+    status instead of hanging, the frames delivered before are bit-exact and in order, the frames that were in flight
+    on the stalled device come back LOST instead of being converted again behind its back (their late downloads land in
+    the quarantined buffers), mibayer_pool_destroy does not block on the wedged contexts, the wedges settle by
+    themselves once the stall is over, and a new pool then converts everything."""
     res = subprocess.run([sys.executable, "-c", POOL_STALL_SCRIPT, ROOT], capture_output=True, text=True,
-                         timeout=120, env=dict(os.environ, MIBAYER_SHARED_QUEUES="0"))
+                         timeout=120, env=dict(os.environ, MIBAYER_SHARED_QUEUES="0",
+                                               MIBAYER_LIB_PATH=gpu_pkg.LAB_LIB_PATH))     # (a knob of the lab build)
     assert res.returncode == 0 and "pool stall drill ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
 
 

@@ -29,10 +29,12 @@ def test_rgb2bayer_matches_oracle_all_sizes(gpu_pkg, oracle):
 
 @pytest.mark.parametrize("shape", ["0:2", "0:8", "1:4", "2:8", "4:4", "4:8", "8:8"])
 @pytest.mark.parametrize("ldnt", ["0", "1"])
-def test_rgb2bayer_every_launch_shape_is_bit_exact(gpu_pkg, oracle, shape, ldnt, monkeypatch):
-    """The tile kernel (flat = 0, rows per block) and every flat-kernel shape (groups per thread : pixels per group,
+def test_rgb2bayer_every_launch_shape_is_bit_exact(gpu_lab_pkg, oracle, shape, ldnt, monkeypatch):
+    """(Lab build: the launch shapes are MIBAYER_R2B_* knobs; the product build carries the measured one.)
+    The tile kernel (flat = 0, rows per block) and every flat-kernel shape (groups per thread : pixels per group,
     with and without the nt hint on the loads), in both block orders, on sizes that exercise row-straddling waves,
     odd dword counts per row (8-pixel groups fall back to 4), padded strides, partial last dwords and batches."""
+    gpu_pkg = gpu_lab_pkg
     flat, px = shape.split(":")
     monkeypatch.setenv("MIBAYER_R2B_FLAT", flat)
     monkeypatch.setenv("MIBAYER_R2B_ROWS" if flat == "0" else "MIBAYER_R2B_PX", px)
@@ -55,9 +57,10 @@ def test_rgb2bayer_every_launch_shape_is_bit_exact(gpu_pkg, oracle, shape, ldnt,
 
 
 @pytest.mark.parametrize("bands", ["", "1", "3", "8"], ids=["default", "1", "3", "8"])
-def test_rgb2bayer_banded_synchronous_host_path(gpu_pkg, oracle, bands, monkeypatch):
+def test_rgb2bayer_banded_synchronous_host_path(gpu_lab_pkg, oracle, bands, monkeypatch):
     """Frames of 16 MB input and more go through the synchronous host path in horizontal bands (16-row units), like
     bayer2rgb's: same bytes for every band count, odd heights, padded source rows; queued use stays unbanded."""
+    gpu_pkg = gpu_lab_pkg         # MIBAYER_HOST_BANDS is a knob of the lab build
     if bands:
         monkeypatch.setenv("MIBAYER_HOST_BANDS", bands)
     else:

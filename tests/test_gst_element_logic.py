@@ -179,16 +179,22 @@ def test_stride_change_without_caps_event_finishes_the_frames_in_flight_first(ri
 
 def test_a_gpu_that_stops_answering_is_dropped_after_timeout_ms(rig, tmp_path):
     """timeout-ms: with two shards the one that stops answering (MOCK_MIBAYER_HANG) leaves the rotation after the
-    deadline -- ONE warning, every frame out in order, EOS drains, nothing hangs; with a single device the stream
-    errors out instead of hanging.  The double aborts on any wait without a deadline on the hung context."""
+    deadline -- ONE warning, EOS drains, nothing hangs.  The frames that were IN FLIGHT on it (at most `inflight`)
+    are dropped, not converted again behind its back, and their buffers stay quarantined -- the double's device
+    resumes later and writes them, a released buffer would be a sanitizer report; every other frame
+    comes out, in order.  With a single device the stream errors out instead of hanging.  The double aborts on any
+    wait without a deadline on the hung context."""
     w, h, n = 64, 48, 14
     inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
     frames(n, w * h, first=5).tofile(inp)
-    kv = run(rig, "convert", "bayer2rgb inflight=2 devices=0,0 timeout-ms=30", B2R % ("bggr", w, h), inp, w * h, outp,
-             extra_env={"MOCK_MIBAYER_HANG": "0:3"})
-    assert kv["pushed"] == str(n) and kv["pulled"] == str(n) and kv["warnings"] == "1" and kv["errors"] == "0"
-    _, fill = stamps(outp, n, 4 * w * h)
-    assert fill == list(range(5, 5 + n))
+    for resume in ("3", "-1"):          # the device comes back while the stream runs / never
+        kv = run(rig, "convert", "bayer2rgb inflight=2 devices=0,0 timeout-ms=30", B2R % ("bggr", w, h), inp, w * h, outp,
+                 extra_env={"MOCK_MIBAYER_HANG": "0:3", "MOCK_MIBAYER_RESUME_POLLS": resume})
+        pulled = int(kv["pulled"])
+        assert kv["pushed"] == str(n) and n - 2 <= pulled < n and kv["warnings"] == "1" and kv["errors"] == "0", kv
+        _, fill = stamps(outp, pulled, 4 * w * h)
+        assert fill == sorted(fill) and len(set(fill)) == pulled and set(fill) <= set(range(5, 5 + n)), fill
+        assert fill[:3] == [5, 6, 7]    # what completed before the stall
     # flush while the hung device still holds frames: dropped, no hang
     kv = run(rig, "flush", "bayer2rgb inflight=3 devices=0,0 timeout-ms=30", B2R % ("bggr", w, h), inp, w * h, outp, 6,
              extra_env={"MOCK_MIBAYER_HANG": "1:2"})

@@ -111,19 +111,27 @@ def test_randomised_scenarios(driver):
 
 @pytest.mark.parametrize("pageable", [False, True], ids=["pinned", "pageable"])
 def test_a_device_that_stops_answering_is_dropped_after_the_deadline(driver, pageable):
-    """MOCK_MIBAYER_HANG: the context's waits run into the deadline (MIBAYER_ERR_TIMEOUT).  The pool treats that
-    like a device error -- the shard leaves the rotation, its frames are converted again elsewhere, order is kept,
-    ONE note -- and never waits for that context again (the double aborts on a wait without deadline, and on the
-    destroy of a hung context that was not abandoned)."""
+    """MOCK_MIBAYER_HANG: the context's waits run into the deadline (MIBAYER_ERR_TIMEOUT).  The shard leaves the
+    rotation, ONE note, and the pool never waits for that context again (the double aborts on a wait without deadline,
+    and on the destroy of a hung context that was not abandoned).  What the stalled device had IN FLIGHT is not
+    converted again behind its back: those frames come back LOST, in order, at most `inflight` of them per
+    stalled shard, their buffers stay quarantined until mibayer_pool_reclaim hands the tags back -- the double's
+    device resumes after a few polls and writes them late, into buffers the driver must still hold -- and every
+    other frame is delivered."""
     env = {"MOCK_MIBAYER_HANG": "1:3", "POOL_LOGIC_TIMEOUT_MS": "30"}
     kv, err = run(driver, 4, 2, 60, pageable, "-", "ok", env=env)
-    assert kv["delivered"] == "60" and kv["dropped_devices"] == "1" and kv["alive"] == "3"
-    assert err.count("note:") == 1 and "dropped from the rotation" in err
+    assert int(kv["delivered"]) + int(kv["lost"]) == 60 and 1 <= int(kv["lost"]) <= 2, kv
+    assert kv["reclaimed"] == kv["lost"] and kv["dropped_devices"] == "1" and kv["alive"] == "3"
+    assert err.count("note:") == 1 and "dropped from the rotation" in err and "in flight on it lost" in err
     # two of three stop answering at different times; hang and error mixed
     kv, _ = run(driver, 3, 2, 50, pageable, "-", "ok", env={"MOCK_MIBAYER_HANG": "0:2,2:7", "POOL_LOGIC_TIMEOUT_MS": "20"})
-    assert kv["delivered"] == "50" and kv["alive"] == "1"
+    assert int(kv["delivered"]) + int(kv["lost"]) == 50 and 2 <= int(kv["lost"]) <= 4 and kv["alive"] == "1", kv
     kv, _ = run(driver, 4, 3, 70, pageable, "3:4", "ok", env={"MOCK_MIBAYER_HANG": "1:5", "POOL_LOGIC_TIMEOUT_MS": "20"})
-    assert kv["delivered"] == "70" and kv["alive"] == "2"
+    assert int(kv["delivered"]) + int(kv["lost"]) == 70 and 1 <= int(kv["lost"]) <= 3 and kv["alive"] == "2", kv
+    # a device that never comes back: the lost buffers stay quarantined to the end (released after the pool is gone)
+    kv, _ = run(driver, 4, 2, 40, pageable, "-", "ok",
+                env={"MOCK_MIBAYER_HANG": "2:4", "POOL_LOGIC_TIMEOUT_MS": "20", "MOCK_MIBAYER_RESUME_POLLS": "-1"})
+    assert int(kv["delivered"]) + int(kv["lost"]) == 40 and int(kv["lost"]) >= 1 and kv["reclaimed"] == "0", kv
     # every device hangs: the stream ends with the timeout status, nothing blocks
     kv, _ = run(driver, 2, 2, 30, pageable, "-", "dead", env={"MOCK_MIBAYER_HANG": "0:3,1:5", "POOL_LOGIC_TIMEOUT_MS": "20"})
     assert kv["alive"] == "0" and kv["rc"] in ("-9", "-5")
@@ -131,7 +139,8 @@ def test_a_device_that_stops_answering_is_dropped_after_the_deadline(driver, pag
 
 def test_stall_drill_through_the_pool_api(driver):
     kv, err = run(driver, 3, 2, 40, False, "-", "ok", env={"POOL_LOGIC_STALL": "2", "POOL_LOGIC_TIMEOUT_MS": "25"})
-    assert kv["delivered"] == "40" and kv["alive"] == "2" and err.count("note:") == 1
+    assert int(kv["delivered"]) + int(kv["lost"]) == 40 and int(kv["lost"]) <= 2, kv
+    assert kv["alive"] == "2" and err.count("note:") == 1
 
 
 @pytest.mark.parametrize("threads", ["0", "1"], ids=["streaming_thread", "thread_per_shard"])
