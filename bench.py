@@ -278,21 +278,19 @@ def parity_spot_check(pkg, ctxs, d_src, d_dst, rank, world, stream):
     return "bit-exact vs oracle on frames %d and %d of the batch (rggb->%s)" % (0, BATCH - 1, FORMAT)
 
 
-def host_path_rate(pkg, device, frames=24, inflight=3, flags=0, graph_mode=None):
+def host_path_rate(pkg, device, frames=24, inflight=3, flags=0, graph_mode=None, stats=None):
     """PCIe-inclusive rate of the host path (hipHostMalloc-pinned buffers, async ring).  flags=FLAG_HIPGRAPH: the
     compute-queue segment of every slot (wait for the upload -> kernel -> signal the download) is a captured graph,
     one hipGraphLaunch per frame, the copies stay on the copy queues; graph_mode="chain": the A/B arm that puts the
-    whole H2D -> kernel -> D2H chain of a slot into one graph on the slot's own queue.  Returns (Mpix/s, seconds)."""
+    whole H2D -> kernel -> D2H chain of a slot into one graph on the slot's own queue (MIBAYER_FLAG_HIPGRAPH_CHAIN).
+    `stats` (a dict) receives the host CPU the timed frames cost (mibayer_get_host_stats).
+    Returns (Mpix/s, seconds)."""
     import ctypes
     import numpy as np
     L = pkg.lib()
-    if graph_mode:
-        os.environ["MIBAYER_GRAPH_MODE"] = graph_mode
-    try:
-        ctx_cm = pkg.Context(WIDTH, HEIGHT, "rggb", FORMAT, device=device, inflight=inflight, flags=flags)
-    finally:
-        os.environ.pop("MIBAYER_GRAPH_MODE", None)
-    with ctx_cm as ctx:
+    if graph_mode == "chain":
+        flags |= pkg.FLAG_HIPGRAPH | pkg.FLAG_HIPGRAPH_CHAIN
+    with pkg.Context(WIDTH, HEIGHT, "rggb", FORMAT, device=device, inflight=inflight, flags=flags) as ctx:
         srcs, dsts = [], []
         for _ in range(inflight):
             # pinned staging on the NUMA node next to THIS rank's GPU (on a two-socket 8-GPU node half the ranks
@@ -306,6 +304,7 @@ def host_path_rate(pkg, device, frames=24, inflight=3, flags=0, graph_mode=None)
             dsts.append((pd, d))
         for phase in ("warm", "timed"):
             n = 2 * inflight if phase == "warm" else frames
+            before = ctx.host_stats()
             t0 = time.perf_counter()
             for i in range(n):
                 if ctx.pending() == inflight:
@@ -314,6 +313,13 @@ def host_path_rate(pkg, device, frames=24, inflight=3, flags=0, graph_mode=None)
             while ctx.pending():
                 ctx.wait()
             el = time.perf_counter() - t0
+        if stats is not None:
+            after = ctx.host_stats()
+            stats.update({"submit_cpu_us_per_frame": round((after["submit_cpu_ms"] - before["submit_cpu_ms"]) * 1e3 / frames, 1),
+                          "wait_cpu_us_per_frame": round((after["wait_cpu_ms"] - before["wait_cpu_ms"]) * 1e3 / frames, 1),
+                          "wait_wall_us_per_frame": round((after["wait_wall_ms"] - before["wait_wall_ms"]) * 1e3 / frames, 1),
+                          "polls_per_frame": round((after["polls"] - before["polls"]) / frames, 1),
+                          "naps_per_frame": round((after["naps"] - before["naps"]) / frames, 1)})
         for (ps, _), (pd, _) in zip(srcs, dsts):
             L.mibayer_host_free(ps)
             L.mibayer_host_free(pd)
@@ -322,13 +328,16 @@ def host_path_rate(pkg, device, frames=24, inflight=3, flags=0, graph_mode=None)
 
 def host_path_note(pkg, device):
     host_path_rate(pkg, device, 12, 3, 0)       # first touch of the copy queues and the PCIe link: not measured
-    plain, _ = host_path_rate(pkg, device, 24, 3, 0)
+    cpu = {}
+    plain, _ = host_path_rate(pkg, device, 24, 3, 0, stats=cpu)
     graph, _ = host_path_rate(pkg, device, 24, 3, pkg.FLAG_HIPGRAPH)
     chain, _ = host_path_rate(pkg, device, 24, 3, pkg.FLAG_HIPGRAPH, "chain")
     return {"value": round(max(plain, graph), 1), "unit": "Mpix/s", "streams_and_events": round(plain, 1),
             "hipgraph_captured_launch": round(graph, 1), "hipgraph_whole_chain_per_slot": round(chain, 1),
+            "host_cpu": cpu,
             "note": "host->host incl. H2D + D2H over PCIe, hipHostMalloc-pinned buffers, 3 frames in flight, 24 4K "
-                    "frames; bound by PCIe (5 B/pixel over a Gen5 x16 link), not HBM; never `value`"}
+                    "frames; bound by PCIe (5 B/pixel over a Gen5 x16 link), not HBM; never `value`; host_cpu = CPU "
+                    "time of the submitting / waiting thread per frame (streams+events arm)"}
 
 
 def build_hash():

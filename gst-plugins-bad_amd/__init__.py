@@ -148,6 +148,7 @@ ABI = {
                                         ctypes.POINTER(ctypes.c_int)]),
     "mibayer_set_plan": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mibayer_plan_source": (ctypes.c_int, [_vp]),
+    "mibayer_plan_from_cache": (ctypes.c_int, [_vp]),
     "mibayer_plan_cache_clear": (None, []),
     "mibayer_host_alloc": (_vp, [ctypes.c_size_t]),
     "mibayer_host_free": (None, [_vp]),
@@ -496,6 +497,11 @@ class Context:
     def set_plan(self, variant, band, align=0):
         _check(lib().mibayer_set_plan(self._h, variant, band, align), "mibayer_set_plan")
         self.variant_name = lib().mibayer_ctx_variant_name(self._h).decode()
+
+    def plan_from_cache(self):
+        hit = lib().mibayer_plan_from_cache(self._h) == 1
+        self.variant_name = lib().mibayer_ctx_variant_name(self._h).decode()
+        return hit
 
     @property
     def plan_source(self):

@@ -2174,6 +2174,15 @@ extern "C" void mibayer_plan_cache_clear (void)
   g_plans.clear ();
 }
 
+extern "C" int mibayer_plan_from_cache (mibayer_ctx *c)
+{
+  if (!c)
+    return MIBAYER_ERR_ARG;
+  if (c->band_forced || !c->align_tunable)      /* (lab builds) a plan pinned from the environment stays */
+    return 0;
+  return plan_cache_load (c) ? 1 : 0;
+}
+
 extern "C" int mibayer_plan_source (const mibayer_ctx *c)
 {
   return c ? c->plan_source : MIBAYER_ERR_ARG;

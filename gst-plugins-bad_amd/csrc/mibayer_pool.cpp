@@ -456,6 +456,12 @@ extern "C" int mibayer_pool_create (const mibayer_pool_cfg *cfg,
     for (Shard *sh : pool->shards)
       sh->ring_room = pool->per_shard;
   }
+  /* More than one shard: whenever a frame is waited for, the other shards hold queued work, so no wait ever needs to
+   * spin for latency's sake (mibayer_set_wait_spin; a context on its own cannot know that its neighbours are busy).
+   * MIBAYER_WAIT_SPIN_US in the environment still decides. */
+  if (pool->shards.size () > 1 && getenv ("MIBAYER_WAIT_SPIN_US") == NULL)
+    for (Shard *sh : pool->shards)
+      (void) mibayer_set_wait_spin (sh->ctx, 0);
   /* one shard: a helper would only add a hand-off */
   pool->use_helpers = pool->shards.size () > 1;
   if (const char *e = getenv ("MIBAYER_POOL_HELPERS"))

@@ -39,7 +39,9 @@ enum
   PROP_0,
   PROP_DEVICE_ID,
   PROP_ASYNC,
-  PROP_BATCH
+  PROP_BATCH,
+  PROP_AUTOTUNE,
+  PROP_PLAN
 };
 
 /* bytes of one frame for either media type; same rules as bayer2rgb's
@@ -779,6 +781,9 @@ typedef struct
   /* batch mode (property "batch" > 1): input / output buffer pairs waiting for ONE launch over all of
    * them, and converted outputs waiting to be handed to the base class one by one */
   gint batch;
+  gint autotune;                /* property "autotune": measure the launch plan on the first frames (g_atomic_int_*) */
+  gboolean tuned;               /* the context's plan has been settled: measured, or taken from the process cache */
+  gchar plan[160];              /* property "plan" (read-only): the context's launch plan and where it came from */
   gboolean prerolled;           /* a frame has left since start / flush: batching may begin */
   GQueue waiting;               /* Hb2rPair* */
   GQueue ready;                 /* GstBuffer* */
@@ -849,6 +854,9 @@ hb2r_set_property (GObject * object, guint prop_id, const GValue * value,
   else if (prop_id == PROP_BATCH)
     g_atomic_int_set (&((GstMiHipBayer2RGB *) object)->batch,
         g_value_get_int (value));
+  else if (prop_id == PROP_AUTOTUNE)
+    g_atomic_int_set (&((GstMiHipBayer2RGB *) object)->autotune,
+        g_value_get_boolean (value) ? 1 : 0);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
 }
@@ -863,7 +871,14 @@ hb2r_get_property (GObject * object, guint prop_id, GValue * value,
   else if (prop_id == PROP_BATCH)
     g_value_set_int (value,
         g_atomic_int_get (&((GstMiHipBayer2RGB *) object)->batch));
-  else
+  else if (prop_id == PROP_AUTOTUNE)
+    g_value_set_boolean (value,
+        g_atomic_int_get (&((GstMiHipBayer2RGB *) object)->autotune) != 0);
+  else if (prop_id == PROP_PLAN) {
+    GST_OBJECT_LOCK (object);
+    g_value_set_string (value, ((GstMiHipBayer2RGB *) object)->plan);
+    GST_OBJECT_UNLOCK (object);
+  } else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
 }
 
@@ -1004,6 +1019,23 @@ hb2r_device_of (GstMiHipBayer2RGB * self, GstBuffer * inbuf, gint * device)
   return TRUE;
 }
 
+/* the context's plan, for the read-only "plan" property and the debug log */
+static void
+hb2r_note_plan (GstMiHipBayer2RGB * self)
+{
+  static const char *const source[] = { "default", "measured", "cached", "set" };
+  int variant = 0, band = 0, align = 0;
+  const int src = mibayer_plan_source (self->ctx);
+
+  (void) mibayer_get_plan (self->ctx, &variant, &band, &align);
+  GST_OBJECT_LOCK (self);
+  g_snprintf (self->plan, sizeof self->plan, "%s band=%d align=%d source=%s",
+      mibayer_ctx_variant_name (self->ctx), band == G_MININT32 ? -999 : band, align,
+      (src >= 0 && src < 4) ? source[src] : "?");
+  GST_OBJECT_UNLOCK (self);
+  GST_INFO_OBJECT (self, "launch plan: %s", self->plan);
+}
+
 static gboolean
 hb2r_ensure_ctx (GstMiHipBayer2RGB * self, gint device)
 {
@@ -1032,7 +1064,43 @@ hb2r_ensure_ctx (GstMiHipBayer2RGB * self, gint device)
     return FALSE;
   }
   self->ctx_device = device;
+  self->tuned = FALSE;
+  hb2r_note_plan (self);
   return TRUE;
+}
+
+/* Property "autotune" (additive, default off): the launch plan of this stream geometry is measured once, on the
+ * first frame(s) the element converts -- mibayer_autotune_list over the very device buffers it holds (the kernel is
+ * idempotent, so the outputs are right whichever candidate ran last) -- and recorded in the library's process-wide
+ * plan cache; every later context of that geometry on that device, in this element or another, starts from the
+ * measured plan without measuring (the reference sets its ORC programs up once per process the same way,
+ * gst/bayer/gstbayerorc-dist.c:321-397).  Costs ~0.1-0.2 s of the first frame's latency.  The caller has ordered
+ * the context's stream after the buffers' last accesses. */
+static void
+hb2r_autotune_once (GstMiHipBayer2RGB * self, const void *const *srcs,
+    void *const *dsts, guint n)
+{
+  char report[1024] = "";
+  int rc;
+
+  if (self->tuned || HB2R_INVERSE (self))
+    return;
+  self->tuned = TRUE;
+  if (mibayer_plan_source (self->ctx) != MIBAYER_PLAN_DEFAULT)
+    return;                     /* the process cache had a plan when the context was created */
+  if (mibayer_plan_from_cache (self->ctx) == 1) {
+    hb2r_note_plan (self);      /* ... or has one now: another element measured since */
+    return;
+  }
+  if (!g_atomic_int_get (&self->autotune))
+    return;                     /* nobody asked */
+  rc = mibayer_autotune_list (self->ctx, srcs, dsts, (int) n, report, sizeof report);
+  if (rc != MIBAYER_OK) {
+    GST_WARNING_OBJECT (self, "plan measurement failed (%s); the default plan stays", mibayer_strerror (rc));
+    return;
+  }
+  hb2r_note_plan (self);
+  GST_INFO_OBJECT (self, "plan measured on %u frame(s): %s [%s]", n, self->plan, report);
 }
 
 /* output frames come from the element's own device-memory pool on the device of
@@ -1146,6 +1214,12 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
     gst_mi_hip_memory_wait ((GstMiHipMemory *) in_mem);
     gst_mi_hip_memory_wait ((GstMiHipMemory *) out_mem);
   }
+  {
+    const void *one_src = in_map.data;
+    void *one_dst = out_map.data;
+
+    hb2r_autotune_once (self, &one_src, &one_dst, 1);
+  }
   /* device-resident call: no PCIe traffic at all */
   rc = mibayer_process_device (self->ctx, in_map.data, 0, out_map.data, 0, 1,
       stream);
@@ -1216,6 +1290,8 @@ hb2r_convert_waiting (GstMiHipBayer2RGB * self)
     srcs[i] = in_map[i].data;
     dsts[i] = out_map[i].data;
   }
+  if (ret == GST_FLOW_OK && n >= (guint) MIN (MAX (g_atomic_int_get (&self->batch), 1), HB2R_MAX_BATCH))
+    hb2r_autotune_once (self, srcs, dsts, n);   /* on a full batch: what the steady state launches */
   rc = ret == GST_FLOW_OK
       ? mibayer_process_device_list (self->ctx, srcs, dsts, (int) n, stream)
       : MIBAYER_OK;
@@ -1368,6 +1444,20 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
           "launch per 4K frame costs about as much as the kernel runs.  The "
           "first frame after a start or flush is never held back (preroll)",
           1, HB2R_MAX_BATCH, 1, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (object_class, PROP_AUTOTUNE,
+      g_param_spec_boolean ("autotune", "Measure the launch plan",
+          "Measure the kernel launch plan (tile shape, block order, store policy) "
+          "once on the first frame(s) of a stream geometry and record it in the "
+          "process-wide plan cache; later contexts of that geometry on that GPU "
+          "-- in any element -- take the measured plan without measuring.  Off: "
+          "the static default plan, or the cached one if some element measured "
+          "before.  No effect on hiprgb2bayer",
+          FALSE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (object_class, PROP_PLAN,
+      g_param_spec_string ("plan", "Launch plan",
+          "The launch plan of the current stream and where it came from "
+          "(default / measured / cached)", "",
+          G_PARAM_READABLE | G_PARAM_STATIC_STRINGS));
   xfer_add_templates (element_class, HB2R_SINK_CAPS, HB2R_SRC_CAPS);
   gst_element_class_set_static_metadata (element_class,
       "Bayer to RGB decoder (HIP device memory)", "Filter/Converter/Video",
@@ -1394,6 +1484,9 @@ gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
   self->out_pool = NULL;
   self->out_pool_device = 0;
   self->batch = 1;
+  self->autotune = 0;
+  self->tuned = FALSE;
+  self->plan[0] = '\0';
   self->prerolled = FALSE;
   g_queue_init (&self->waiting);
   g_queue_init (&self->ready);

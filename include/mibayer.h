@@ -364,6 +364,9 @@ int mibayer_set_plan (mibayer_ctx *ctx, int variant, int band, int align_stores)
 #define MIBAYER_PLAN_CACHED 2   /* taken from the process plan cache at create       */
 #define MIBAYER_PLAN_SET 3      /* mibayer_set_plan / mibayer_copy_plan               */
 int mibayer_plan_source (const mibayer_ctx *ctx);
+/* Looks the context's geometry up in the cache again (a plan may have been measured
+ * since the context was created): 1 = a cached plan was applied, 0 = none. */
+int mibayer_plan_from_cache (mibayer_ctx *ctx);
 void mibayer_plan_cache_clear (void);
 
 /* ---- memory helpers --------------------------------------------------------- */

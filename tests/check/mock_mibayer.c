@@ -58,6 +58,8 @@ static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;     /* elements and h
 static uint32_t g_seq;          /* host-path frames submitted since the first context of a pool was created */
 static int g_live_host_ctx;     /* contexts alive: the counter restarts with every new pool */
 static int g_created;           /* contexts created so far == index of the next one (fault injection) */
+static int g_plan_cached;       /* a context of this process ran mibayer_autotune_list: later ones report "cached" */
+static int g_autotunes;
 
 struct mibayer_ctx
 {
@@ -75,6 +77,7 @@ struct mibayer_ctx
   int timeout_ms;               /* mibayer_set_wait_timeout; 0 = none */
   int abandoned;
   int settle_polls;             /* mibayer_internal_settled calls since it stopped answering */
+  int plan_source;              /* MIBAYER_PLAN_* */
 };
 
 /* fake NUMA placement: blocks handed out by mibayer_host_alloc_near */
@@ -543,6 +546,7 @@ mibayer_create (const mibayer_cfg * cfg, mibayer_ctx ** out)
   c->fail_after = -1;
   c->hang_after = -1;
   c->timeout_ms = 10000;
+  c->plan_source = g_plan_cached ? MIBAYER_PLAN_CACHED : MIBAYER_PLAN_DEFAULT;
   pthread_mutex_lock (&g_lock);
   if (g_live_host_ctx++ == 0)
     g_seq = 0;                  /* a new pool stamps its frames from 0 */
@@ -622,6 +626,63 @@ mibayer_destroy (mibayer_ctx * c)
   g_live_host_ctx--;
   pthread_mutex_unlock (&g_lock);
   free (c);
+}
+
+/* ---- launch plans: the double has one, "measured" once somebody asks for it ---- */
+
+int
+mibayer_plan_source (const mibayer_ctx * c)
+{
+  return c ? c->plan_source : MIBAYER_ERR_ARG;
+}
+
+int
+mibayer_plan_from_cache (mibayer_ctx * c)
+{
+  if (!c)
+    return MIBAYER_ERR_ARG;
+  if (!g_plan_cached)
+    return 0;
+  c->plan_source = MIBAYER_PLAN_CACHED;
+  return 1;
+}
+
+int
+mibayer_get_plan (const mibayer_ctx * c, int *variant, int *band, int *align_stores)
+{
+  if (!c)
+    return MIBAYER_ERR_ARG;
+  if (variant)
+    *variant = 1;
+  if (band)
+    *band = c->plan_source == MIBAYER_PLAN_DEFAULT ? 1 : 0;
+  if (align_stores)
+    *align_stores = 0;
+  return MIBAYER_OK;
+}
+
+const char *
+mibayer_ctx_variant_name (const mibayer_ctx * c)
+{
+  return c ? "mock_plan" : NULL;
+}
+
+int
+mibayer_autotune_list (mibayer_ctx * c, const void *const *d_srcs, void *const *d_dsts, int nframes, char *report,
+    size_t report_len)
+{
+  if (!c || !d_srcs || !d_dsts || nframes < 1)
+    return MIBAYER_ERR_ARG;
+  pthread_mutex_lock (&g_lock);
+  g_plan_cached = 1;
+  g_autotunes++;
+  pthread_mutex_unlock (&g_lock);
+  c->plan_source = MIBAYER_PLAN_MEASURED;
+  if (report && report_len)
+    snprintf (report, report_len, "mock autotune over %d frame(s)", nframes);
+  if (getenv ("MOCK_MIBAYER_LOG_AUTOTUNE"))
+    fprintf (stderr, "mock_mibayer: autotune #%d over %d frame(s)\n", g_autotunes, nframes);
+  return MIBAYER_OK;
 }
 
 void *

@@ -255,6 +255,36 @@ def test_device_memory_elements_honour_the_last_access_event(rig, tmp_path):
     assert kv["cycles_ok"] == "3"
 
 
+def test_autotune_property_measures_once_and_later_contexts_take_the_cached_plan(rig, tmp_path):
+    """hipbayer2rgb autotune=true measures the launch plan ONCE, on the first frame (frame by frame) or on the first full
+    batch (batch=N), with the device buffers it holds; the second converter of the same pipeline -- created after the
+    first one measured -- starts from the cached plan and does not measure; without the property nothing is measured.
+    Every frame still comes out once, in order (the double counts mibayer_autotune_list calls)."""
+    w, h, n = 64, 48, 10
+    inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
+    frames(n, w * h, first=11).tofile(inp)
+    exe, env, _ = rig
+    chain = "hipupload ! hipbayer2rgb %s ! hiprgb2bayer ! hipbayer2rgb %s ! hipdownload"
+    for props, frames_measured in (("autotune=true", 1), ("autotune=true batch=4", 4)):
+        res = subprocess.run([exe, "convert", chain % (props, props),
+                              B2R % ("bggr", w, h), str(inp), str(w * h), str(outp)], capture_output=True, text=True,
+                             env=dict(env, MOCK_MIBAYER_LOG_AUTOTUNE="1", GST_DEBUG="mihip:4"), timeout=120)
+        out = res.stdout + res.stderr
+        assert res.returncode == 0 and "AddressSanitizer" not in out, out[-3000:]
+        assert out.count("mock_mibayer: autotune #") == 1, out[-3000:]
+        assert "autotune #1 over %d frame(s)" % frames_measured in out
+        assert out.count("plan measured on") == 1 and "source=cached" in out and "source=measured" in out
+        kv = dict(item.split("=") for item in res.stdout.split() if "=" in item and item.count("=") == 1)
+        assert kv["pushed"] == str(n) and kv["pulled"] == str(n)
+        _, fill = stamps(outp, n, 4 * w * h)
+        assert len(fill) == n
+    res = subprocess.run([exe, "convert", chain % ("", ""), B2R % ("bggr", w, h), str(inp), str(w * h), str(outp)],
+                         capture_output=True, text=True, env=dict(env, MOCK_MIBAYER_LOG_AUTOTUNE="1", GST_DEBUG="mihip:4"),
+                         timeout=120)
+    assert res.returncode == 0 and "autotune #" not in res.stdout + res.stderr
+    assert "source=default" in res.stdout + res.stderr
+
+
 def test_device_memory_rgb2bayer_shares_the_converter_logic(rig, tmp_path):
     """hiprgb2bayer = hipbayer2rgb with the pad roles swapped (a subclass whose class carries the direction): frame
     by frame and batched, every frame once, in order, mosaic-sized output, last-access events honoured."""
