@@ -364,6 +364,149 @@ def test_config4_8k_batch64_per_gpu_share(gpu_pkg, oracle):
         ctx.device_free(d_dst)
 
 
+def test_config4_and_5_every_ranks_share(gpu_pkg, oracle):
+    """not only rank 0's share of the two 8-GPU configs.  configs[3] (7680x4320, 512 frames over 8
+    GPUs): for every rank 1..7 the first and the last frame of its share -- global frames r and r + 8*63, seed 3 --
+    are generated on the device the way bench.py does (frame-index-addressed, so a wrong g -> rank map shows) and
+    converted, and compared with the oracle.  configs[4] (1000 frames over 8 GPUs): shard_frames() gives every rank
+    its 125 frames, g % 8 == r, and one frame per rank (its last) goes through the hipGraph host path."""
+    import bench
+    w, h, world = 7680, 4320, 8
+    r_, g_, b_ = oracle.LAYOUTS["RGBx"]
+    with gpu_pkg.Context(w, h, "bggr", "RGBx") as ctx:
+        d_src = ctx.device_alloc(2 * ctx.src_bytes)
+        d_dst = ctx.device_alloc(2 * ctx.dst_bytes)
+        for rank in range(1, world):
+            share = bench.shard_frames(512, world, rank)
+            assert len(share) == 64 and share[0] == rank and share[-1] == rank + 8 * 63
+            for k, gframe in enumerate((share[0], share[-1])):
+                ctx.fill_synthetic(d_src + k * ctx.src_bytes, 1, seed=3, first_frame=gframe)
+            ctx.process_device(d_src, d_dst, 2)
+            ctx.sync()
+            for k, gframe in enumerate((share[0], share[-1])):
+                src = oracle.fill_synthetic(w, h, 1, 3, first_frame=gframe)[0]
+                assert np.array_equal(ctx.from_device(d_src + k * ctx.src_bytes, ctx.src_bytes), src.reshape(-1))
+                want = oracle.bayer2rgb(src, w, "bggr", r_, g_, b_).reshape(-1)
+                assert np.array_equal(ctx.from_device(d_dst + k * ctx.dst_bytes, ctx.dst_bytes), want), (rank, gframe)
+        ctx.device_free(d_src)
+        ctx.device_free(d_dst)
+    w, h = 3840, 2160
+    r_, g_, b_ = oracle.LAYOUTS["BGRx"]
+    shares = [bench.shard_frames(1000, world, rank) for rank in range(world)]
+    assert [len(s_) for s_ in shares] == [125] * 8 and sorted(f for s_ in shares for f in s_) == list(range(1000))
+    with gpu_pkg.Context(w, h, "rggb", "BGRx", inflight=2, flags=gpu_pkg.FLAG_HIPGRAPH) as ctx:
+        for rank, share in enumerate(shares):
+            assert all(f % world == rank for f in share)
+            src = oracle.fill_synthetic(w, h, 1, 2, first_frame=share[-1])[0]
+            assert np.array_equal(ctx.process_host(src), oracle.bayer2rgb(src, w, "rggb", r_, g_, b_)), rank
+
+
+def test_plan_cache_hands_the_measured_plan_to_later_contexts(gpu_pkg, oracle):
+    """what mibayer_autotune measured is kept per (device, geometry) for the process; the next context
+    of that geometry starts from it (plan_source CACHED) without measuring, other geometries do not, the bytes are
+    the oracle's before and after, a context created earlier can pick the plan up (mibayer_plan_from_cache), and
+    mibayer_plan_cache_clear() / MIBAYER_PLAN_CACHE=0 bring the default back."""
+    w, h, n = 1920, 1080, 8
+    L = gpu_pkg.lib()
+    L.mibayer_plan_cache_clear()
+    src = oracle.fill_synthetic(w, h, n, seed=5)
+    want = oracle.bayer2rgb_batch(src, w, "rggb", 2, 1, 0, nthreads=4)
+    with gpu_pkg.Context(w, h, "rggb", "BGRx") as first, gpu_pkg.Context(w, h, "gbrg", "BGRx") as early:
+        assert first.plan_source == gpu_pkg.PLAN_DEFAULT and early.plan_source == gpu_pkg.PLAN_DEFAULT
+        default_plan = first.get_plan()
+        assert np.array_equal(first.process_batch_via_device(src), want)
+        d_src = first.device_alloc(n * first.src_bytes)
+        d_dst = first.device_alloc(n * first.dst_bytes)
+        first.to_device(d_src, src)
+        report = first.autotune(d_src, d_dst, n)
+        assert first.plan_source == gpu_pkg.PLAN_MEASURED and "band" in report
+        measured = first.get_plan()
+        assert np.array_equal(first.from_device(d_dst, n * first.dst_bytes).reshape(want.shape), want)
+        # a later context of the same geometry (another Bayer order: same kernel): the measured plan, not measured again
+        with gpu_pkg.Context(w, h, "bggr", "RGBx") as second:
+            assert second.plan_source == gpu_pkg.PLAN_CACHED and second.get_plan() == measured
+            assert np.array_equal(second.process_batch_via_device(src[:2]),
+                                  oracle.bayer2rgb_batch(src[:2], w, "bggr", 0, 1, 2, nthreads=2))
+        # one created before the measurement picks it up on request
+        assert early.get_plan() == default_plan and early.plan_from_cache() and early.get_plan() == measured
+        assert early.plan_source == gpu_pkg.PLAN_CACHED
+        # another geometry, another stride: not this entry
+        with gpu_pkg.Context(w, h + 2, "rggb", "BGRx") as other, \
+                gpu_pkg.Context(w, h, "rggb", "BGRx", dst_stride=4 * w + 64) as padded:
+            assert other.plan_source == gpu_pkg.PLAN_DEFAULT and padded.plan_source == gpu_pkg.PLAN_DEFAULT
+            assert not other.plan_from_cache()
+        # an explicit variant is never overridden
+        with gpu_pkg.Context(w, h, "rggb", "BGRx", variant=3) as pinned:
+            assert pinned.plan_source == gpu_pkg.PLAN_DEFAULT and pinned.variant_name == "lds_1x8_r4_dpp_nt"
+        # the list form measures over separate allocations and records too
+        L.mibayer_plan_cache_clear()
+        with gpu_pkg.Context(w, h, "rggb", "BGRx") as third:
+            assert third.plan_source == gpu_pkg.PLAN_DEFAULT
+            srcs = [d_src + f * third.src_bytes for f in range(4)]
+            dsts = [d_dst + f * third.dst_bytes for f in range(4)]
+            third.autotune_list(srcs, dsts)
+            assert third.plan_source == gpu_pkg.PLAN_MEASURED
+            assert np.array_equal(third.from_device(d_dst, 4 * third.dst_bytes).reshape(want[:4].shape), want[:4])
+            with gpu_pkg.Context(w, h, "rggb", "BGRx") as fourth:
+                assert fourth.plan_source == gpu_pkg.PLAN_CACHED and fourth.get_plan() == third.get_plan()
+        L.mibayer_plan_cache_clear()
+        with gpu_pkg.Context(w, h, "rggb", "BGRx") as again:
+            assert again.plan_source == gpu_pkg.PLAN_DEFAULT and again.get_plan() == default_plan
+        first.device_free(d_src)
+        first.device_free(d_dst)
+    code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as e; p = e.load_package(); "
+            "c = p.Context(640, 480, 'rggb', 'BGRx'); d = c.device_alloc(c.src_bytes); o = c.device_alloc(c.dst_bytes); "
+            "c.fill_synthetic(d, 1, 1); c.autotune(d, o, 1); c2 = p.Context(640, 480, 'rggb', 'BGRx'); "
+            "print('source', c2.plan_source)" % ROOT)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, MIBAYER_PLAN_CACHE="0"))
+    assert res.returncode == 0 and "source 0" in res.stdout, res.stdout + res.stderr[-1500:]
+
+
+def test_host_waits_nap_when_other_frames_are_queued(gpu_pkg, oracle):
+    """VERDICT r03 #4 / ADVICE r03: a wait spins only while the frame waited for is alone in flight; with other frames
+    queued behind it the thread naps (a few wake-ups per frame), so the CPU spent waiting per frame falls far below the
+    frame time, at an unchanged frame rate; mibayer_set_wait_spin() pins either behaviour; results stay the oracle's."""
+    import time
+    w, h, n = 3840, 2160, 60
+    L = gpu_pkg.lib()
+    src = oracle.fill_synthetic(w, h, 1, seed=8)[0]
+    want = oracle.bayer2rgb(src, w, "rggb", 2, 1, 0)
+    bufs = [(_pinned(L, w * h, (h, w)), _pinned(L, 4 * w * h, (h, 4 * w))) for _ in range(3)]
+    for (ps, s_), _ in bufs:
+        s_[...] = src
+
+    def stream(inflight, spin):
+        with gpu_pkg.Context(w, h, "rggb", "BGRx", inflight=inflight) as ctx:
+            ctx.set_wait_spin(spin)
+            for phase in range(2):              # the first pass warms the ring and the link
+                before = ctx.host_stats()
+                t0 = time.perf_counter()
+                for i in range(n):
+                    if ctx.pending() == inflight:
+                        ctx.wait()
+                    ctx.submit(bufs[i % inflight][0][1], bufs[i % inflight][1][1], tag=i + 1)
+                while ctx.pending():
+                    ctx.wait()
+                dt = time.perf_counter() - t0
+            after = ctx.host_stats()
+        assert all(np.array_equal(bufs[k][1][1], want) for k in range(inflight))
+        d = {k: after[k] - before[k] for k in after}
+        return n / dt, d["wait_cpu_ms"] * 1e3 / n, d["wait_wall_ms"] * 1e3 / n, d["polls"] / n, d["naps"] / n
+
+    fps_spin, cpu_spin, wall_spin, polls_spin, _ = stream(3, 1000000)     # every wait spins (what round 3 did)
+    fps_auto, cpu_auto, wall_auto, polls_auto, naps_auto = stream(3, -1)  # automatic: other frames are queued -> naps
+    fps_sync, cpu_sync, wall_sync, _, naps_sync = stream(1, -1)           # synchronous use: alone in flight -> spins
+    assert cpu_spin > 0.7 * wall_spin                       # spinning: the wait costs its wall time in CPU
+    assert cpu_auto < 0.5 * cpu_spin and naps_auto >= 1.0, (cpu_auto, cpu_spin, naps_auto)
+    assert polls_auto < 0.2 * polls_spin
+    assert fps_auto > 0.95 * fps_spin, (fps_auto, fps_spin)
+    assert naps_sync < 0.5 and cpu_sync > 0.5 * wall_sync   # latency first when nothing else is in flight
+    for (ps, _), (pd, _) in bufs:
+        L.mibayer_host_free(ps)
+        L.mibayer_host_free(pd)
+
+
 def _pinned(L, nbytes, shape):
     import ctypes
     p = L.mibayer_host_alloc(nbytes)

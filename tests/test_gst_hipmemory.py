@@ -160,3 +160,32 @@ def test_upload_download_is_identity_on_raw_video(plugin, gpu_pkg, tmp_path):
                  "t. ! queue ! filesink location=%s t. ! queue ! hipupload ! hipdownload ! filesink location=%s" % (a, b))
     assert res.returncode == 0, res.stderr[-2000:]
     assert os.path.getsize(a) > 0 and open(a, "rb").read() == open(b, "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("props", ["autotune=true", "autotune=true batch=4"])
+def test_autotune_property_and_the_process_plan_cache(plugin, gpu_pkg, oracle, tmp_path, props):
+    """VERDICT r03 #5 at element level on real hardware: two hipbayer2rgb instances of ONE geometry in one pipeline
+    (hipbayer2rgb ! hiprgb2bayer ! hipbayer2rgb, device memory all the way).  The first measures its launch plan on
+    the buffers of its first frame / first full batch (mibayer_autotune_list); the second reports that very plan as
+    `cached` and measures nothing; the bytes that come out are the oracle's -- rgb2bayer of a demosaiced frame gives
+    the mosaic back, so the chain equals one bayer2rgb -- before and after the plan changes."""
+    w, h, n = 1920, 1080, 24
+    inp, outp = str(tmp_path / "in.raw"), str(tmp_path / "out.raw")
+    res = launch(tmp_path,
+                 "videotestsrc num-buffers=%d pattern=snow ! video/x-bayer,format=rggb,width=%d,height=%d,framerate=30/1 "
+                 "! tee name=t t. ! queue ! filesink location=%s t. ! queue ! hipupload ! hipbayer2rgb %s name=first "
+                 "! video/x-raw(memory:HIPMemory),format=ARGB ! hiprgb2bayer ! video/x-bayer(memory:HIPMemory),format=rggb "
+                 "! hipbayer2rgb %s name=second ! hipdownload ! video/x-raw,format=BGRx ! filesink location=%s"
+                 % (n, w, h, inp, props, props, outp), debug="mihip:4")
+    assert res.returncode == 0, res.stderr[-3000:]
+    src = np.fromfile(inp, np.uint8).reshape(n, h, w)
+    got = np.fromfile(outp, np.uint8).reshape(n, h, 4 * w)
+    assert np.array_equal(got, oracle.bayer2rgb_batch(src, w, "rggb", 2, 1, 0, nthreads=4))
+    log = res.stderr
+    measured = [ln for ln in log.splitlines() if "plan measured on" in ln]
+    assert len(measured) == 1 and "<first>" in measured[0], log[-3000:]
+    cached = [ln for ln in log.splitlines() if "launch plan:" in ln and "source=cached" in ln]
+    assert cached and all("<second>" in ln for ln in cached), log[-3000:]
+    plan = measured[0].split("plan measured on")[1].split(":", 1)[1].split("source=")[0].strip()
+    assert plan and all(plan in ln for ln in cached), (plan, cached)
