@@ -419,6 +419,8 @@ def measure_traffic(plan, launches=8, timeout_s=120.0):
     rocprof = find_rocprofv3()
     if rocprof is None:
         return None, "rocprofv3 not on PATH"
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "this run is itself profiled (rocprofv3 wraps it): no nested profiler"
     t_start = time.perf_counter()
     tmp = tempfile.mkdtemp(prefix="mibayer_traffic_", dir=os.environ.get("TMPDIR", "/tmp"))
     env = {k: v for k, v in os.environ.items()

@@ -16,13 +16,13 @@ echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | ta
 echo "== bench (the driver's arguments)"; timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | tee $O/bench.json | cut -c1-600
 cd /tmp
 echo "== rocprof stats (same command as the bench line, fewer steps)"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-host-path 2>&1 | grep -v "^W20" | tail -1 | cut -c1-300
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-host-path --no-traffic 2>&1 | grep -v "^W20" | tail -1 | cut -c1-300
 # HBM-side traffic, separate --pmc passes, for the THREE block orders the autotuner chooses between
 # (forced with MIBAYER_XCD_BAND, autotune off), plus the calibration probe
 for c in FETCH_SIZE WRITE_SIZE; do
   for plan in band1:1 chunk:-1 identity:0; do
     name=${plan%%:*}; band=${plan##*:}
-    MIBAYER_XCD_BAND=$band timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_bench_${name}_$c -o $TAG -- python $R/bench.py --steps 8 --warmup 2 --prewarm-ms 0 --no-cpu --no-host-path --no-autotune 2>&1 | grep -v "^W20" | tail -1 | cut -c1-120
+    MIBAYER_LIB_PATH=$R/gst-plugins-bad_amd/libmibayer_lab.so MIBAYER_XCD_BAND=$band timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_bench_${name}_$c -o $TAG -- python $R/bench.py --steps 8 --warmup 2 --prewarm-ms 0 --no-cpu --no-host-path --no-autotune --no-traffic 2>&1 | grep -v "^W20" | tail -1 | cut -c1-120
   done
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_probe_$c -o $TAG -- $R/tools/hbm_probe 2 32768 2>&1 | grep -v "^W20" | tail -1
 done

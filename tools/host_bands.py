@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import __graft_entry__ as entry  # noqa: E402
 
-pkg = entry.load_package()
+pkg = entry.load_package(lab=True)    # the tuning knobs exist in the lab build only (make lab)
 L = pkg.lib()
 
 

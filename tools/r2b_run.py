@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
-pkg = entry.load_package()
+pkg = entry.load_package(lab=True)    # the tuning knobs exist in the lab build only (make lab)
 W, H, N = 3840, 2160, 64
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 with pkg.Context(W, H, "rggb", (1, 2, 3), flags=pkg.FLAG_RGB2BAYER) as ctx:

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
-pkg = entry.load_package()
+pkg = entry.load_package(lab=True)    # the tuning knobs exist in the lab build only (make lab)
 W, H, N = 3840, 2160, 64
 args = sys.argv[1:]
 if args and "x" in args[0]:

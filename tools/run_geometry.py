@@ -20,7 +20,7 @@ ap.add_argument("--variant", default="auto")
 ap.add_argument("--pattern", default="rggb")
 ap.add_argument("--fmt", default="BGRx")
 a = ap.parse_args()
-pkg = entry.load_package()
+pkg = entry.load_package(lab=True)    # the tuning knobs exist in the lab build only (make lab)
 with pkg.Context(a.w, a.h, a.pattern, a.fmt, variant=pkg.variant_names().index(a.variant)) as ctx:
     d_src = ctx.device_alloc(a.n * ctx.src_bytes)
     d_dst = ctx.device_alloc(a.n * ctx.dst_bytes)

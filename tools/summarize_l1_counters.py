@@ -53,7 +53,17 @@ lines = ["# profiles/%s_generic_l1 — counters between the wave and the L2, gen
          "device-resident batch, mean).  `same` = shape 1024x8, nt stores, band 1 forced on BOTH geometries (the generic "
          "one runs the GENERIC arm of that kernel, the aligned one the 16-byte arm); `default` = the generic geometry's "
          "own default plan.  Values are PER PIXEL; the ratio columns divide by the aligned neighbour's per-pixel value. "
-         "Kernel time (ns per launch, under the profiler) is the mean over the passes.", ""]
+         "Kernel time (ns per launch, under the profiler, i.e. slower than unprofiled) is the mean over the passes.  A "
+         "TA_* pass (TA_TA_BUSY, TA_*_STALLED_BY_TC, TA_FLAT_WRITE_WAVEFRONTS) aborts rocprofv3 7.2 on gfx950 (signal 6 at "
+         "finalisation) and is missing; SQ_ACTIVE_INST_VMEM reads 0 on this image.", "",
+         "**Reading.** `TCP_TCC_WRITE_REQ` is exactly 1 request per 64 bytes for the aligned geometry (0.0625 per pixel) and "
+         "1.03-1.07 x that for the generic one: the 16-byte lane stores that straddle a 16-byte boundary (width % 4 == 2) "
+         "are NOT taken apart into two requests each -- the texture path coalesces a wave-store into 64-byte segments "
+         "either way, and misalignment only adds the one partial segment at the end of each 1 KiB wave-store (17/16 = "
+         "1.0625).  The L2 sees 3-6 % more requests, the fabric 0-3 % more writes; VALU instructions are 5 % up (the "
+         "generic arm's per-lane guards).  Nothing between the wave and the L2 is 1.5 x or 2 x: there is no request "
+         "amplification for an LDS transposition of the finished pixels to remove (VERDICT r03 next #3: item closed, "
+         "DESIGN.md section 5).", ""]
 counters = []
 for e in runs.values():
     for c in e["counters"]:

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
-pkg = entry.load_package()
+pkg = entry.load_package(lab=True)    # the tuning knobs exist in the lab build only (make lab)
 W, H, N, ROUNDS = (int(v) for v in sys.argv[1:5])
 names = pkg.variant_names()
 arms = []
