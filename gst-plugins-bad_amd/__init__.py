@@ -220,8 +220,9 @@ class MibayerErrorNoLib(RuntimeError):
 
 
 class FrameLost(MibayerError):
-    """mibayer_pool_wait handed a frame back as lost (MIBAYER_ERR_TIMEOUT with its tag, devices left): the frame was in
-    flight on a device that ran into the wait deadline; its buffers stay the device's until Pool.reclaim()."""
+    """mibayer_pool_wait handed a frame back as lost (MIBAYER_ERR_TIMEOUT with its tag): the frame was in flight on a
+    device that ran into the wait deadline; its buffers stay the device's until Pool.reclaim().  The stream carries on
+    as long as Pool.alive() > 0."""
 
     def __init__(self, tag):
         super().__init__(ERR_TIMEOUT, "mibayer_pool_wait (frame lost)")
@@ -274,8 +275,8 @@ class Pool:
     def wait(self):
         tag = _vp()
         rc = lib().mibayer_pool_wait(self._h, ctypes.byref(tag))
-        if rc == ERR_TIMEOUT and tag.value and self.alive() > 0:
-            raise FrameLost(tag.value)
+        if rc == ERR_TIMEOUT and tag.value:
+            raise FrameLost(tag.value)          # (whether the stream carries on is alive() > 0)
         _check(rc, "mibayer_pool_wait")
         return tag.value or 0
 

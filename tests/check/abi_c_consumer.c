@@ -52,8 +52,31 @@ main (void)
     fprintf (stderr, "create: %s %s\n", mibayer_strerror (rc), mibayer_last_hip_error ());
     return 4;
   }
+  {
+    /* ABI v4 from C: the launch plan as a value, the host-wait policy and the host statistics */
+    int variant = -1, band = 0, align = -1;
+    mibayer_host_stats st;
+
+    if (mibayer_is_lab_build () != 0 || mibayer_plan_source (ctx) != MIBAYER_PLAN_DEFAULT
+        || mibayer_get_plan (ctx, &variant, &band, &align) != MIBAYER_OK || variant < 1 || align != 0
+        || mibayer_set_plan (ctx, variant, 0, 0) != MIBAYER_OK || mibayer_plan_source (ctx) != MIBAYER_PLAN_SET
+        || mibayer_set_wait_spin (ctx, 0) != MIBAYER_OK || mibayer_get_host_stats (ctx, &st) != MIBAYER_OK
+        || st.submits != 0 || mibayer_wedged_contexts () != 0 || mibayer_deferred_frees () != 0) {
+      fprintf (stderr, "ABI v4 calls: unexpected answer (variant %d band %d align %d)\n", variant, band, align);
+      return 7;
+    }
+  }
   memset (out, 0, sizeof out);
   rc = mibayer_process_host (ctx, frame, out);
+  {
+    mibayer_host_stats st;
+
+    if (mibayer_get_host_stats (ctx, &st) != MIBAYER_OK || st.submits != 1 || st.waits < 1 || st.polls < 1) {
+      fprintf (stderr, "host stats after one frame: submits %lu waits %lu\n", (unsigned long) st.submits,
+          (unsigned long) st.waits);
+      return 8;
+    }
+  }
   mibayer_destroy (ctx);
   if (rc != MIBAYER_OK) {
     fprintf (stderr, "process: %s\n", mibayer_strerror (rc));

@@ -1265,6 +1265,9 @@ def stream(stall_at):
                 except pkg.FrameLost as e:      # in flight on the stalled shard: dropped, in order, buffers quarantined
                     tag = e.tag
                     lost.append(tag)
+                    if pool.alive() == 0:       # ... and that was the last device: the stream has failed
+                        got += 1
+                        raise
                 assert tag == got + 1, (tag, got)
                 got += 1
         except pkg.MibayerError as e:
