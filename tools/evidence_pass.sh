@@ -19,22 +19,22 @@ timeout 900 python -m pytest tests -m gpu -q --timeout 600 2>&1 | tail -25 | tee
 step "pytest -m gpu (lab build as the library under test)"
 MIBAYER_LIB_PATH=$R/gst-plugins-bad_amd/libmibayer_lab.so timeout 900 python -m pytest tests -m gpu -q --timeout 600 2>&1 | tail -25 | tee $O/pytest_gpu_lab.log | tail -3
 step "bench, the driver's arguments"
-timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 2> $O/bench.err | tail -1 | tee $O/bench.json | cut -c1-400
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 2> $O/bench.err | grep '^{' | tail -1 | tee $O/bench.json | cut -c1-400
 step "rocprofv3 --kernel-trace --stats of the same command"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-host-path --no-traffic 2>&1 | grep -v "^W20" | tail -1 | cut -c1-300)
 step "force-dist (RCCL group of one rank)"
-timeout 300 python bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-cpu --no-host-path --no-traffic 2>> $O/bench.err | tail -1 > $O/bench_force_dist.json
+timeout 300 python bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-cpu --no-host-path --no-traffic 2>> $O/bench.err | grep '^{' | tail -1 > $O/bench_force_dist.json
 step "stream mode (configs[4])"
-timeout 300 python bench.py --mode stream 2>> $O/bench.err | tail -1 > $O/stream_mode.json
+timeout 300 python bench.py --mode stream 2>> $O/bench.err | grep '^{' | tail -1 > $O/stream_mode.json
 step "eight ranks sharing the one GPU (functional: per_gpu, control-plane fields)"
-timeout 400 python bench.py --gpus 8 --share-gpu --backend gloo --steps 5 --warmup 2 --no-cpu --no-host-path 2>> $O/bench.err | tail -1 > $O/eight_ranks_one_gpu.json
+timeout 400 python bench.py --gpus 8 --share-gpu --backend gloo --steps 5 --warmup 2 --no-cpu --no-host-path 2>> $O/bench.err | grep '^{' | tail -1 > $O/eight_ranks_one_gpu.json
 step "host CPU per frame"
 timeout 300 bash tools/host_cpu_bench.sh 1500 > $O/host_cpu.log 2>&1; tail -16 $O/host_cpu.log | cut -c1-150
 step "default vs measured vs cached plan"
 timeout 300 python tools/common_geometries.py > $O/common_geometries.log 2>&1; tail -17 $O/common_geometries.log | cut -c1-200
 if [ -z "$QUICK" ]; then
   step "element-level fps"
-  timeout 400 bash tools/gst_pipeline_bench.sh 600 > $O/gst_pipeline_bench.log 2>&1; tail -20 $O/gst_pipeline_bench.log
+  timeout 400 bash tools/gst_pipeline_bench.sh 2000 > $O/gst_pipeline_bench.log 2>&1; tail -20 $O/gst_pipeline_bench.log
   step "parity fuzz soak"
   MIBAYER_FUZZ_SEED=404 MIBAYER_FUZZ_CASES=1200 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k randomised 2>&1 | tail -3 | tee $O/fuzz_soak.log
   MIBAYER_LIB_PATH=$R/gst-plugins-bad_amd/libmibayer_lab.so MIBAYER_FUZZ_SEED=405 MIBAYER_FUZZ_CASES=1200 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k randomised 2>&1 | tail -3 | tee -a $O/fuzz_soak.log

@@ -4,6 +4,9 @@
 #   auto       spin only while the frame waited for is alone in flight, otherwise naps from the start (the default)
 #   spin2000   MIBAYER_WAIT_SPIN_US=2000: every wait spins its first 2 ms (what round 3 did)
 #   nap        MIBAYER_WAIT_SPIN_US=0: never spin
+# Arms marked PINNED take their input from videotestsrc (which uses the pinned pool the element proposes; the painting of
+# the frames is then part of cpu_ms/frame, the element's own figures are not affected); the others from fakesrc, whose
+# malloc'ed buffers make every upload a blocking staging copy -- that copy is the bulk of submit_cpu_us_per_frame there.
 # Per arm: fps, CPU-ms per frame of the whole gst-launch process (user + sys, frames N+20 minus 20), and the element's
 # own per-frame figures from its host-stats log line (submit / wait CPU of the streaming and helper threads, polls, naps).
 # Usage (GPU box): bash tools/host_cpu_bench.sh [frames]
@@ -18,8 +21,14 @@ run () {   # frames, element-with-props -> "wall cpu" on stdout, the element's s
 import os, resource, subprocess, sys, time
 n, el = sys.argv[1], sys.argv[2]
 W, H = 3840, 2160
-cmd = ["/opt/conda/bin/gst-launch-1.0", "-q", "fakesrc", "num-buffers=" + n, "sizetype=fixed", "sizemax=%d" % (W * H),
-       "filltype=nothing", "!", "video/x-bayer,format=rggb,width=%d,height=%d,framerate=0/1" % (W, H), "!"] + el.split() + \
+# fakesrc ignores the pinned pool the element proposes and hands over malloc memory (pageable input: the upload is the
+# runtime's blocking staging copy); videotestsrc takes the pool (pinned input), at the price of painting each frame
+if os.environ.get("HOSTCPU_PINNED_SRC"):
+    src = ["videotestsrc", "num-buffers=" + n, "pattern=solid-color"]
+else:
+    src = ["fakesrc", "num-buffers=" + n, "sizetype=fixed", "sizemax=%d" % (W * H), "filltype=nothing"]
+cmd = ["/opt/conda/bin/gst-launch-1.0", "-q"] + src + \
+      ["!", "video/x-bayer,format=rggb,width=%d,height=%d,framerate=0/1" % (W, H), "!"] + el.split() + \
       ["!", "video/x-raw,format=BGRx", "!", "fakesink", "sync=false"]
 env = dict(os.environ, GST_DEBUG="bayer2rgb:4", GST_DEBUG_NO_COLOR="1")
 t0 = time.perf_counter()
@@ -33,14 +42,15 @@ print("%.4f %.4f" % (t1 - t0, (r1.ru_utime + r1.ru_stime) - (r0.ru_utime + r0.ru
 PY
 }
 printf "%-46s %-9s %8s %14s   %s\n" "arm" "policy" "fps" "cpu_ms/frame" "element: per-frame host stats"
-for arm in "bayer2rgb" "bayer2rgb inflight=2" "bayer2rgb inflight=4" "bayer2rgb inflight=2 devices=0,0,0,0" "THREADS bayer2rgb inflight=2 devices=0,0,0,0"; do
+for arm in "bayer2rgb" "bayer2rgb inflight=2" "bayer2rgb inflight=4" "PINNED bayer2rgb inflight=2" "bayer2rgb inflight=2 devices=0,0,0,0" "THREADS bayer2rgb inflight=2 devices=0,0,0,0"; do
   for policy in auto spin2000 nap; do
     case $policy in auto) unset MIBAYER_WAIT_SPIN_US;; spin2000) export MIBAYER_WAIT_SPIN_US=2000;; nap) export MIBAYER_WAIT_SPIN_US=0;; esac
-    el=$arm; unset MIBAYER_POOL_THREADS
+    el=$arm; unset MIBAYER_POOL_THREADS HOSTCPU_PINNED_SRC
     case $arm in THREADS*) export MIBAYER_POOL_THREADS=1; el=${arm#THREADS };; esac
+    case $arm in PINNED*) export HOSTCPU_PINNED_SRC=1; el=${arm#PINNED };; esac   # videotestsrc: pinned input (its painting is in cpu_ms/frame)
     a=($(run 20 "$el")); b=($(run $((N+20)) "$el"))
     echo "${a[0]} ${a[1]} ${b[0]} ${b[1]} $N" | awk -v arm="$arm" -v pol="$policy" -v st="$(cat /tmp/hostcpu.err)" \
       '{dt=$3-$1; cpu=$4-$2; printf "%-46s %-9s %8.1f %14.3f   %s\n", arm, pol, $5/dt, cpu*1e3/$5, st}'
   done
 done
-unset MIBAYER_WAIT_SPIN_US MIBAYER_POOL_THREADS
+unset MIBAYER_WAIT_SPIN_US MIBAYER_POOL_THREADS HOSTCPU_PINNED_SRC

@@ -59,10 +59,24 @@ if os.path.exists(bench):
               % (b["value"], b["ms_per_step"], b["roofline"]["kernel_ms"], b["roofline"]["achieved"],
                  100 * b["roofline"]["frac"]),
               "* plan: %s, autotune: %s" % (b["config"]["kernel_variant"], b["config"].get("autotune")), ""]
+    t = b["roofline"].get("traffic")
+    if t:
+        lines += ["## HBM-side traffic measured INSIDE that bench run (`roofline.traffic`)", "",
+                  "bench.py re-launched itself after the timed region as a profiled child (`--traffic-pass`, the same batch "
+                  "and plan, %d launches averaged) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` "
+                  "(separate passes); FETCH_SIZE KiB x 2 (gfx950 correction), WRITE_SIZE KiB x 1:" % t["launches_averaged"], "",
+                  "* kernel `%s`, plan %s" % (t["kernel"], t["plan"]),
+                  "* read %d B (%.4f x), write %d B (%.4f x), total %d B = **%.4f x** the algorithmic 2 654 208 000 B; "
+                  "the pass took %.1f s" % (t["read"], t["read_ratio"], t["write"], t["write_ratio"], t["total"], t["ratio"],
+                                            t["seconds"]), ""]
+    for k in ("control_plane", "barrier_ms", "value_kernel_only"):
+        if k in b:
+            lines.append("* %s: %s" % (k, b[k]))
+    lines.append("")
 stats = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
-    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-host-path` "
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-host-path --no-traffic` "
               "(the driver's arguments)", "",
               "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---:|---:|---:|---:|---:|"]
     for r in csv.DictReader(open(stats[0])):
