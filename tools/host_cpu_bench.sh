@@ -24,11 +24,12 @@ W, H = 3840, 2160
 # fakesrc ignores the pinned pool the element proposes and hands over malloc memory (pageable input: the upload is the
 # runtime's blocking staging copy); videotestsrc takes the pool (pinned input), at the price of painting each frame
 if os.environ.get("HOSTCPU_PINNED_SRC"):
-    src = ["videotestsrc", "num-buffers=" + n, "pattern=solid-color"]
+    src = ["videotestsrc", "num-buffers=" + n]
 else:
     src = ["fakesrc", "num-buffers=" + n, "sizetype=fixed", "sizemax=%d" % (W * H), "filltype=nothing"]
 cmd = ["/opt/conda/bin/gst-launch-1.0", "-q"] + src + \
-      ["!", "video/x-bayer,format=rggb,width=%d,height=%d,framerate=0/1" % (W, H), "!"] + el.split() + \
+      ["!", "video/x-bayer,format=rggb,width=%d,height=%d,framerate=%s" % (
+          W, H, "30/1" if os.environ.get("HOSTCPU_PINNED_SRC") else "0/1"), "!"] + el.split() + \
       ["!", "video/x-raw,format=BGRx", "!", "fakesink", "sync=false"]
 env = dict(os.environ, GST_DEBUG="bayer2rgb:4", GST_DEBUG_NO_COLOR="1")
 t0 = time.perf_counter()
@@ -48,8 +49,9 @@ for arm in "bayer2rgb" "bayer2rgb inflight=2" "bayer2rgb inflight=4" "PINNED bay
     el=$arm; unset MIBAYER_POOL_THREADS HOSTCPU_PINNED_SRC
     case $arm in THREADS*) export MIBAYER_POOL_THREADS=1; el=${arm#THREADS };; esac
     case $arm in PINNED*) export HOSTCPU_PINNED_SRC=1; el=${arm#PINNED };; esac   # videotestsrc: pinned input (its painting is in cpu_ms/frame)
-    a=($(run 20 "$el")); b=($(run $((N+20)) "$el"))
-    echo "${a[0]} ${a[1]} ${b[0]} ${b[1]} $N" | awk -v arm="$arm" -v pol="$policy" -v st="$(cat /tmp/hostcpu.err)" \
+    NN=$N; case $arm in PINNED*) NN=$((N/5));; esac       # (videotestsrc paints ~10 ms per 4K frame)
+    a=($(run 20 "$el")); b=($(run $((NN+20)) "$el"))
+    echo "${a[0]} ${a[1]} ${b[0]} ${b[1]} $NN" | awk -v arm="$arm" -v pol="$policy" -v st="$(cat /tmp/hostcpu.err)" \
       '{dt=$3-$1; cpu=$4-$2; printf "%-46s %-9s %8.1f %14.3f   %s\n", arm, pol, $5/dt, cpu*1e3/$5, st}'
   done
 done

@@ -2,7 +2,9 @@
 """Development tool: every production plan -- 3 tile shapes x {band 1, chunk, identity} -- on sector-aligned frame
 widths, interleaved rounds, through mibayer_set_plan (product build).  What the static default of mibayer_create
 (resolve_variant + the band rules of plan_launch) should pick per width is read off this table.
-Usage (GPU box): python tools/plan_sweep.py [json-out]"""
+Usage (GPU box): python tools/plan_sweep.py [json-out] [Mpixel per batch, default 265] [common]
+(a 265-Mpixel batch keeps the SOURCE resident in the 256 MB Infinity Cache between launches -- what a streaming pipeline
+sees; 530 Mpixel is the bench's regime, where the source comes from HBM every time)"""
 import json
 import os
 import sys
@@ -17,13 +19,17 @@ BANDS = (1, -1, 0)
 widths = sorted(set(list(range(1088, 8192 + 1, 128)) + [
     1280, 1296, 1440, 1600, 1920, 1936, 2048, 2304, 2448, 2560, 2592, 2688, 2704, 3072, 3264, 3280, 3840, 4000, 4032,
     4064, 4096, 4112, 4208, 4608, 4656, 5120, 5472, 6000, 6144, 7680, 8192]))
+MPIX = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 265e6
+if len(sys.argv) > 3:
+    widths = [1280, 1600, 1920, 1936, 2048, 2304, 2448, 2560, 2592, 2688, 3072, 3264, 3280, 3840, 4000, 4032, 4096, 4112, 4208,
+              4608, 4656, 5120, 5472, 6000, 6144, 7680, 8192]
 widths = [w for w in widths if w % 16 == 0]
 out = {}
-print("# width: default plan %%  |  best plan %%  |  per plan (shape/band): %% of 8 TB/s; ~265 Mpixel batches, median of 3 "
+print("# width: default plan %%  |  best plan %%  |  per plan (shape/band): %% of 8 TB/s; ~%d Mpixel batches" % (MPIX / 1e6) + ", median of 3 "
       "interleaved rounds x 6 launches", flush=True)
 for w in widths:
     h = 1080 if w <= 2600 else (2160 if w <= 5200 else 4320)
-    n = max(4, int(265e6 / (w * h)))
+    n = max(4, int(MPIX / (w * h)))
     pct = lambda t: 5.0 * w * h * n / t / 1e6 / 80   # noqa: E731
     with pkg.Context(w, h, "rggb", "BGRx") as ctx:
         d_src = ctx.device_alloc(n * ctx.src_bytes)
