@@ -459,6 +459,27 @@ static bool ctx_settled (mibayer_ctx *c)
   return c->wedge->settled;
 }
 
+/* A context that ran into a deadline works again once the device has caught up with everything it had queued at
+ * that moment (its frames' events have fired, so they can be waited for and handed back in order): a spurious timeout
+ * -- a small deadline, a neighbour process hogging the GPU, the stall drill -- heals by itself.  Polls, never waits. */
+static bool wedged_for_good (mibayer_ctx *c)
+{
+  if (!c->wedged)
+    return false;
+  if (!ctx_settled (c))
+    return true;
+  std::lock_guard<std::mutex> lk (g_wedge_mu);
+  for (size_t i = 0; i < g_wedges.size (); i++)
+    if (g_wedges[i] == c->wedge)
+      g_wedges.erase (g_wedges.begin () + (long) i);
+  for (hipEvent_t e : c->wedge->fences)
+    (void) hipEventDestroy (e);
+  delete c->wedge;
+  c->wedge = nullptr;
+  c->wedged = false;
+  return false;
+}
+
 static double thread_cpu_ms ()
 {
   timespec t;
@@ -484,7 +505,7 @@ constexpr int kAutoSpinUs = 2000;       /* a 4K frame through the host path take
  * gst/debugutils/gstwatchdog.c:21-123. */
 static int wait_event (mibayer_ctx *c, hipEvent_t ev, bool alone)
 {
-  if (c->wedged)
+  if (wedged_for_good (c))
     return MIBAYER_ERR_TIMEOUT;
   c->stats.waits++;
   CpuMeter cpu (&c->stats.wait_cpu_ms);
@@ -1673,7 +1694,7 @@ static int enqueue_frame (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
 static int submit_locked (mibayer_ctx *c, const uint8_t *src, uint8_t *dst,
     void *tag, bool alone)
 {
-  if (c->wedged)
+  if (wedged_for_good (c))
     return MIBAYER_ERR_TIMEOUT;
   const int rc = enqueue_frame (c, src, dst, tag, alone);
   if (rc != MIBAYER_OK && rc != MIBAYER_ERR_BUSY) {
@@ -1776,7 +1797,7 @@ extern "C" int mibayer_internal_run_spare (mibayer_ctx *c, const uint8_t *src,
     }
     c->spare_ready = true;
   }
-  if (c->wedged)
+  if (wedged_for_good (c))
     return MIBAYER_ERR_TIMEOUT;
   int rc = enqueue_plain (c, c->spare, src, dst, written_row_bytes (c));
   if (rc != MIBAYER_OK) {

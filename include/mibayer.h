@@ -74,8 +74,11 @@ typedef enum mibayer_status {
   MIBAYER_ERR_EMPTY = -8,       /* mibayer_wait() with nothing in flight     */
   MIBAYER_ERR_TIMEOUT = -9      /* the device did not complete a frame within
                                    the wait deadline (mibayer_set_wait_timeout);
-                                   the context is wedged from then on: every
-                                   later call returns this at once           */
+                                   the context is wedged: every later call
+                                   returns this at once -- until the device has
+                                   caught up with what the context had queued
+                                   (polled, never waited for), then the context
+                                   works again and its frames can be collected */
 } mibayer_status;
 
 /* Per-stream configuration == the fields of struct _GstBayer2RGB
@@ -174,7 +177,9 @@ int mibayer_pending (const mibayer_ctx *ctx);
  * streaming thread must not hang on it (cf. gst/debugutils/gstwatchdog.c:21-123).
  * Default 10000 (also MIBAYER_WAIT_TIMEOUT_MS); 0 = wait for ever; < 0 = default.
  * A wait that runs into the deadline returns MIBAYER_ERR_TIMEOUT and leaves the
- * frame where it is -- its buffers still belong to the device. */
+ * frame where it is -- its buffers still belong to the device.  The deadline also
+ * bounds mibayer_sync() after device-resident launches: a device that is shared
+ * with long-running foreign kernels needs a longer one. */
 int mibayer_set_wait_timeout (mibayer_ctx *ctx, int ms);
 /* How a host-side wait spends its time.  The completion event is polled: a tight
  * loop for `spin_us` microseconds, then naps that double from 20 us to 250 us.
