@@ -96,3 +96,45 @@ for i in range(N):
 f1, r1 = free_bytes(), rss_kb()
 print("device memory free: before %d B, after %d rounds %d B, delta %+d B" % (f0, N, f1, f1 - f0))
 print("host RSS: before %d kB, after %d kB, delta %+d kB" % (r0, r1, r1 - r0))
+
+
+# round 4: the wedge registry.  A context that runs into its wait deadline and is destroyed while the device has not
+# caught up hands its ring (device frames, events, queues) to the registry, and pinned blocks freed meanwhile are parked;
+# once the stall is over everything must have gone back to the runtime -- by polling alone.
+def wedge_round():
+    import time
+    ctx = pkg.Context(w, h, "rggb", "BGRx", inflight=2)
+    ctx.process_host(src)
+    ctx.set_wait_timeout(40)
+    ctx.stall(250)
+    ps, pd = L.mibayer_host_alloc(w * h), L.mibayer_host_alloc(4 * w * h)
+    hs = np.ctypeslib.as_array(ctypes.cast(ps, ctypes.POINTER(ctypes.c_uint8)), (h, w))
+    hd = np.ctypeslib.as_array(ctypes.cast(pd, ctypes.POINTER(ctypes.c_uint8)), (h, 4 * w))
+    hs[...] = src
+    ctx.submit(hs, hd, 1)
+    try:
+        ctx.wait()
+        raise SystemExit("the stalled frame came back before the deadline?")
+    except pkg.MibayerError as exc:
+        assert exc.status == pkg.ERR_TIMEOUT
+    ctx.close()                                 # orphaned: the registry owns the ring now
+    extra = L.mibayer_host_alloc(1 << 20)
+    L.mibayer_host_free(extra)                  # parked
+    assert L.mibayer_wedged_contexts() == 1 and L.mibayer_deferred_frees() == 1
+    time.sleep(0.35)
+    assert L.mibayer_wedged_contexts() == 0 and L.mibayer_deferred_frees() == 0
+    L.mibayer_host_free(ps)
+    L.mibayer_host_free(pd)
+
+
+for i in range(3):
+    wedge_round()
+f2 = free_bytes()
+M = 25
+for i in range(M):
+    wedge_round()
+with pkg.Context(w, h, "rggb", "BGRx") as ctx:      # (the last context of the device trims the frame cache)
+    ctx.process_host(src)
+f3 = free_bytes()
+print("wedge registry: device memory free before %d B, after %d timed-out-and-destroyed contexts %d B, delta %+d B" % (
+    f2, M, f3, f3 - f2))
