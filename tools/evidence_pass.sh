@@ -32,6 +32,8 @@ step "host CPU per frame"
 timeout 300 bash tools/host_cpu_bench.sh 1500 > $O/host_cpu.log 2>&1; tail -16 $O/host_cpu.log | cut -c1-150
 step "default vs measured vs cached plan"
 timeout 300 python tools/common_geometries.py > $O/common_geometries.log 2>&1; tail -17 $O/common_geometries.log | cut -c1-200
+step "leaks (contexts, pools, wedge registry; GStreamer leak tracer)"
+(timeout 300 python tools/leak_check.py 2>&1 | tail -4; timeout 300 bash tools/gst_leaks.sh 2>&1 | tail -14) > $O/leaks.log; tail -4 $O/leaks.log | cut -c1-160
 if [ -z "$QUICK" ]; then
   step "element-level fps"
   timeout 400 bash tools/gst_pipeline_bench.sh 2000 > $O/gst_pipeline_bench.log 2>&1; tail -20 $O/gst_pipeline_bench.log
