@@ -344,6 +344,7 @@ struct Wedge {
 static std::mutex g_wedge_mu;
 static std::vector<Wedge *> g_wedges;
 static std::vector<void *> g_deferred_host;     /* pinned blocks whose hipHostFree is waiting for the wedges to settle */
+static std::atomic<int> g_deferred_count { 0 }; /* its size, for the lock-free fast paths */
 static std::atomic<int> g_wedges_open { 0 };    /* unsettled wedges: the fast path of mibayer_host_free */
 
 static void release_wedge_resources (Wedge *w)
@@ -398,12 +399,13 @@ static void poll_wedges_locked ()
     for (void *p : g_deferred_host)
       (void) hipHostFree (p);
     g_deferred_host.clear ();
+    g_deferred_count.store (0);
   }
 }
 
 static void poll_wedges ()
 {
-  if (g_wedges_open.load () == 0 && g_deferred_host.empty ())
+  if (g_wedges_open.load () == 0 && g_deferred_count.load () == 0)
     return;
   std::lock_guard<std::mutex> lk (g_wedge_mu);
   poll_wedges_locked ();
@@ -1262,16 +1264,22 @@ extern "C" void mibayer_destroy (mibayer_ctx *c)
   for (auto &b : trim)          /* the last context of the device: nothing of ours is queued there any more */
     (void) hipFree (b.first);
   if (c->wedge) {
-    std::lock_guard<std::mutex> lk (g_wedge_mu);
-    if (c->wedge->settled) {
-      for (size_t i = 0; i < g_wedges.size (); i++)
-        if (g_wedges[i] == c->wedge)
-          g_wedges.erase (g_wedges.begin () + (long) i);
-      for (hipEvent_t e : c->wedge->fences)
-        (void) hipEventDestroy (e);
-      delete c->wedge;
-    } else {
-      c->wedge->orphan = true;  /* the registry releases what was handed over once the fences fire */
+    Wedge *done = nullptr;
+    {
+      std::lock_guard<std::mutex> lk (g_wedge_mu);
+      poll_wedges_locked ();
+      if (c->wedge->settled) {  /* (possibly since the resources above were handed over: they are released here) */
+        for (size_t i = 0; i < g_wedges.size (); i++)
+          if (g_wedges[i] == c->wedge)
+            g_wedges.erase (g_wedges.begin () + (long) i);
+        done = c->wedge;
+      } else {
+        c->wedge->orphan = true;        /* the registry releases what was handed over once the fences fire */
+      }
+    }
+    if (done) {
+      release_wedge_resources (done);
+      delete done;
     }
   }
   delete c;
@@ -2241,7 +2249,7 @@ static int autotune_core (mibayer_ctx *c, F launch_once, bool generic_off_grid, 
   int ncand = 0;
   auto add = [&](const Variant *v, int band, int align) {
     if (align && !(align == 128 ? v->aligned128 : v->aligned64))
-      return;
+      align = 0;                /* this shape has no such arm: it runs unshifted */
     for (int i = 0; i < ncand; i++)
       if (cand[i].var == v && cand[i].band == band && cand[i].align == align)
         return;
@@ -2562,16 +2570,18 @@ extern "C" void mibayer_host_free (void *p)
 {
   if (!p)
     return;
-  if (g_wedges_open.load () == 0 && g_deferred_host.empty ()) {
+  if (g_wedges_open.load () == 0 && g_deferred_count.load () == 0) {
     (void) hipHostFree (p);
     return;
   }
   std::lock_guard<std::mutex> lk (g_wedge_mu);
   poll_wedges_locked ();
-  if (g_wedges_open.load () == 0)
+  if (g_wedges_open.load () == 0) {
     (void) hipHostFree (p);
-  else
+  } else {
     g_deferred_host.push_back (p);
+    g_deferred_count.fetch_add (1);
+  }
 }
 
 /* pinned blocks waiting on the deferred list / contexts whose device has not caught up yet (diagnostics, tests) */
