@@ -479,15 +479,29 @@ extern "C" int mibayer_pool_create (const mibayer_pool_cfg *cfg,
     if (const char *e = getenv ("MIBAYER_POOL_NUMA"))
       pool->numa_route = pool->numa_route && atoi (e) != 0;
   }
-  /* A submit thread per shard, pinned frames included (include/mibayer.h): off by default.  Measured
-   * (profiles/r04_host_cpu.log, bench.py host_path.host_cpu): queueing a 4K frame from PINNED buffers costs the
-   * calling thread ~15 us of CPU and waiting for it ~20 us (napping waits), so one streaming thread feeds eight GPUs at
-   * the ~1.4 k frames/s each that a PCIe link carries with a third of a core; from PAGEABLE buffers the runtime's
-   * staging copy makes it 200-300 us per frame -- and those shards get a helper thread each anyway (above). */
-  if (const char *e = getenv ("MIBAYER_POOL_THREADS"))
-    if (atoi (e) != 0 && pool->shards.size () > 1)
+  /* A submit thread per shard, pinned frames included (include/mibayer.h).  Measured (profiles/r04_host_cpu.log,
+   * bench.py host_path.host_cpu): queueing a 4K frame from PINNED buffers costs the calling thread 14 us of CPU at the
+   * ABI and ~80 us in the element (buffer maps, pool traffic), waiting for it ~8-20 us (napping waits) -- one
+   * streaming thread saturates at roughly 11 k frames/s, which is what EIGHT PCIe links carry (8 x ~1.4 k frames/s
+   * at 4K).  So pools over six or more DISTINCT GPUs start with a thread per shard (each then spends ~12 % of a core,
+   * pinned next to its GPU); smaller pools keep the enqueue-only streaming thread (and shards that see PAGEABLE
+   * buffers, 200-300 us of staging copy per frame, get their helper thread either way).  MIBAYER_POOL_THREADS=0 / 1
+   * decides otherwise. */
+  {
+    size_t distinct = 0;
+    for (size_t i = 0; i < pool->shards.size (); i++) {
+      bool seen = false;
+      for (size_t k = 0; k < i; k++)
+        seen = seen || pool->shards[k]->device == pool->shards[i]->device;
+      distinct += seen ? 0 : 1;
+    }
+    bool threads = distinct >= 6;
+    if (const char *e = getenv ("MIBAYER_POOL_THREADS"))
+      threads = atoi (e) != 0;
+    if (threads && pool->shards.size () > 1)
       for (size_t i = 0; i < pool->shards.size (); i++)
         enter_helper_mode (pool, (int) i, false);
+  }
   if (const char *e = getenv ("MIBAYER_INJECT_FAULT")) {
     /* "shard:frames[,shard:frames...]" */
     while (*e) {

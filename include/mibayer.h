@@ -213,9 +213,10 @@ int mibayer_get_host_stats (const mibayer_ctx *ctx, mibayer_host_stats *out);
  * in submission order.  By default the calling thread drives all shards -- with
  * pinned buffers every call below only enqueues work -- and a shard that sees
  * pageable buffers gets a helper thread (queueing a 4K frame from pinned buffers
- * costs the caller ~15 us of CPU, from pageable ones 200-300 us: the runtime's
- * staging copy); MIBAYER_POOL_THREADS=1 gives every shard its own submit thread
- * from the start.  When the devices span more than
+ * costs the caller 14-80 us of CPU, from pageable ones 200-300 us: the runtime's
+ * staging copy).  One thread saturates at ~11 k frames/s, what eight PCIe links
+ * carry at 4K: pools over six or more DISTINCT GPUs give every shard its own
+ * submit thread from the start; MIBAYER_POOL_THREADS=1 / 0 forces that on / off.  When the devices span more than
  * one NUMA node, a frame goes to the live shard next to its 4-byte-per-pixel
  * buffer as long as that keeps the rotation balanced (MIBAYER_POOL_NUMA=0:
  * strictly g % ndevices).  Ordinals may repeat (N logical shards on one GPU). */

@@ -169,6 +169,15 @@ def test_thread_per_shard_with_faults(driver):
     for faults in ("-", "2:4", "0:1,3:6"):
         kv, _ = run(driver, 4, 2, 70, False, faults, "ok", env={"MIBAYER_POOL_THREADS": "1"})
         assert kv["delivered"] == "70", (faults, kv)
+    # pools over six or more DISTINCT devices start with a submit thread per shard by default (one streaming thread
+    # saturates at what eight PCIe links carry): eight fake GPUs, pinned frames, with and without a failing / a
+    # stalling device; MIBAYER_POOL_THREADS=0 keeps the single enqueue-only thread
+    env8 = {"MOCK_MIBAYER_DEVICES": "8", "POOL_LOGIC_DISTINCT": "1"}
+    for faults, extra in (("-", {}), ("5:3", {}), ("-", {"MIBAYER_POOL_THREADS": "0"}),
+                          ("-", {"MOCK_MIBAYER_HANG": "2:3", "POOL_LOGIC_TIMEOUT_MS": "20"})):
+        kv, _ = run(driver, 8, 2, 120, False, faults, "ok", env=dict(env8, **extra))
+        assert int(kv["delivered"]) + int(kv["lost"]) == 120, (faults, extra, kv)
+        assert kv["alive"] == ("8" if faults == "-" and "MOCK_MIBAYER_HANG" not in extra else "7"), kv
 
 
 def test_a_redone_frame_is_not_handed_back_before_its_dead_context_is_abandoned(driver):
