@@ -91,11 +91,15 @@ for i in range(6):
     one_round(i)                # warm-up: runtime pools, code objects
 f0, r0 = free_bytes(), rss_kb()
 N = 150
+trail = []
 for i in range(N):
     one_round(i)
+    if (i + 1) % (N // 5) == 0:         # a leak grows with the rounds; a pool the runtime fills once does not
+        trail.append((i + 1, free_bytes() - f0, rss_kb() - r0))
 f1, r1 = free_bytes(), rss_kb()
 print("device memory free: before %d B, after %d rounds %d B, delta %+d B" % (f0, N, f1, f1 - f0))
 print("host RSS: before %d kB, after %d kB, delta %+d kB" % (r0, r1, r1 - r0))
+print("trail (rounds: device delta B, RSS delta kB): " + "  ".join("%d: %+d, %+d" % t for t in trail))
 
 
 # round 4: the wedge registry.  A context that runs into its wait deadline and is destroyed while the device has not
