@@ -16,7 +16,9 @@ from .bayer2rgb_np import LAYOUTS, PATTERNS, synthetic_frames  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle_bayer.so")
 REF_ROWS_PATH = os.path.join(_HERE, "_ref", "libbayerorc_ref.so")
+REF_FRAME_PATH = os.path.join(_HERE, "_ref", "libbayer_frame_ref.so")
 _lib = None
+_ref_frame = None
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 
@@ -67,6 +69,53 @@ def load_ref_rows():
 
 def _p(a):
     return a.ctypes.data_as(_u8p)
+
+
+def have_ref_frame():
+    """oracle/_ref/libbayer_frame_ref.so: the reference's own gst_bayer2rgb_process and gst_rgb2bayer_transform,
+    compiled from the lines where they lie by `make -C oracle ref_frame` (needs the GStreamer libraries at run time)."""
+    return os.path.exists(REF_FRAME_PATH)
+
+
+def ref_frame_lib():
+    global _ref_frame
+    if _ref_frame is None:
+        L = ctypes.CDLL(REF_FRAME_PATH)
+        L.ref_frame_bayer2rgb.argtypes = [_u8p, ctypes.c_int, _u8p, ctypes.c_int] + [ctypes.c_int] * 6
+        L.ref_frame_rgb2bayer.argtypes = [_u8p, _u8p] + [ctypes.c_int] * 4
+        L.ref_frame_describe.restype = ctypes.c_char_p
+        _ref_frame = L
+    return _ref_frame
+
+
+def ref_frame_bayer2rgb(src, width, pattern, r_off, g_off, b_off, dst_stride=None):
+    """The REFERENCE's frame driver (gstbayer2rgb.c:387-451) on one frame: src (H, src_stride) -> (H, dst_stride);
+    bytes beyond 4*width of a row keep the 0xA5 guard fill."""
+    if isinstance(pattern, str):
+        pattern = PATTERNS[pattern]
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    H, sstride = src.shape
+    dstride = 4 * width if dst_stride is None else dst_stride
+    dst = np.full((H, dstride), 0xA5, np.uint8)
+    rc = ref_frame_lib().ref_frame_bayer2rgb(_p(dst), dstride, _p(src), sstride, width, H, pattern,
+                                             r_off, g_off, b_off)
+    if rc != 0:
+        raise ValueError("reference frame driver: geometry outside its defined domain (rc=%d)" % rc)
+    return dst
+
+
+def ref_frame_rgb2bayer(src, width, pattern):
+    """The REFERENCE's gst_rgb2bayer_transform (gstrgb2bayer.c:229-278) on one ARGB frame: src (H, src_stride >= 4W)
+    -> (H, ROUND_UP_4(W)) mosaic; destination bytes beyond `width` keep the 0xA5 guard fill."""
+    if isinstance(pattern, str):
+        pattern = PATTERNS[pattern]
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    H, sstride = src.shape
+    dst = np.full((H, (width + 3) & ~3), 0xA5, np.uint8)
+    rc = ref_frame_lib().ref_frame_rgb2bayer(_p(dst), _p(src), sstride, width, H, pattern)
+    if rc != 0:
+        raise ValueError("reference rgb2bayer transform failed (rc=%d)" % rc)
+    return dst
 
 
 def bayer2rgb(src, width, pattern, r_off, g_off, b_off, dst_stride=None, ref_rows=False):

@@ -89,7 +89,7 @@ def bayer2rgb(S, pattern, r_off, g_off, b_off):
 
 def rgb2bayer(P, pattern, r_off=1, g_off=2, b_off=3):
     """Inverse element (gst/bayer/gstrgb2bayer.c:254-268).  P: (H, W, 4) uint8 -> (H, W) uint8.
-    Parity unpinned (see bayer2rgb_oracle.h)."""
+    Pinned against the reference's compiled gst_rgb2bayer_transform (see bayer2rgb_oracle.h)."""
     if isinstance(pattern, str):
         pattern = PATTERNS[pattern]
     P = np.asarray(P, dtype=np.uint8)

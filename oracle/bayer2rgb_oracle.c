@@ -503,7 +503,7 @@ oracle_bayer2rgb_batch (uint8_t *dst, size_t dst_frame_bytes, int dst_stride,
 
 /* ---- rgb2bayer --------------------------------------------------------------- */
 
-/* gst_rgb2bayer_transform, gstrgb2bayer.c:254-268 (parity unpinned, see header) */
+/* gst_rgb2bayer_transform, gstrgb2bayer.c:254-268 (pinned against the compiled reference function, see header) */
 int
 oracle_rgb2bayer (uint8_t *dst, int dst_stride, const uint8_t *src,
     int src_stride, int width, int height, int pattern, int r_off, int g_off,

@@ -12,9 +12,9 @@
  *   gst/bayer/gstbayerorc.orc:3-19     bayer_orc_horiz_upsample_unaligned
  *   gst/bayer/gstbayerorc.orc:43-248   bayer_orc_merge_{bg,gr}_{bgra,abgr,rgba,argb}
  *
- * Parity pin: see oracle/README.md (reference row kernels compiled into
- * oracle/_ref, the md5 known answers of SURVEY.md Appendix B.3 and the
- * hand-checkable 4x4 frame of Appendix B.4).
+ * Parity pin: see oracle/README.md (the reference's own frame driver and row
+ * kernels compiled into oracle/_ref, the md5 known answers of SURVEY.md
+ * Appendix B.3 and the hand-checkable 4x4 frame of Appendix B.4).
  */
 #ifndef BAYER2RGB_ORACLE_H
 #define BAYER2RGB_ORACLE_H
@@ -96,13 +96,16 @@ int oracle_bayer2rgb_batch_bands_repeat (uint8_t *dst, size_t dst_frame_bytes,
  * byte (j,i) is byte r_off / g_off / b_off of input pixel (j,i) according to the
  * CFA site ((j&1)<<1)|(i&1); the reference hard-codes ARGB (r,g,b = 1,2,3).
  * Padding bytes of a destination row are left untouched, as in the reference.
- * PARITY UNPINNED for this function: the reference element cannot be built
- * here (GStreamer >= 1.20 macros) and its tests hold no vectors for it; the
- * restatement is a line-by-line reading of an 11-line loop.  Independent
- * cross-check of the site -> channel mapping (not of the reference element):
- * gst-plugins-base's videotestsrc, the GStreamer 1.14 binary of this image,
- * writes video/x-bayer itself from the ARGB it paints; its mosaic equals this
- * function of its ARGB frame for all four orders (tests/test_oracle.py). */
+ * PARITY PINNED (round 5): the reference's own gst_rgb2bayer_transform
+ * (gstrgb2bayer.c:229-278) is compiled where it lies into
+ * oracle/_ref/libbayer_frame_ref.so (oracle/Makefile: ref_frame; its lines are
+ * extracted at build time, real GStreamer 1.14 headers, no stand-ins); this
+ * function equals it byte for byte incl. odd sizes and padded source rows, and
+ * tests/golden/rgb2bayer_small.npz + the rgb2bayer md5 table hold its outputs
+ * (tests/test_oracle.py).  Second, independent cross-check of the site ->
+ * channel mapping: gst-plugins-base's videotestsrc, the GStreamer 1.14 binary
+ * of this image, writes video/x-bayer itself from the ARGB it paints; its
+ * mosaic equals this function of its ARGB frame for all four orders. */
 int oracle_rgb2bayer (uint8_t *dst, int dst_stride, const uint8_t *src,
     int src_stride, int width, int height, int pattern, int r_off, int g_off,
     int b_off);

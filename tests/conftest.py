@@ -72,3 +72,10 @@ def _fresh_plan_cache():
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "bayer2rgb_small.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_r2b():
+    """rgb2bayer fixtures: outputs of the reference's own gst_rgb2bayer_transform (tests/golden/make_golden.py)."""
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "rgb2bayer_small.npz"))

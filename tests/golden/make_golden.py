@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/bayer2rgb_small.npz and tests/golden/known_md5.json.
+"""Generates tests/golden/bayer2rgb_small.npz, tests/golden/rgb2bayer_small.npz and tests/golden/known_md5.json.
 
 Run in the build container, where /root/reference is mounted:  python tests/golden/make_golden.py
 
-Expected outputs come from oracle_bayer2rgb_refrows(), i.e. every row is computed by the
-REFERENCE's own compiled row kernels (oracle/_ref/libbayerorc_ref.so = gst/bayer/gstbayerorc-dist.c
-built with the reference's -DDISABLE_ORC mode); inputs come from the counter-based generator of
-SURVEY.md Appendix C.  known_md5.json records the whole-element known answers that the survey
-session obtained from the compiled reference element; this script
-re-derives each of them through the reference row kernels and refuses to write the file if any
-differs.
+Every expected output is computed by the REFERENCE'S OWN FRAME-LEVEL FUNCTIONS compiled here
+(oracle/_ref/libbayer_frame_ref.so, `make -C oracle ref_frame`): gst_bayer2rgb_process
+(gst/bayer/gstbayer2rgb.c:387-451, with its row helper :354-381 and the reference's -DDISABLE_ORC row
+kernels) and gst_rgb2bayer_transform (gst/bayer/gstrgb2bayer.c:229-278).  The restated frame driver over
+the reference's row kernels (oracle_bayer2rgb_refrows) must agree byte for byte, or nothing is written.
+Inputs come from the counter-based generator of SURVEY.md Appendix C.  known_md5.json holds the
+whole-element known answers the survey session recorded -- re-derived here through
+the reference's frame driver, refused if any differs -- plus rgb2bayer known answers at full size from the
+reference's transform.
 """
 import hashlib
 import json
@@ -43,9 +45,22 @@ def md5(a):
     return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+# rgb2bayer: (W, H, extra bytes per source row); odd widths and heights included (the reference accepts them)
+R2B_SMALL = [(1, 1, 0), (2, 3, 0), (3, 2, 0), (5, 7, 0), (5, 7, 8), (16, 9, 0), (66, 50, 0), (101, 33, 0), (64, 48, 0),
+             (130, 21, 24), (257, 5, 0), (1030, 17, 0)]
+# rgb2bayer at full size: (W, H, seed, pattern) -> md5 of the reference's mosaic
+R2B_KNOWN = [(1920, 1080, 1, "rggb"), (3840, 2160, 2, "bggr"), (3840, 2160, 2, "gbrg"), (3840, 2160, 2, "grbg"),
+             (3840, 2160, 2, "rggb"), (3841, 2161, 4, "grbg")]
+
+
+def argb_frame(w, h, seed, pad=0):
+    """An ARGB frame (H, 4W + pad) from the Appendix C generator (a 4W x H byte image)."""
+    return oracle.fill_synthetic(4 * w + pad, h, 1, seed=seed)[0]
+
+
 def main():
-    if not oracle.have_ref_rows():
-        sys.exit("oracle/_ref/libbayerorc_ref.so missing: run `make -C oracle` where /root/reference exists")
+    if not oracle.have_ref_rows() or not oracle.have_ref_frame():
+        sys.exit("oracle/_ref/*.so missing: run `make -C oracle` where /root/reference exists")
     arrays = {}
     for i, (w, h) in enumerate(SMALL):
         stride = (w + 3) & ~3
@@ -54,24 +69,47 @@ def main():
         for pat in PATTERNS:
             for lay in LAYOUTS:
                 r, g, b = oracle.LAYOUTS[lay]
-                arrays["out_%dx%d_%s_%s" % (w, h, pat, lay)] = oracle.bayer2rgb(
-                    src, w, pat, r, g, b, ref_rows=True)
+                out = oracle.ref_frame_bayer2rgb(src, w, pat, r, g, b)
+                if not np.array_equal(out, oracle.bayer2rgb(src, w, pat, r, g, b, ref_rows=True)):
+                    sys.exit("reference frame driver and restated driver over reference rows differ: %s"
+                             % ((w, h, pat, lay),))
+                arrays["out_%dx%d_%s_%s" % (w, h, pat, lay)] = out
     np.savez_compressed(os.path.join(HERE, "bayer2rgb_small.npz"), **arrays)
+
+    inv = {}
+    for i, (w, h, pad) in enumerate(R2B_SMALL):
+        key = "%dx%d%s" % (w, h, "p%d" % pad if pad else "")
+        src = argb_frame(w, h, 200 + i, pad)
+        inv["in_" + key] = src
+        for pat in PATTERNS:
+            inv["out_%s_%s" % (key, pat)] = oracle.ref_frame_rgb2bayer(src, w, pat)[:, :w]
+    np.savez_compressed(os.path.join(HERE, "rgb2bayer_small.npz"), **inv)
 
     table = []
     for (w, h, seed, pat, lay, md5_in, md5_out) in KNOWN:
         src = oracle.fill_synthetic(w, h, 1, seed=seed)[0]
         r, g, b = oracle.LAYOUTS[lay]
-        out = oracle.bayer2rgb(src, w, pat, r, g, b, ref_rows=True)
+        out = oracle.ref_frame_bayer2rgb(src, w, pat, r, g, b)
         if md5(src) != md5_in or md5(out) != md5_out:
             sys.exit("known answer %s does not reproduce" % ((w, h, seed, pat, lay),))
         table.append(dict(width=w, height=h, seed=seed, pattern=pat, format=lay,
                           md5_input=md5_in, md5_output=md5_out))
+    inv_table = []
+    for (w, h, seed, pat) in R2B_KNOWN:
+        src = argb_frame(w, h, seed)
+        out = oracle.ref_frame_rgb2bayer(src, w, pat)[:, :w]
+        inv_table.append(dict(width=w, height=h, seed=seed, pattern=pat, format="ARGB",
+                              md5_input=md5(src), md5_output=md5(out)))
     with open(os.path.join(HERE, "known_md5.json"), "w") as f:
-        json.dump({"source": "SURVEY.md Appendix B.3 (compiled reference element), re-derived through "
-                             "oracle/_ref reference row kernels by tests/golden/make_golden.py",
-                   "entries": table}, f, indent=1)
-    print("wrote %d arrays, %d known answers" % (len(arrays), len(table)))
+        json.dump({"source": "SURVEY.md Appendix B.3 (compiled reference element), re-derived through the "
+                             "reference's own gst_bayer2rgb_process (oracle/_ref/libbayer_frame_ref.so) by "
+                             "tests/golden/make_golden.py",
+                   "entries": table,
+                   "rgb2bayer_source": "the reference's own gst_rgb2bayer_transform (gstrgb2bayer.c:229-278) compiled "
+                                       "here; input = Appendix C generator as a 4W x H byte image (ARGB), output = the "
+                                       "W valid columns of each mosaic row",
+                   "rgb2bayer_entries": inv_table}, f, indent=1)
+    print("wrote %d + %d arrays, %d + %d known answers" % (len(arrays), len(inv), len(table), len(inv_table)))
 
 
 if __name__ == "__main__":

@@ -170,6 +170,27 @@ def test_known_md5_answers_full_size(gpu_pkg):
             ctx.device_free(d_dst)
 
 
+def test_hip_equals_the_reference_frame_driver_directly(gpu_pkg, oracle):
+    """HIP output against the REFERENCE'S OWN gst_bayer2rgb_process (gstbayer2rgb.c:387-451, compiled into
+    oracle/_ref/libbayer_frame_ref.so, which travels to the GPU box as a binary) with no restatement in between:
+    1080p, 4K, camera geometries off every grid, one order x layout each way round."""
+    if not oracle.have_ref_frame():
+        pytest.skip("oracle/_ref/libbayer_frame_ref.so not on this box")
+    rng = np.random.default_rng(77)
+    cases = [(1920, 1080, "rggb", "BGRx"), (3840, 2160, "bggr", "RGBx"), (3840, 2160, "grbg", "xBGR"),
+             (3838, 2160, "gbrg", "ARGB"), (4056, 3040, "rggb", "RGBA"), (1366, 768, "grbg", "BGRA"),
+             (2590, 1942, "bggr", "xRGB"), (640, 480, "bggr", "RGBx"), (4, 3, "gbrg", "ABGR"), (66, 7, "rggb", "BGRx")]
+    for (w, h, pat, fmt) in cases:
+        src = rng.integers(0, 256, (h, (w + 3) & ~3), dtype=np.uint8)
+        r, g, b = gpu_pkg.FORMATS[fmt]
+        want = oracle.ref_frame_bayer2rgb(src, w, pat, r, g, b)
+        with gpu_pkg.Context(w, h, pat, fmt, src_stride=src.shape[1]) as ctx:
+            got_d = ctx.process_batch_via_device(src[None])[0]
+            got_h = ctx.process_host(src)
+        assert np.array_equal(got_d, want), (w, h, pat, fmt)
+        assert np.array_equal(got_h, want), (w, h, pat, fmt)
+
+
 def test_batch_launch_equals_per_frame(gpu_pkg, oracle):
     """One launch over N frames (blockIdx decodes frame, tile) == N oracle frames; also with a
     frame pitch larger than the frame (gaps must stay untouched)."""

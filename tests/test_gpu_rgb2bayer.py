@@ -1,5 +1,10 @@
 """GPU tests of the inverse direction (MIBAYER_FLAG_RGB2BAYER; reference gst/bayer/gstrgb2bayer.c:230-278):
-bit-exact against the oracle, exact left inverse of bayer2rgb at full size, and through the element."""
+bit-exact against the committed outputs of the reference's own gst_rgb2bayer_transform (tests/golden/
+rgb2bayer_small.npz, the rgb2bayer md5 table), against the oracle pinned to it, exact left inverse of bayer2rgb at full
+size, and through the element."""
+import hashlib
+import json
+import os
 import subprocess
 
 import numpy as np
@@ -9,6 +14,64 @@ from test_gst_element import GST_LAUNCH, gst_env, needs_gst, plugin  # noqa: F40
 
 pytestmark = pytest.mark.gpu
 PATTERNS = ("bggr", "gbrg", "grbg", "rggb")
+
+
+def test_rgb2bayer_golden_fixtures_of_the_reference_transform(gpu_pkg, golden_r2b):
+    """HIP path vs the committed outputs of the reference's gst_rgb2bayer_transform (no oracle in between): every
+    fixture (odd sizes, padded source rows) x 4 orders, host path and device-resident path."""
+    names = [k for k in golden_r2b.files if k.startswith("in_")]
+    assert len(names) >= 12
+    for name in names:
+        key = name[3:]
+        dims, _, pad = key.partition("p")
+        w, h = (int(v) for v in dims.split("x"))
+        pad = int(pad or 0)
+        src = golden_r2b[name]
+        for pat in PATTERNS:
+            want = golden_r2b["out_%s_%s" % (key, pat)]
+            with gpu_pkg.Context(w, h, pat, (1, 2, 3), src_stride=4 * w + pad, flags=gpu_pkg.FLAG_RGB2BAYER) as ctx:
+                got_h = ctx.process_host(src)
+                got_d = ctx.process_batch_via_device(src[None])[0]
+            assert np.array_equal(got_h[:, :w], want), (key, pat)
+            assert np.array_equal(got_d[:, :w], want), (key, pat)
+
+
+def test_rgb2bayer_known_md5_answers_full_size(gpu_pkg):
+    """1080p / 4K / an odd 3841x2161 frame: md5 of the HIP mosaic == md5 of the reference transform's mosaic
+    (tests/golden/known_md5.json: rgb2bayer_entries; inputs regenerated on the device's host side by the Appendix C
+    generator, so no oracle arithmetic takes part)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "known_md5.json")) as f:
+        entries = json.load(f)["rgb2bayer_entries"]
+    assert len(entries) >= 6
+    for e in entries:
+        w, h = e["width"], e["height"]
+        # the ARGB frame is the generator's 4W x H byte image
+        with gpu_pkg.Context(4 * w, h, "bggr", "RGBx") as gen:
+            d = gen.device_alloc(4 * w * h)
+            gen.fill_synthetic(d, 1, seed=e["seed"])
+            gen.sync()
+            src = gen.from_device(d, 4 * w * h).reshape(h, 4 * w)
+            gen.device_free(d)
+        assert hashlib.md5(src.tobytes()).hexdigest() == e["md5_input"]
+        with gpu_pkg.Context(w, h, e["pattern"], (1, 2, 3), flags=gpu_pkg.FLAG_RGB2BAYER) as ctx:
+            got = ctx.process_batch_via_device(src[None])[0]
+        assert hashlib.md5(np.ascontiguousarray(got[:, :w]).tobytes()).hexdigest() == e["md5_output"], e
+
+
+def test_rgb2bayer_equals_the_reference_transform_directly(gpu_pkg, oracle):
+    """HIP mosaic against the REFERENCE'S OWN gst_rgb2bayer_transform (oracle/_ref/libbayer_frame_ref.so on this box),
+    no restatement in between: 4K, 1080p, odd and padded geometries."""
+    if not oracle.have_ref_frame():
+        pytest.skip("oracle/_ref/libbayer_frame_ref.so not on this box")
+    rng = np.random.default_rng(78)
+    for (w, h, pad, pat) in [(3840, 2160, 0, "rggb"), (1920, 1080, 0, "gbrg"), (3841, 2161, 0, "grbg"),
+                             (1367, 769, 40, "bggr"), (5, 7, 8, "gbrg"), (1, 1, 0, "rggb")]:
+        src = rng.integers(0, 256, (h, 4 * w + pad), dtype=np.uint8)
+        want = oracle.ref_frame_rgb2bayer(src, w, pat)
+        with gpu_pkg.Context(w, h, pat, (1, 2, 3), src_stride=4 * w + pad, flags=gpu_pkg.FLAG_RGB2BAYER) as ctx:
+            got = ctx.process_batch_via_device(src[None])[0]
+        assert np.array_equal(got[:, :w], want[:, :w]), (w, h, pad, pat)
 
 
 def test_rgb2bayer_matches_oracle_all_sizes(gpu_pkg, oracle):

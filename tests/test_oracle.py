@@ -1,7 +1,8 @@
 """CPU tests of the oracle itself: it must reproduce the reference before it may judge the HIP path.
 
-Pins (see oracle/README.md): reference row kernels (oracle/_ref, when present), the survey's
-whole-element md5 known answers, the hand-checkable 4x4 frame, committed golden fixtures."""
+Pins (see oracle/README.md): the reference's own frame-level functions and row kernels compiled here (oracle/_ref,
+when present), the whole-element md5 known answers, the hand-checkable 4x4 frame, committed golden fixtures (generated
+through the reference's frame functions)."""
 import hashlib
 import json
 import os
@@ -76,6 +77,98 @@ def test_golden_fixtures_all_implementations(oracle, golden):
                 got_np = oracle.np_oracle.bayer2rgb(src[:, :w], pat, r, g, b).reshape(h, 4 * w)
                 assert np.array_equal(got_c, want), (dims, pat, lay)
                 assert np.array_equal(got_np, want), (dims, pat, lay)
+
+
+def r2b_key_dims(name):
+    """'in_5x7p8' -> ('5x7p8', 5, 7, 8)"""
+    key = name[3:]
+    dims, _, pad = key.partition("p")
+    w, h = (int(v) for v in dims.split("x"))
+    return key, w, h, int(pad or 0)
+
+
+def test_oracle_equals_reference_frame_driver(oracle):
+    """The restated frame driver (ring priming, up(0) = 1, dn(H-1) = H-4, the four edge columns, pattern symmetry)
+    against the REFERENCE'S OWN gst_bayer2rgb_process (gstbayer2rgb.c:387-451) compiled here: golden size list,
+    camera widths off every grid, padded source and destination rows; C and NumPy forms."""
+    if not oracle.have_ref_frame():
+        pytest.skip("oracle/_ref/libbayer_frame_ref.so not built (needs /root/reference at build time)")
+    rng = np.random.default_rng(55)
+    sizes = [(w, h) for w in (4, 6, 8, 66) for h in (3, 4, 5, 6, 7)] + [
+        (64, 48), (16, 3), (258, 9), (130, 33), (1366, 11), (3838, 6), (4056, 5), (2590, 7), (640, 480), (1920, 31)]
+    n = 0
+    for (w, h) in sizes:
+        src = rng.integers(0, 256, (h, (w + 3) & ~3), dtype=np.uint8)
+        if w == 66:
+            src[::2] = 255
+            src[1::2] &= 1
+        for pat in PATTERNS:
+            for lay in sorted(oracle.LAYOUTS):
+                r, g, b = oracle.LAYOUTS[lay]
+                want = oracle.ref_frame_bayer2rgb(src, w, pat, r, g, b)
+                assert np.array_equal(oracle.bayer2rgb(src, w, pat, r, g, b), want), (w, h, pat, lay)
+                if w * h <= 70 * 70:
+                    got_np = oracle.np_oracle.bayer2rgb(src[:, :w], pat, r, g, b).reshape(h, 4 * w)
+                    assert np.array_equal(got_np, want), (w, h, pat, lay)
+                n += 1
+    assert n == len(sizes) * 4 * len(oracle.LAYOUTS)
+    # padded rows on both sides: the reference honours the strides it is given (:476-477)
+    src = rng.integers(0, 256, (9, 140), dtype=np.uint8)
+    a = oracle.ref_frame_bayer2rgb(src, 130, "gbrg", 3, 2, 1, dst_stride=4 * 130 + 40)
+    assert np.array_equal(a, oracle.bayer2rgb(src, 130, "gbrg", 3, 2, 1, dst_stride=4 * 130 + 40))
+    assert (a[:, 4 * 130:] == 0xA5).all()
+
+
+def test_known_md5_answers_reproduce_through_the_reference_frame_driver(oracle):
+    if not oracle.have_ref_frame():
+        pytest.skip("oracle/_ref/libbayer_frame_ref.so not built")
+    with open(os.path.join(ROOT, "tests", "golden", "known_md5.json")) as f:
+        entries = json.load(f)["entries"]
+    for e in entries:
+        if e["width"] > 3840:
+            continue        # 8K: covered by make_golden.py itself; keep the CPU suite short
+        src = oracle.fill_synthetic(e["width"], e["height"], 1, e["seed"])[0]
+        r, g, b = oracle.LAYOUTS[e["format"]]
+        assert md5(oracle.ref_frame_bayer2rgb(src, e["width"], e["pattern"], r, g, b)) == e["md5_output"], e
+
+
+def test_rgb2bayer_oracle_equals_reference_transform(oracle):
+    """oracle.rgb2bayer (C and NumPy) against the REFERENCE'S OWN gst_rgb2bayer_transform (gstrgb2bayer.c:229-278)
+    compiled here: odd and even sizes, padded source rows (GstVideoMeta stride), all four orders."""
+    if not oracle.have_ref_frame():
+        pytest.skip("oracle/_ref/libbayer_frame_ref.so not built (needs /root/reference at build time)")
+    rng = np.random.default_rng(56)
+    for (w, h, pad) in [(1, 1, 0), (2, 3, 0), (3, 2, 0), (5, 7, 0), (5, 7, 8), (16, 9, 0), (66, 50, 0), (101, 33, 0),
+                        (130, 21, 24), (257, 5, 0), (1030, 17, 0), (1920, 31, 0), (3840, 9, 0)]:
+        src = rng.integers(0, 256, (h, 4 * w + pad), dtype=np.uint8)
+        for pat in PATTERNS:
+            want = oracle.ref_frame_rgb2bayer(src, w, pat)
+            got = oracle.rgb2bayer(src, w, pat, 1, 2, 3)
+            assert np.array_equal(got, want), (w, h, pad, pat)      # incl. the untouched padding columns
+            got_np = oracle.np_oracle.rgb2bayer(src[:, :4 * w].reshape(h, w, 4), pat, 1, 2, 3)
+            assert np.array_equal(got_np, want[:, :w]), (w, h, pad, pat)
+
+
+def test_rgb2bayer_golden_fixtures_and_known_md5(oracle, golden_r2b):
+    """Committed outputs of the reference's gst_rgb2bayer_transform: the oracle reproduces every one (runs on boxes
+    without oracle/_ref too)."""
+    names = [k for k in golden_r2b.files if k.startswith("in_")]
+    assert len(names) >= 12
+    for name in names:
+        key, w, h, pad = r2b_key_dims(name)
+        src = golden_r2b[name]
+        assert src.shape == (h, 4 * w + pad)
+        for pat in PATTERNS:
+            want = golden_r2b["out_%s_%s" % (key, pat)]
+            assert np.array_equal(oracle.rgb2bayer(src, w, pat, 1, 2, 3)[:, :w], want), (key, pat)
+    with open(os.path.join(ROOT, "tests", "golden", "known_md5.json")) as f:
+        entries = json.load(f)["rgb2bayer_entries"]
+    assert len(entries) >= 6
+    for e in entries:
+        w, h = e["width"], e["height"]
+        src = oracle.fill_synthetic(4 * w, h, 1, e["seed"])[0]
+        assert md5(src) == e["md5_input"]
+        assert md5(oracle.rgb2bayer(src, w, e["pattern"], 1, 2, 3)[:, :w]) == e["md5_output"], e
 
 
 def test_own_rows_equal_reference_rows(oracle):
@@ -212,7 +305,8 @@ def test_domain_is_rejected(oracle):
 
 
 def test_rgb2bayer_oracle_forms_agree_and_invert_bayer2rgb(oracle):
-    """rgb2bayer (gstrgb2bayer.c:254-268; parity unpinned) in C and NumPy agree, and it is the exact left
+    """rgb2bayer (gstrgb2bayer.c:254-268) in C and NumPy agree for every 4-byte layout (the reference's ARGB and the
+    three this build adds), and it is the exact left
     inverse of bayer2rgb: every output pixel of bayer2rgb carries the original sample at its own CFA site."""
     rng = np.random.default_rng(8)
     for (w, h) in [(1, 1), (3, 2), (5, 7), (16, 9), (66, 50)]:
@@ -238,8 +332,8 @@ def test_rgb2bayer_oracle_matches_videotestsrc_bayer_writer(oracle, tmp_path):
     """An independent pin for the CFA-site -> channel mapping of the rgb2bayer oracle: gst-plugins-base's videotestsrc
     (the GStreamer 1.14 binary of this image, not part of the reference tree) paints every pattern as ARGB and, for
     video/x-bayer caps, writes the mosaic itself.  For the same pattern and size that mosaic must be exactly
-    rgb2bayer(ARGB frame) for all four orders.  (The reference's rgb2bayer element itself cannot be built here and its
-    tests hold no vectors -- parity with *it* stays unpinned, see bayer2rgb_oracle.h.)"""
+    rgb2bayer(ARGB frame) for all four orders.  (A second, independent pin next to the reference's own transform
+    function: test_rgb2bayer_oracle_equals_reference_transform.)"""
     import subprocess
     from test_gst_element import GST_LAUNCH, GST_PREFIX
     if not os.path.exists(GST_LAUNCH):
