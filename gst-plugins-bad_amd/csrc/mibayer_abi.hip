@@ -333,6 +333,7 @@ struct Wedge {
   int device = 0;
   std::vector<hipEvent_t> fences;       /* behind everything the context had queued when the deadline hit */
   bool settled = false;
+  bool incomplete = false;              /* a queue could not be fenced: never settles (fail closed) */
   bool orphan = false;                  /* its context has been destroyed: the registry owns what follows */
   std::vector<void *> dev_mem;
   std::vector<hipEvent_t> events;
@@ -364,6 +365,22 @@ static void release_wedge_resources (Wedge *w)
   (void) hipGetLastError ();
 }
 
+/* errors after which nothing queued on the device will run any more (sticky: the process has lost its GPU state) */
+static bool device_is_gone (hipError_t e)
+{
+  switch (e) {
+    case hipErrorIllegalAddress:
+    case hipErrorLaunchFailure:
+    case hipErrorECCNotCorrectable:
+    case hipErrorNoDevice:
+    case hipErrorDeinitialized:
+    case hipErrorContextIsDestroyed:
+      return true;
+    default:
+      return false;
+  }
+}
+
 /* g_wedge_mu held.  Non-blocking: one hipEventQuery per outstanding fence. */
 static void poll_wedges_locked ()
 {
@@ -374,10 +391,17 @@ static void poll_wedges_locked ()
       (void) hipGetDevice (&prev);
       if (prev != w->device)
         (void) hipSetDevice (w->device);
-      bool done = true;
-      for (hipEvent_t e : w->fences)
-        if (hipEventQuery (e) == hipErrorNotReady)    /* an error state ends the wait too: the queue is dead */
+      /* Fail closed: a wedge that could not fence every queue never settles (its buffers are leaked
+       * rather than handed back under a DMA that may still run), and only hipSuccess or an error that says the
+       * device context is gone -- nothing queued will ever execute -- ends the wait for a fence. */
+      bool done = !w->incomplete;
+      for (hipEvent_t e : w->fences) {
+        if (!done)
+          break;
+        const hipError_t q = hipEventQuery (e);
+        if (q != hipSuccess && !device_is_gone (q))
           done = false;
+      }
       (void) hipGetLastError ();
       if (done) {
         w->settled = true;
@@ -434,10 +458,15 @@ static void on_deadline (mibayer_ctx *c)
       queues.push_back (sl.s_graph);
   for (hipStream_t q : queues) {
     hipEvent_t ev = nullptr;
-    if (!q || hipEventCreateWithFlags (&ev, hipEventDisableTiming) != hipSuccess)
+    if (!q)
       continue;
+    if (hipEventCreateWithFlags (&ev, hipEventDisableTiming) != hipSuccess) {
+      w->incomplete = true;     /* a queue without a fence: this wedge can never be called settled */
+      continue;
+    }
     if (hipEventRecord (ev, q) != hipSuccess) {
       (void) hipEventDestroy (ev);
+      w->incomplete = true;
       continue;
     }
     w->fences.push_back (ev);
@@ -2081,7 +2110,9 @@ extern "C" int mibayer_sync (mibayer_ctx *c)
   if (rc != MIBAYER_OK)
     return rc;
   if (c->dirty_compute) {
-    if (c->wedged)
+    /* not `c->wedged`: with nothing pending wait_own_frames() polled nothing, so this is where a context whose
+     * device-resident launch ran into a deadline finds out that the device has caught up */
+    if (wedged_for_good (c))
       return MIBAYER_ERR_TIMEOUT;
     HIP_TRY (hipEventRecord (c->ev_fence, c->s_compute));
     rc = wait_event (c, c->ev_fence, true);

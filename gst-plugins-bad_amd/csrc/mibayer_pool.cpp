@@ -748,6 +748,17 @@ extern "C" int mibayer_pool_wait (mibayer_pool *pool, void **tag)
     if (state == F_FAILED)
       return f.rc;              /* not a device failure (those become F_REDO): the caller's to handle */
     if (state == F_LOST) {
+      /* The helper thread may have marked it while the shard still counts as alive to this thread: take the shard
+       * out first, so that mibayer_pool_alive() / take_failure already tell the caller what happened
+       * when the lost frame comes back, and kill_shard() has its last word on held-vs-quiesced (a context that
+       * could be quiesced after all turns the frame into F_REDO: converted elsewhere instead of lost). */
+      (void) reap_if_broken (pool, f.shard);
+      {
+        std::lock_guard<std::mutex> lk (sh->mu);
+        state = f.state;
+      }
+      if (state != F_LOST)
+        continue;
       /* in flight on a device that ran into the deadline: handed back as lost, in order; its buffers stay the
        * device's until mibayer_pool_reclaim() says otherwise */
       pool->lost.push_back (mibayer_pool::Lost { f.tag, f.shard });

@@ -1250,6 +1250,25 @@ host_dst[...] = 0
 ctx5.submit(host_src, host_dst, 8)
 assert ctx5.wait() == 8 and np.array_equal(host_dst, want)
 ctx5.close()
+# the same for a DEVICE-RESIDENT context (hipbayer2rgb's mibayer_sync, Context.sync(); ADVICE r04): nothing is pending
+# in its ring, so mibayer_sync itself must find out that the device has caught up
+ctx6 = pkg.Context(w, h, "rggb", "BGRx")
+d_src, d_dst = ctx6.device_alloc(ctx6.src_bytes), ctx6.device_alloc(ctx6.dst_bytes)
+ctx6.to_device(d_src, src)
+ctx6.process_device(d_src, d_dst, 1)
+ctx6.sync()
+ctx6.set_wait_timeout(100)
+ctx6.stall(700)
+ctx6.process_device(d_src, d_dst, 1)
+assert status_of(ctx6.sync) == pkg.ERR_TIMEOUT and status_of(ctx6.sync) == pkg.ERR_TIMEOUT
+assert L.mibayer_wedged_contexts() == 1
+time.sleep(0.8)
+assert status_of(ctx6.sync) == pkg.OK and L.mibayer_wedged_contexts() == 0     # healed, within the 100 ms deadline
+ctx6.process_device(d_src, d_dst, 1)
+ctx6.sync()
+assert np.array_equal(ctx6.from_device(d_dst, ctx6.dst_bytes).reshape(want.shape), want)
+ctx6.device_free(d_src); ctx6.device_free(d_dst)
+ctx6.close()
 L.mibayer_host_free(p_src)
 L.mibayer_host_free(p_dst)
 assert L.mibayer_deferred_frees() == 0                      # really freed: no wedge is outstanding any more
