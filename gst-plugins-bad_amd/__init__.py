@@ -147,6 +147,9 @@ ABI = {
     "mibayer_get_plan": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                         ctypes.POINTER(ctypes.c_int)]),
     "mibayer_set_plan": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mibayer_get_plan_for": (ctypes.c_int, [_vp, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 4),
+    "mibayer_set_plan_for": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mibayer_ctx_stream2": (_vp, [_vp]),
     "mibayer_plan_source": (ctypes.c_int, [_vp]),
     "mibayer_plan_from_cache": (ctypes.c_int, [_vp]),
     "mibayer_plan_cache_clear": (None, []),
@@ -209,7 +212,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.mibayer_abi_version() != 4:
+        if L.mibayer_abi_version() != 5:
             raise MibayerErrorNoLib("libmibayer.so ABI version mismatch")
         _lib = L
     return _lib
@@ -494,6 +497,24 @@ class Context:
         v, b, a = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _check(lib().mibayer_get_plan(self._h, ctypes.byref(v), ctypes.byref(b), ctypes.byref(a)), "mibayer_get_plan")
         return v.value, b.value, a.value
+
+    def get_plan_for(self, nframes):
+        """(variant id, band override, store alignment, source) of the launch class an nframes-frame launch falls into"""
+        v, b, a, s = (ctypes.c_int() for _ in range(4))
+        _check(lib().mibayer_get_plan_for(self._h, nframes, ctypes.byref(v), ctypes.byref(b), ctypes.byref(a),
+                                          ctypes.byref(s)), "mibayer_get_plan_for")
+        return v.value, b.value, a.value, s.value
+
+    def set_plan_for(self, nframes, variant, band, align=0):
+        _check(lib().mibayer_set_plan_for(self._h, nframes, variant, band, align), "mibayer_set_plan_for")
+
+    @property
+    def stream2(self):
+        """The context's second compute stream (hipStream_t as an int), created on first use."""
+        s = lib().mibayer_ctx_stream2(self._h)
+        if not s:
+            raise MibayerError(ERR_HIP, "mibayer_ctx_stream2")
+        return s
 
     def set_plan(self, variant, band, align=0):
         _check(lib().mibayer_set_plan(self._h, variant, band, align), "mibayer_set_plan")

@@ -157,6 +157,7 @@ struct Slot {
   hipGraph_t cgraph = nullptr;
   hipGraphExec_t cexec = nullptr;
   bool cgraph_events = false;     /* the graph holds the event nodes too */
+  unsigned plan_epoch = 0;        /* mibayer_ctx::plan_epoch both graphs were built under */
 };
 
 int device_count_cached ()
@@ -248,6 +249,14 @@ static bool shared_queues_enabled ()
 
 struct Wedge;
 
+enum { PLAN_BATCH = 0, PLAN_FRAME = 1, PLAN_CLASSES = 2 };
+struct Plan {
+  const Variant *var = nullptr;
+  int band = INT32_MIN;
+  int align = 0;
+  int source = MIBAYER_PLAN_DEFAULT;
+};
+
 struct mibayer_ctx {
   mibayer_cfg cfg;
   int device = 0;
@@ -258,20 +267,24 @@ struct mibayer_ctx {
   int swap_rows = 0;
   bool inverse = false;                 /* MIBAYER_FLAG_RGB2BAYER */
   uint32_t r2b_lo[2], r2b_hi[2];        /* rgb2bayer v_perm selectors per row parity */
-  const Variant *var = nullptr;         /* launch plan: tile shape ...                */
-  int band_override = INT32_MIN;        /* ... and XCD band (INT32_MIN = the variant's);
-                                           set by MIBAYER_XCD_BAND or mibayer_autotune() */
+  /* Launch plan: tile shape (kernel variant), XCD band (INT32_MIN = the variant's; MIBAYER_XCD_BAND or
+   * mibayer_autotune() set it), store alignment of the generic arm, and where the three came from
+   * (mibayer_plan_source).  One plan per LAUNCH CLASS (round 5): PLAN_BATCH for launches that keep every workgroup
+   * slot of the device busy for many rounds (the 64-frame batch of the bench), PLAN_FRAME for launches of at most
+   * kFrameClassRounds rounds -- one frame per launch, what the elements and the host path issue -- where the number
+   * of rounds the grid needs decides (launch_class(), frame_class_variant()).  A plan measured on one class never
+   * becomes the default of the other. */
+  Plan plan[PLAN_CLASSES];
+  unsigned plan_epoch = 0;              /* bumped by every plan change: graphs captured under an older one are rebuilt */
   int num_cus = 256;                    /* hipDeviceProp_t.multiProcessorCount */
   int persist_wgs_per_cu = 4;           /* MIBAYER_PERSIST_WGS (tuning), persistent arms */
   bool rows_off_sector = false;         /* dst_stride % 64 != 0: see plain_store_twin () */
-  int align_stores = 0;                 /* generic geometries with output rows off the sector grid: boundary (bytes)
-                                           every wave-store starts on (the shifted arm, bayer2rgb_lds_aligned_kernel);
-                                           0 = the unshifted generic arm.  Chosen by mibayer_autotune() where it
-                                           wins; MIBAYER_ALIGN_STORES = 0 | 64 | 128 forces it (-1 in the
-                                           environment keeps it out of the autotuner's candidates) */
+  /* Plan::align -- generic geometries with output rows off the sector grid: boundary (bytes) every wave-store starts
+   * on (the shifted arm, bayer2rgb_lds_aligned_kernel); 0 = the unshifted generic arm.  Chosen by mibayer_autotune()
+   * where it wins; MIBAYER_ALIGN_STORES = 0 | 64 | 128 forces it (-1 in the environment keeps it out of the
+   * autotuner's candidates) */
   bool align_tunable = true;
   bool band_forced = false;             /* the block order was pinned from outside (lab builds: MIBAYER_XCD_BAND) */
-  int plan_source = MIBAYER_PLAN_DEFAULT;  /* where var / band_override / align_stores came from (mibayer_plan_source) */
   int graph_mode = 0;                   /* MIBAYER_FLAG_HIPGRAPH: 0 = the compute-queue segment of a frame as
                                            a graph per slot (default), 1 = the whole upload -> kernel ->
                                            download chain as a graph per slot on the slot's own queue
@@ -290,6 +303,12 @@ struct mibayer_ctx {
   hipStream_t s_compute = nullptr;
   hipStream_t s_d2h = nullptr;
   bool shared_queues = false;           /* the three above belong to g_queues[device] */
+  /* A second compute queue, the context's own, created by the first mibayer_ctx_stream2(): device-resident callers
+   * deal consecutive, independent single-frame launches alternately over s_compute and this one, so that the ramp-up
+   * of frame n+1 overlaps the drain of frame n (a one-frame launch is one round of workgroups: it never reaches a
+   * steady state by itself; profiles/r05_single_frame.md) */
+  hipStream_t s_compute2 = nullptr;
+  bool dirty_compute2 = false;          /* as dirty_compute, for s_compute2 */
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_fence = nullptr;        /* fence of mibayer_sync / of a failed submit */
   /* Deadline of every host-side wait for the device (mibayer_wait, the synchronous frame call, sync, destroy):
@@ -452,7 +471,7 @@ static void on_deadline (mibayer_ctx *c)
   if (!w)
     return;
   w->device = c->device;
-  std::vector<hipStream_t> queues = { c->s_h2d, c->s_compute, c->s_d2h };
+  std::vector<hipStream_t> queues = { c->s_h2d, c->s_compute, c->s_d2h, c->s_compute2 };
   for (Slot &sl : c->ring)
     if (sl.s_graph)
       queues.push_back (sl.s_graph);
@@ -579,7 +598,7 @@ static void fence_queues (mibayer_ctx *c)
 {
   if (c->wedged || !c->ev_fence)
     return;
-  for (hipStream_t q : { c->s_h2d, c->s_compute, c->s_d2h }) {
+  for (hipStream_t q : { c->s_h2d, c->s_compute, c->s_d2h, c->s_compute2 }) {
     if (!q)
       continue;
     if (hipEventRecord (c->ev_fence, q) != hipSuccess) {
@@ -677,17 +696,39 @@ static bool aligned16 (const void *p)
   return (((uintptr_t) p) & 15u) == 0;
 }
 
+/* Launches of at most this many rounds of workgroups take the PLAN_FRAME plan (a production workgroup covers 8192
+ * pixels, a device holds 4 of them per CU): on 256 CUs up to 33.5 Mpixel -- one 8K frame, four 4K frames. */
+constexpr int kFrameClassRounds = 4;
+
+static int launch_class (const mibayer_ctx *c, long long nframes)
+{
+  const long long px = nframes * c->cfg.width * (long long) c->cfg.height;
+  return px <= (long long) kFrameClassRounds * c->num_cus * 4 * 8192 ? PLAN_FRAME : PLAN_BATCH;
+}
+
+static const Plan &plan_for (const mibayer_ctx *c, long long nframes)
+{
+  return c->plan[launch_class (c, nframes)];
+}
+
+static Plan &plan_for (mibayer_ctx *c, long long nframes)
+{
+  return c->plan[launch_class (c, nframes)];
+}
+
 /* tile grid of one launch (host side; the kernel gets the division-free TileMap) */
 struct Geometry {
   int tiles_x, tiles_y, band;
   long long tile_rows;
+  const Variant *var;           /* the shape the launch class of this launch runs in */
 };
 
-static void fill_params (const mibayer_ctx *c, KParams &p, Geometry &g,
+static void fill_params (const mibayer_ctx *c, const Plan &pl, KParams &p, Geometry &g,
     const void *d_src, size_t src_frame_bytes, void *d_dst,
     size_t dst_frame_bytes, int nframes)
 {
   const mibayer_cfg &f = c->cfg;
+  g.var = pl.var;
   p.src = (const uint8_t *) d_src;
   p.dst = (uint8_t *) d_dst;
   p.src_frame_bytes = src_frame_bytes;
@@ -698,10 +739,10 @@ static void fill_params (const mibayer_ctx *c, KParams &p, Geometry &g,
   p.dst_stride = f.dst_stride;
   p.wlimit4 = (f.width + 3) & ~3;
   p.dn_last = f.height >= 4 ? f.height - 4 : 1;   /* ring slot reuse, :430-447 */
-  g.tiles_x = (f.width + c->var->tile_w - 1) / c->var->tile_w;
-  g.tiles_y = (f.height + c->var->tile_h - 1) / c->var->tile_h;
+  g.tiles_x = (f.width + pl.var->tile_w - 1) / pl.var->tile_w;
+  g.tiles_y = (f.height + pl.var->tile_h - 1) / pl.var->tile_h;
   g.tile_rows = (long long) nframes * g.tiles_y;
-  int band = c->band_override != INT32_MIN ? c->band_override : c->var->band;
+  int band = pl.band != INT32_MIN ? pl.band : pl.var->band;
   if (band < 0)                 /* one contiguous chunk of tile rows per XCD */
     band = (int) ((g.tile_rows + kNumXcd - 1) / kNumXcd);
   g.band = band;
@@ -724,13 +765,14 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
     long long tile_row0 = 0, long long ntile_rows = -1, int pointers_aligned16 = -1)
 {
   Geometry g;
-  fill_params (c, p, g, d_src, src_frame_bytes, d_dst, dst_frame_bytes,
+  const Plan &pl = plan_for (c, nframes);
+  fill_params (c, pl, p, g, d_src, src_frame_bytes, d_dst, dst_frame_bytes,
       nframes);
   if (ntile_rows >= 0) {        /* one horizontal band of the batch */
     if (tile_row0 < 0 || tile_row0 + ntile_rows > g.tile_rows)
       return MIBAYER_ERR_ARG;
     g.tile_rows = ntile_rows;
-    if (c->band_override == INT32_MIN ? c->var->band < 0 : c->band_override < 0)
+    if (pl.band == INT32_MIN ? pl.var->band < 0 : pl.band < 0)
       g.band = (int) ((g.tile_rows + kNumXcd - 1) / kNumXcd);
   } else {
     tile_row0 = 0;
@@ -748,19 +790,19 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
           : (aligned16 (d_src) && aligned16 (d_dst)
               && (nframes == 1 || (src_frame_bytes % 16 == 0
                       && dst_frame_bytes % 16 == 0))));
-  kern = fast ? c->var->fast : c->var->generic;
-  if (!fast && c->align_stores && (c->align_stores == 128 ? c->var->aligned128 : c->var->aligned64)) {
+  kern = fast ? pl.var->fast : pl.var->generic;
+  if (!fast && pl.align && (pl.align == 128 ? pl.var->aligned128 : pl.var->aligned64)) {
     /* output rows off the sector grid, all of them 8-byte aligned (even per-row shifts): the sector-aligned arm */
     const bool rows8 = (f.dst_stride % 8 == 0)
         && (pointers_aligned16 >= 0 ? pointers_aligned16 >= 1
             : ((((uintptr_t) d_dst) & 7u) == 0 && (nframes == 1 || dst_frame_bytes % 8 == 0)));
-    const unsigned a = (unsigned) c->align_stores;
+    const unsigned a = (unsigned) pl.align;
     const bool on_grid = (f.dst_stride % a == 0)
         && (pointers_aligned16 >= 0 ? false
             : ((((uintptr_t) d_dst) & (a - 1)) == 0 && (nframes == 1 || dst_frame_bytes % a == 0)));
     static const bool force_arm = LAB_GETENV ("MIBAYER_FORCE_ALIGNED_ARM") != NULL;     /* A/B: tools/sweep2.py */
     if (rows8 && (!on_grid || force_arm))
-      kern = c->align_stores == 128 ? c->var->aligned128 : c->var->aligned64;
+      kern = pl.align == 128 ? pl.var->aligned128 : pl.var->aligned64;
   }
   /* The variant's default band map is dropped for the identity order in two cases
    * (profiles/r01_sweep_narrow_frames.log, r01_sweep_tile_multiple_widths.log):
@@ -771,10 +813,10 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
    *    each other and collide in the memory channels (2048 / 3072 / 4096 / 5120 px:
    *    70-77 % with band 1, 81-83 % in identity order; 1920 / 3840 / 7680 px, whose
    *    last tile is partial, are the other way round by 2-4 points). */
-  if (g.band > 0 && c->band_override == INT32_MIN
-      && (g.tiles_x == 1 || f.width % c->var->tile_w == 0))
+  if (g.band > 0 && pl.band == INT32_MIN
+      && (g.tiles_x == 1 || f.width % pl.var->tile_w == 0))
     g.band = 0;
-  if (fast && c->var->persistent) {
+  if (fast && pl.var->persistent) {
     /* persistent arm: only "one chunk per XCD" or "identity" make sense, and
      * the grid is a fixed number of workgroups per CU */
     if (g.band > 0)
@@ -800,7 +842,7 @@ static int plan_launch (const mibayer_ctx *c, const void *d_src,
    * for the identity order, and pure latency for launches that do not even fill
    * the machine once -- so only grids of more than 4 workgroups per CU slot get it. */
   if (c->start_sleep < 0)
-    p.start_sleep = (g.band > 0 && !c->var->persistent
+    p.start_sleep = (g.band > 0 && !pl.var->persistent
         && (long long) grid > 16LL * c->num_cus) ? kStartSleepChunk : 0;
   if (geom)
     *geom = g;
@@ -829,7 +871,7 @@ static int launch (const mibayer_ctx *c, const void *d_src,
     /* block order: identity for the flat kernel (82.5 % of peak against 77.5 % with one chunk of
      * the batch per XCD), one chunk per XCD for the tile kernel (74.4 vs 73.8 %) --
      * profiles/r02_rgb2bayer_sweep.log */
-    q.band = c->band_override != INT32_MIN ? c->band_override
+    q.band = c->plan[PLAN_BATCH].band != INT32_MIN ? c->plan[PLAN_BATCH].band
         : (c->r2b_flat_k > 0 ? 0 : -1);
     q.start_sleep = c->start_sleep > 0 ? c->start_sleep : 0;
     q.flat_k = c->r2b_flat_k;
@@ -857,11 +899,17 @@ static int launch (const mibayer_ctx *c, const void *d_src,
   KParams p;
   KernelFn kern;
   unsigned grid;
+  Geometry g;
   int rc = plan_launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes,
-      nframes, p, kern, grid, nullptr, tile_row0, ntile_rows);
+      nframes, p, kern, grid, &g, tile_row0, ntile_rows);
   if (rc != MIBAYER_OK)
     return rc;
-  hipLaunchKernelGGL (kern, dim3 (grid), dim3 (c->var->threads), 0, stream, p);
+  /* (lab builds) dynamic LDS per workgroup, only to cap the workgroups per CU in occupancy experiments */
+  static const unsigned dyn_lds = [] {
+    const char *e = LAB_GETENV ("MIBAYER_DYN_LDS");
+    return e ? (unsigned) atoi (e) : 0u;
+  } ();
+  hipLaunchKernelGGL (kern, dim3 (grid), dim3 (g.var->threads), dyn_lds, stream, p);
   HIP_TRY (hipGetLastError ());
   return MIBAYER_OK;
 }
@@ -1035,7 +1083,14 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   c->src_bytes = (size_t) f.src_stride * f.height;
   c->dst_bytes = (size_t) f.dst_stride * f.height;
   c->inverse = (f.flags & MIBAYER_FLAG_RGB2BAYER) != 0;
-  c->var = &variant (resolve_variant (f.variant, f.width));
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount,
+            dev) == hipSuccess && cus > 0)
+      c->num_cus = cus;
+  }
+  Plan &pb = c->plan[PLAN_BATCH];
+  pb.var = &variant (resolve_variant (f.variant, f.width));
   /* Output rows off the 64-byte sector grid (generic geometries; profiles/r03_generic_path.log).  Rows that fit one
    * tile keep their identity-order plan.  Wider ones:
    *  - rows 16-byte aligned (width % 4 == 0, e.g. 4056 px): every lane's 16-byte store is aligned, only the two
@@ -1045,26 +1100,34 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
    *    stores + one chunk of the batch per XCD, where the L2 puts the pieces together (plain_store_twin).
    * mibayer_autotune() times all store policies, and the shifted arm, against each other. */
   c->rows_off_sector = !c->inverse && (f.dst_stride % 64) != 0;
-  if (c->rows_off_sector && f.variant == 0 && f.width > c->var->tile_w) {
+  if (c->rows_off_sector && f.variant == 0 && f.width > pb.var->tile_w) {
     if (f.dst_stride % 16 == 0) {
-      c->var = &variant (hybrid_store_twin (resolve_variant (0, f.width)));
-      c->band_override = 1;
+      pb.var = &variant (hybrid_store_twin (resolve_variant (0, f.width)));
+      pb.band = 1;
     } else {
-      c->var = &variant (plain_store_twin (resolve_variant (0, f.width)));
-      c->band_override = -1;
+      pb.var = &variant (plain_store_twin (resolve_variant (0, f.width)));
+      pb.band = -1;
     }
   }
-  /* a plan measured earlier in this process for this geometry on this device (mibayer_autotune) replaces the default */
+  /* One frame per launch (PLAN_FRAME): the same plan, except that for sector-aligned geometries "auto" takes the
+   * shape whose grid needs the fewest rounds of workgroups (frame_class_variant) */
+  c->plan[PLAN_FRAME] = pb;
+  if (f.variant == 0 && !c->inverse && !c->rows_off_sector)
+    c->plan[PLAN_FRAME].var = &variant (frame_class_variant (f.width, f.height, c->num_cus * 4));
+  /* a plan measured earlier in this process for this geometry and launch class on this device (mibayer_autotune)
+   * replaces the default */
   (void) plan_cache_load (c);
   if (const char *e = LAB_GETENV ("MIBAYER_XCD_BAND")) {
-    c->band_override = atoi (e);
+    for (Plan &pl : c->plan)
+      pl.band = atoi (e);
     c->band_forced = true;
   }
   if (const char *e = LAB_GETENV ("MIBAYER_START_SLEEP"))
     c->start_sleep = atoi (e) >= 0 ? atoi (e) : -1;
   if (const char *e = LAB_GETENV ("MIBAYER_ALIGN_STORES")) {
     const int a = atoi (e);
-    c->align_stores = (a == 64 || a == 128) ? a : 0;
+    for (Plan &pl : c->plan)
+      pl.align = (a == 64 || a == 128) ? a : 0;
     c->align_tunable = false;
   }
   if (const char *e = LAB_GETENV ("MIBAYER_R2B_FLAT"))
@@ -1084,12 +1147,6 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
     c->graph_mode = (strcmp (e, "chain") == 0 || strcmp (e, "1") == 0) ? 1 : 0;
   if (const char *e = LAB_GETENV ("MIBAYER_PERSIST_WGS"))
     c->persist_wgs_per_cu = atoi (e) > 0 ? atoi (e) : 4;
-  {
-    int cus = 0;
-    if (hipDeviceGetAttribute (&cus, hipDeviceAttributeMultiprocessorCount,
-            dev) == hipSuccess && cus > 0)
-      c->num_cus = cus;
-  }
   if (c->inverse)
     make_inverse_plan (c);
   else
@@ -1280,8 +1337,11 @@ extern "C" void mibayer_destroy (mibayer_ctx *c)
       g_cache[c->device].bytes = 0;
     }
   }
-  if (!c->shared_queues) {
-    for (hipStream_t st : { c->s_h2d, c->s_compute, c->s_d2h }) {
+  {
+    std::vector<hipStream_t> own = { c->s_compute2 };
+    if (!c->shared_queues)
+      own.insert (own.end (), { c->s_h2d, c->s_compute, c->s_d2h });
+    for (hipStream_t st : own) {
       if (!st)
         continue;
       if (how == RELEASE_ORPHAN)
@@ -1337,7 +1397,7 @@ extern "C" int mibayer_auto_variant (int width)
 
 extern "C" const char *mibayer_ctx_variant_name (const mibayer_ctx *c)
 {
-  return c ? c->var->name : NULL;
+  return c ? c->plan[PLAN_BATCH].var->name : NULL;
 }
 
 extern "C" int mibayer_get_cfg (const mibayer_ctx *c, mibayer_cfg *out)
@@ -1367,9 +1427,9 @@ extern "C" int mibayer_launch_geometry (const mibayer_ctx *c, int nframes,
   if (nframes == 0)
     grid = 0;
   if (tile_w)
-    *tile_w = c->var->tile_w;
+    *tile_w = g.var->tile_w;
   if (tile_h)
-    *tile_h = c->var->tile_h;
+    *tile_h = g.var->tile_h;
   if (tiles_x)
     *tiles_x = g.tiles_x;
   if (tile_rows)
@@ -1438,6 +1498,13 @@ static int graph_submit (mibayer_ctx *c, Slot &s, const uint8_t *src,
 {
   if (!s.s_graph)
     HIP_TRY (hipStreamCreateWithFlags (&s.s_graph, hipStreamNonBlocking));
+  if (s.exec && s.plan_epoch != c->plan_epoch) {
+    /* the plan has changed since the kernel node was built (the slot's previous frame has completed: it is free) */
+    (void) hipGraphExecDestroy (s.exec);
+    (void) hipGraphDestroy (s.graph);
+    s.exec = nullptr;
+    s.graph = nullptr;
+  }
   if (s.exec && (s.g_src != src || s.g_dst != dst)) {
     hipError_t e1 = hipGraphExecMemcpyNodeSetParams1D (s.exec, s.n_h2d,
         s.d_src, src, c->src_bytes, hipMemcpyHostToDevice);
@@ -1455,8 +1522,9 @@ static int graph_submit (mibayer_ctx *c, Slot &s, const uint8_t *src,
     KParams p;
     KernelFn kern;
     unsigned grid;
+    Geometry g;
     int rc = plan_launch (c, s.d_src, c->src_bytes, s.d_dst, c->dst_bytes, 1,
-        p, kern, grid);
+        p, kern, grid, &g);
     if (rc != MIBAYER_OK)
       return rc;
     void *args[1] = { &p };
@@ -1464,7 +1532,7 @@ static int graph_submit (mibayer_ctx *c, Slot &s, const uint8_t *src,
     memset (&kp, 0, sizeof kp);
     kp.func = (void *) kern;
     kp.gridDim = dim3 (grid);
-    kp.blockDim = dim3 ((unsigned) c->var->threads);
+    kp.blockDim = dim3 ((unsigned) g.var->threads);
     kp.sharedMemBytes = 0;
     kp.kernelParams = args;
     kp.extra = NULL;
@@ -1486,6 +1554,7 @@ static int graph_submit (mibayer_ctx *c, Slot &s, const uint8_t *src,
       s.exec = nullptr;
       return MIBAYER_ERR_HIP;
     }
+    s.plan_epoch = c->plan_epoch;
   }
   s.g_src = src;
   s.g_dst = dst;
@@ -1511,11 +1580,11 @@ static int choose_host_bands (const mibayer_ctx *c)
   if (want > kMaxHostBands)
     want = kMaxHostBands;
   const size_t big_side = c->inverse ? c->src_bytes : c->dst_bytes;     /* the 4 B/px frame */
-  if (want < 2 || c->var->persistent
+  if (want < 2 || plan_for (c, 1).var->persistent
       || big_side < ((size_t) 16 << 20))        /* below ~4K the extra enqueues cost more
                                                    than the overlap gains (1080p: -10 %) */
     return 1;
-  const int th = c->inverse ? kInverseBandUnit : c->var->tile_h;
+  const int th = c->inverse ? kInverseBandUnit : plan_for (c, 1).var->tile_h;
   const int tiles_y = (c->cfg.height + th - 1) / th;
   while (want > 1) {
     const int per = (tiles_y + want - 1) / want;        /* tile rows per band */
@@ -1532,7 +1601,7 @@ static int enqueue_frame_banded (mibayer_ctx *c, Slot &s, const uint8_t *src,
     uint8_t *dst, size_t row_bytes)
 {
   const mibayer_cfg &f = c->cfg;
-  const int th = c->inverse ? kInverseBandUnit : c->var->tile_h;
+  const int th = c->inverse ? kInverseBandUnit : plan_for (c, 1).var->tile_h;
   const int halo = c->inverse ? 0 : 1;  /* rgb2bayer has no neighbourhood */
   const int tiles_y = (f.height + th - 1) / th;
   const int nb = c->host_bands;
@@ -1587,12 +1656,20 @@ static int enqueue_frame_banded (mibayer_ctx *c, Slot &s, const uint8_t *src,
  * and the wait / record stay stream calls. */
 static int compute_graph_launch (mibayer_ctx *c, Slot &s)
 {
+  if (s.cexec && s.plan_epoch != c->plan_epoch) {       /* built under an older plan; the slot is free */
+    (void) hipGraphExecDestroy (s.cexec);
+    (void) hipGraphDestroy (s.cgraph);
+    s.cexec = nullptr;
+    s.cgraph = nullptr;
+  }
   if (!s.cexec) {
+    s.plan_epoch = c->plan_epoch;
     KParams p;
     KernelFn kern;
     unsigned grid;
+    Geometry g;
     const int rc = plan_launch (c, s.d_src, c->src_bytes, s.d_dst, c->dst_bytes,
-        1, p, kern, grid);
+        1, p, kern, grid, &g);
     if (rc != MIBAYER_OK)
       return rc;
     void *args[1] = { &p };
@@ -1600,7 +1677,7 @@ static int compute_graph_launch (mibayer_ctx *c, Slot &s)
     memset (&kp, 0, sizeof kp);
     kp.func = (void *) kern;
     kp.gridDim = dim3 (grid);
-    kp.blockDim = dim3 ((unsigned) c->var->threads);
+    kp.blockDim = dim3 ((unsigned) g.var->threads);
     kp.kernelParams = args;
     for (int with_events = 1; with_events >= 0 && !s.cexec; with_events--) {
       hipGraphNode_t n_wait = nullptr, n_kernel = nullptr, n_rec = nullptr;
@@ -1986,6 +2063,8 @@ extern "C" int mibayer_process_device (mibayer_ctx *c, const void *d_src,
   Range r ("mibayer:process_device");
   if ((hipStream_t) hip_stream == c->s_compute)
     c->dirty_compute = true;
+  else if (hip_stream && (hipStream_t) hip_stream == c->s_compute2)
+    c->dirty_compute2 = true;
   return launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes,
       (hipStream_t) hip_stream);
 }
@@ -2012,6 +2091,8 @@ extern "C" int mibayer_process_device_list (mibayer_ctx *c,
   Range r ("mibayer:process_device_list");
   if ((hipStream_t) hip_stream == c->s_compute)
     c->dirty_compute = true;
+  else if (hip_stream && (hipStream_t) hip_stream == c->s_compute2)
+    c->dirty_compute2 = true;
   if (c->inverse) {
     /* the sibling direction (reference loop gst/bayer/gstrgb2bayer.c:254-268): up to kMaxList separately allocated
      * frames per launch of the flat kernel; the tile kernel (MIBAYER_R2B_FLAT=0, tuning) has no table and goes
@@ -2039,7 +2120,7 @@ extern "C" int mibayer_process_device_list (mibayer_ctx *c,
       q.dst_stride = f.dst_stride;
       q.out_dwords = ((f.width + 3) & ~3) / 4;
       q.total_rows = f.height;
-      q.band = c->band_override != INT32_MIN ? c->band_override : 0;
+      q.band = c->plan[PLAN_BATCH].band != INT32_MIN ? c->plan[PLAN_BATCH].band : 0;
       q.start_sleep = c->start_sleep > 0 ? c->start_sleep : 0;
       q.flat_k = c->r2b_flat_k;
       q.flat_px = c->r2b_flat_px;
@@ -2073,8 +2154,9 @@ extern "C" int mibayer_process_device_list (mibayer_ctx *c,
     KernelFn kern;
     unsigned grid;
     /* planned as a batch of n frames; the 16-byte path needs every pointer aligned */
+    Geometry g;
     const int rc = plan_launch (c, d_srcs[f0], c->src_bytes, d_dsts[f0],
-        c->dst_bytes, n, p, kern, grid, nullptr, 0, -1, all16 ? 1 : (dst8 ? 2 : 0));
+        c->dst_bytes, n, p, kern, grid, &g, 0, -1, all16 ? 1 : (dst8 ? 2 : 0));
     if (rc != MIBAYER_OK)
       return rc;
     p.src = nullptr;
@@ -2084,7 +2166,7 @@ extern "C" int mibayer_process_device_list (mibayer_ctx *c,
       p.src_list[f] = (const uint8_t *) d_srcs[f0 + f];
       p.dst_list[f] = (uint8_t *) d_dsts[f0 + f];
     }
-    hipLaunchKernelGGL (kern, dim3 (grid), dim3 (c->var->threads), 0,
+    hipLaunchKernelGGL (kern, dim3 (grid), dim3 (g.var->threads), 0,
         (hipStream_t) hip_stream, p);
     HIP_TRY (hipGetLastError ());
   }
@@ -2094,6 +2176,20 @@ extern "C" int mibayer_process_device_list (mibayer_ctx *c,
 extern "C" void *mibayer_ctx_stream (mibayer_ctx *c)
 {
   return c ? (void *) c->s_compute : NULL;
+}
+
+extern "C" void *mibayer_ctx_stream2 (mibayer_ctx *c)
+{
+  if (!c)
+    return NULL;
+  if (!c->s_compute2) {
+    DeviceGuard guard (c->device);
+    if (!guard.ok || hip_failed (hipStreamCreateWithFlags (&c->s_compute2, hipStreamNonBlocking), "hipStreamCreate")) {
+      c->s_compute2 = nullptr;
+      return NULL;
+    }
+  }
+  return (void *) c->s_compute2;
 }
 
 /* Waits for what THIS context has in flight: the download events of its own pending frames and, if it queued
@@ -2109,16 +2205,20 @@ extern "C" int mibayer_sync (mibayer_ctx *c)
   int rc = wait_own_frames (c);
   if (rc != MIBAYER_OK)
     return rc;
-  if (c->dirty_compute) {
+  struct { hipStream_t q; bool *dirty; } own[2] = {
+    { c->s_compute, &c->dirty_compute }, { c->s_compute2, &c->dirty_compute2 } };
+  for (auto &o : own) {
+    if (!*o.dirty || !o.q)
+      continue;
     /* not `c->wedged`: with nothing pending wait_own_frames() polled nothing, so this is where a context whose
      * device-resident launch ran into a deadline finds out that the device has caught up */
     if (wedged_for_good (c))
       return MIBAYER_ERR_TIMEOUT;
-    HIP_TRY (hipEventRecord (c->ev_fence, c->s_compute));
+    HIP_TRY (hipEventRecord (c->ev_fence, o.q));
     rc = wait_event (c, c->ev_fence, true);
     if (rc != MIBAYER_OK)
       return rc;
-    c->dirty_compute = false;
+    *o.dirty = false;
   }
   return MIBAYER_OK;
 }
@@ -2164,13 +2264,15 @@ extern "C" int mibayer_time_device (mibayer_ctx *c, const void *d_src,
 
 /* ---- process-wide plan cache ------------------------------------------------------------ */
 
-/* What mibayer_autotune measured, kept per (device, geometry): the next context of the same stream geometry on that
- * device -- the second element instance, the context after a renegotiation, the other Bayer orders of one camera --
- * starts from the measured plan instead of the static default, without measuring again.  Reference analogue
- * (compile once per process, reuse): the once-guarded ORC program set-up, gst/bayer/gstbayerorc-dist.c:321-397. */
+/* What mibayer_autotune measured, kept per (device, geometry, launch class): the next context of the same stream
+ * geometry on that device -- the second element instance, the context after a renegotiation, the other Bayer orders of
+ * one camera -- starts from the measured plan instead of the static default, without measuring again.  The launch
+ * class is part of the key: what a 64-frame batch measured is not what a frame-by-frame context should
+ * start from, and the other way round.  Reference analogue (compile once per process, reuse): the once-guarded ORC
+ * program set-up, gst/bayer/gstbayerorc-dist.c:321-397. */
 namespace {
 struct PlanEntry {
-  int device, width, height, src_stride, dst_stride;
+  int device, width, height, src_stride, dst_stride, klass;
   int variant, band, align;
 };
 std::mutex g_plan_mu;
@@ -2185,20 +2287,20 @@ bool plan_cache_enabled ()
   return on;
 }
 
-bool plan_key_is (const PlanEntry &e, const mibayer_ctx *c)
+bool plan_key_is (const PlanEntry &e, const mibayer_ctx *c, int klass)
 {
   return e.device == c->device && e.width == c->cfg.width && e.height == c->cfg.height
-      && e.src_stride == c->cfg.src_stride && e.dst_stride == c->cfg.dst_stride;
+      && e.src_stride == c->cfg.src_stride && e.dst_stride == c->cfg.dst_stride && e.klass == klass;
 }
 
-void plan_cache_store (const mibayer_ctx *c)
+void plan_cache_store (const mibayer_ctx *c, int klass)
 {
   if (!plan_cache_enabled () || c->inverse || c->cfg.variant != 0)
     return;
   std::lock_guard<std::mutex> lk (g_plan_mu);
   PlanEntry *slot = nullptr;
   for (PlanEntry &e : g_plans)
-    if (plan_key_is (e, c))
+    if (plan_key_is (e, c, klass))
       slot = &e;
   if (!slot) {
     if (g_plans.size () >= 256)
@@ -2206,8 +2308,9 @@ void plan_cache_store (const mibayer_ctx *c)
     g_plans.push_back (PlanEntry ());
     slot = &g_plans.back ();
   }
-  *slot = PlanEntry { c->device, c->cfg.width, c->cfg.height, c->cfg.src_stride, c->cfg.dst_stride,
-    (int) (c->var - &variant (0)), c->band_override, c->align_stores };
+  const Plan &pl = c->plan[klass];
+  *slot = PlanEntry { c->device, c->cfg.width, c->cfg.height, c->cfg.src_stride, c->cfg.dst_stride, klass,
+    (int) (pl.var - &variant (0)), pl.band, pl.align };
 }
 
 }  /* namespace */
@@ -2217,15 +2320,15 @@ static bool plan_cache_load (mibayer_ctx *c)
   if (!plan_cache_enabled () || c->inverse || c->cfg.variant != 0)
     return false;
   std::lock_guard<std::mutex> lk (g_plan_mu);
-  for (const PlanEntry &e : g_plans)
-    if (plan_key_is (e, c)) {
-      c->var = &variant (e.variant);
-      c->band_override = e.band;
-      c->align_stores = e.align;
-      c->plan_source = MIBAYER_PLAN_CACHED;
-      return true;
-    }
-  return false;
+  bool hit = false;
+  for (int klass = 0; klass < PLAN_CLASSES; klass++)
+    for (const PlanEntry &e : g_plans)
+      if (plan_key_is (e, c, klass)) {
+        c->plan[klass] = Plan { &variant (e.variant), e.band, e.align, MIBAYER_PLAN_CACHED };
+        c->plan_epoch++;
+        hit = true;
+      }
+  return hit;
 }
 
 extern "C" void mibayer_plan_cache_clear (void)
@@ -2245,7 +2348,7 @@ extern "C" int mibayer_plan_from_cache (mibayer_ctx *c)
 
 extern "C" int mibayer_plan_source (const mibayer_ctx *c)
 {
-  return c ? c->plan_source : MIBAYER_ERR_ARG;
+  return c ? c->plan[PLAN_BATCH].source : MIBAYER_ERR_ARG;
 }
 
 /* Measured plan selection.  The kernel is idempotent and deterministic, so the
@@ -2262,11 +2365,14 @@ struct Candidate {
 constexpr int kMaxCands = 48;
 }
 
-/* `launch_once` queues one conversion of the caller's buffers under the context's CURRENT plan on the compute queue;
- * `generic_off_grid`: those launches take the generic kernel and the output rows sit off the sector grid */
+/* `launch_once` queues one conversion of the caller's buffers under the context's CURRENT plan of launch class `klass`
+ * (the class those launches fall into) on the compute queue; `generic_off_grid`: those launches take the generic
+ * kernel and the output rows sit off the sector grid */
 template <typename F>
-static int autotune_core (mibayer_ctx *c, F launch_once, bool generic_off_grid, char *report, size_t report_len)
+static int autotune_core (mibayer_ctx *c, int klass, F launch_once, bool generic_off_grid, char *report,
+    size_t report_len)
 {
+  Plan &pl = c->plan[klass];
   /* Candidate plans.  Sector-aligned geometries (the 16-byte kernel): {configured shape, the other production
    * shapes under "auto"} x {band 1, one chunk per XCD, identity}; the band orders carry the automatic start delay.
    * Generic geometries whose rows sit off the sector grid add the store policy as a dimension -- streaming,
@@ -2287,18 +2393,18 @@ static int autotune_core (mibayer_ctx *c, F launch_once, bool generic_off_grid, 
     if (ncand < kMaxCands)
       cand[ncand++] = Candidate { v, band, align, 0.f, true };
   };
-  const Variant *keep_var = c->var;
-  const int keep_band = c->band_override;
-  const int keep_align = c->align_stores;
+  const Plan keep = pl;
+  const int keep_band = keep.band;
+  const int keep_align = keep.align;
   /* a forced store alignment (MIBAYER_ALIGN_STORES) is part of every candidate */
   const int fixed_align = c->align_tunable ? 0 : keep_align;
   /* the configured plan first: it also wins ties */
-  add (c->var, band_forced ? keep_band : (keep_band == INT32_MIN ? kBands[0] : keep_band), fixed_align);
+  add (keep.var, band_forced ? keep_band : (keep_band == INT32_MIN ? kBands[0] : keep_band), fixed_align);
   if (c->cfg.variant != 0) {
     for (int bi = 0; bi < nbands; bi++)
-      add (c->var, band_forced ? keep_band : kBands[bi], fixed_align);
+      add (keep.var, band_forced ? keep_band : kBands[bi], fixed_align);
   } else {
-    const int own_id = (int) (c->var - &variant (0));
+    const int own_id = (int) (keep.var - &variant (0));
     for (int v = 3; v >= 1; v--) {
       int ids[3], nids = 0;
       if (generic_off_grid) {
@@ -2337,7 +2443,7 @@ static int autotune_core (mibayer_ctx *c, F launch_once, bool generic_off_grid, 
     return MIBAYER_ERR_NOMEM;
   int rc = MIBAYER_OK;
   float ms = 0.f;
-  c->align_stores = fixed_align;
+  pl.align = fixed_align;
   {
     const double t0 = now_ms ();
     do {
@@ -2348,9 +2454,9 @@ static int autotune_core (mibayer_ctx *c, F launch_once, bool generic_off_grid, 
     for (int i = 0; i < ncand && rc == MIBAYER_OK; i++) {
       if (!cand[i].alive)
         continue;
-      c->var = cand[i].var;
-      c->band_override = cand[i].band;
-      c->align_stores = cand[i].align;
+      pl.var = cand[i].var;
+      pl.band = cand[i].band;
+      pl.align = cand[i].align;
       rc = time_launches (c, launch_once, 1, kReps, &ms);
       rm[i][round] = ms;
     }
@@ -2364,9 +2470,7 @@ static int autotune_core (mibayer_ctx *c, F launch_once, bool generic_off_grid, 
     }
   }
   if (rc != MIBAYER_OK) {
-    c->var = keep_var;
-    c->band_override = keep_band;
-    c->align_stores = keep_align;
+    pl = keep;
     delete[] rm;
     return rc;
   }
@@ -2396,11 +2500,10 @@ static int autotune_core (mibayer_ctx *c, F launch_once, bool generic_off_grid, 
     }
   }
   delete[] rm;
-  c->var = cand[best].var;
-  c->band_override = cand[best].band;
-  c->align_stores = cand[best].align;
-  c->plan_source = MIBAYER_PLAN_MEASURED;
-  plan_cache_store (c);
+  pl = Plan { cand[best].var, cand[best].band, cand[best].align, MIBAYER_PLAN_MEASURED };
+  c->plan_epoch++;
+  c->host_bands = choose_host_bands (c);
+  plan_cache_store (c, klass);
   return MIBAYER_OK;
 }
 
@@ -2423,9 +2526,9 @@ extern "C" int mibayer_autotune (mibayer_ctx *c, const void *d_src,
     const int prc = plan_launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes, p, kern, grid);
     if (prc != MIBAYER_OK)
       return prc;
-    generic_off_grid = kern != c->var->fast && c->rows_off_sector;
+    generic_off_grid = kern != plan_for (c, nframes).var->fast && c->rows_off_sector;
   }
-  return autotune_core (c, [&] {
+  return autotune_core (c, launch_class (c, nframes), [&] {
     return mibayer_process_device (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes, c->s_compute);
   }, generic_off_grid, report, report_len);
 }
@@ -2450,7 +2553,7 @@ extern "C" int mibayer_autotune_list (mibayer_ctx *c, const void *const *d_srcs,
   }
   const mibayer_cfg &f = c->cfg;
   const bool fast = all16 && (f.width % 16 == 0) && (f.src_stride % 16 == 0) && (f.dst_stride % 16 == 0);
-  return autotune_core (c, [&] {
+  return autotune_core (c, launch_class (c, nframes < kMaxList ? nframes : kMaxList), [&] {
     return mibayer_process_device_list (c, d_srcs, d_dsts, nframes, c->s_compute);
   }, !fast && c->rows_off_sector, report, report_len);
 }
@@ -2459,16 +2562,35 @@ extern "C" int mibayer_get_plan (const mibayer_ctx *c, int *variant_id, int *ban
 {
   if (!c)
     return MIBAYER_ERR_ARG;
+  const Plan &pl = c->plan[PLAN_BATCH];
   if (variant_id)
-    *variant_id = (int) (c->var - &variant (0));
+    *variant_id = (int) (pl.var - &variant (0));
   if (band)
-    *band = c->band_override;
+    *band = pl.band;
   if (align_stores)
-    *align_stores = c->align_stores;
+    *align_stores = pl.align;
   return MIBAYER_OK;
 }
 
-extern "C" int mibayer_set_plan (mibayer_ctx *c, int variant_id, int band, int align_stores)
+/* the plan a launch over `nframes` frames runs under (its launch class), and where that plan came from */
+extern "C" int mibayer_get_plan_for (const mibayer_ctx *c, int nframes, int *variant_id, int *band,
+    int *align_stores, int *source)
+{
+  if (!c || nframes < 1)
+    return MIBAYER_ERR_ARG;
+  const Plan &pl = plan_for (c, nframes);
+  if (variant_id)
+    *variant_id = (int) (pl.var - &variant (0));
+  if (band)
+    *band = pl.band;
+  if (align_stores)
+    *align_stores = pl.align;
+  if (source)
+    *source = pl.source;
+  return MIBAYER_OK;
+}
+
+static int plan_args_ok (const mibayer_ctx *c, int variant_id, int align_stores)
 {
   if (!c || c->inverse)
     return MIBAYER_ERR_ARG;
@@ -2478,10 +2600,30 @@ extern "C" int mibayer_set_plan (mibayer_ctx *c, int variant_id, int band, int a
     return MIBAYER_ERR_ARG;
   if (align_stores && !(align_stores == 128 ? variant (variant_id).aligned128 : variant (variant_id).aligned64))
     return MIBAYER_ERR_ARG;
-  c->var = &variant (variant_id);
-  c->band_override = band;
-  c->align_stores = align_stores;
-  c->plan_source = MIBAYER_PLAN_SET;
+  return MIBAYER_OK;
+}
+
+/* pins the plan of ONE launch class: the one launches over `nframes` frames fall into */
+extern "C" int mibayer_set_plan_for (mibayer_ctx *c, int nframes, int variant_id, int band, int align_stores)
+{
+  const int rc = plan_args_ok (c, variant_id, align_stores);
+  if (rc != MIBAYER_OK || nframes < 1)
+    return rc != MIBAYER_OK ? rc : MIBAYER_ERR_ARG;
+  plan_for (c, nframes) = Plan { &variant (variant_id), band, align_stores, MIBAYER_PLAN_SET };
+  c->plan_epoch++;
+  c->host_bands = choose_host_bands (c);
+  return MIBAYER_OK;
+}
+
+extern "C" int mibayer_set_plan (mibayer_ctx *c, int variant_id, int band, int align_stores)
+{
+  const int rc = plan_args_ok (c, variant_id, align_stores);
+  if (rc != MIBAYER_OK)
+    return rc;
+  for (Plan &pl : c->plan)      /* an explicit pin holds for every launch class */
+    pl = Plan { &variant (variant_id), band, align_stores, MIBAYER_PLAN_SET };
+  c->plan_epoch++;
+  c->host_bands = choose_host_bands (c);
   return MIBAYER_OK;
 }
 
@@ -2491,10 +2633,12 @@ extern "C" int mibayer_copy_plan (mibayer_ctx *dst, const mibayer_ctx *src)
     return MIBAYER_ERR_ARG;
   if (dst->cfg.width != src->cfg.width || dst->cfg.height != src->cfg.height)
     return MIBAYER_ERR_GEOMETRY;
-  dst->var = src->var;
-  dst->band_override = src->band_override;
-  dst->align_stores = src->align_stores;
-  dst->plan_source = MIBAYER_PLAN_SET;
+  for (int k = 0; k < PLAN_CLASSES; k++) {
+    dst->plan[k] = src->plan[k];
+    dst->plan[k].source = MIBAYER_PLAN_SET;
+  }
+  dst->plan_epoch++;
+  dst->host_bands = choose_host_bands (dst);
   return MIBAYER_OK;
 }
 

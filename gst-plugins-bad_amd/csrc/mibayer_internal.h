@@ -178,6 +178,8 @@ struct Variant {
 int variant_count ();
 const Variant &variant (int id);
 int resolve_variant (int id, int width);        /* 0 ("auto") -> a concrete id */
+/* "auto" for a launch of one frame: the production shape whose grid needs the fewest rounds of `slots` workgroups */
+int frame_class_variant (int width, int height, int slots);
 /* the plain-store (write-back) arm of a production shape (ids 1-3), for output rows that start off a
  * 64-byte sector; any other id is returned unchanged */
 int plain_store_twin (int id);

@@ -1078,6 +1078,31 @@ int resolve_variant (int id, int width)
   return best + 1;
 }
 
+/* Variant 0 for a launch of ONE frame (PLAN_FRAME, mibayer_abi.hip): such a launch is a handful of rounds of
+ * workgroups at most -- a 4K frame in 1024x8 tiles is 1080 workgroups on the 1024 slots of 256 CUs x 4, i.e. a second
+ * round that is 5 % full -- so the shape whose grid needs the fewest rounds wins (4K: 256x32 tiles = 1020 workgroups,
+ * one round: 54.8 vs 47.9 % of peak launched frame by frame; 3264x2448: 53.9 vs 49.9 %; 8K: 512x16 = 3.96 rounds
+ * against 4.25: 68.0 vs 64.2 %), the widest tile among equals (2592x1944, all one round: 47.1 / 45.7 / 44.6 %;
+ * 4056x3040, all two: 53.6 / 51.8 / 47.7 %) -- profiles/r05_single_frame.md.  Rows that fit one tile keep the rule of
+ * resolve_variant().  `slots`: workgroups resident at once (CUs x 4 for the 512-thread production shapes). */
+int frame_class_variant (int width, int height, int slots)
+{
+  if (width <= 1024 || slots < 1)
+    return resolve_variant (0, width);
+  static const int tile_w[3] = { 1024, 512, 256 }, tile_h[3] = { 8, 16, 32 };      /* variants 1, 2, 3 */
+  int best = 0;
+  long long best_rounds = 0;
+  for (int i = 0; i < 3; i++) {
+    const long long tiles = (long long) ((width + tile_w[i] - 1) / tile_w[i]) * ((height + tile_h[i] - 1) / tile_h[i]);
+    const long long rounds = (tiles + slots - 1) / slots;
+    if (i == 0 || rounds < best_rounds) {
+      best = i;
+      best_rounds = rounds;
+    }
+  }
+  return best + 1;
+}
+
 /* ------------------------------------------------------------------------- */
 /* rgb2bayer: the sibling element's per-pixel gather                           */
 /* ------------------------------------------------------------------------- */

@@ -41,7 +41,8 @@ enum
   PROP_ASYNC,
   PROP_BATCH,
   PROP_AUTOTUNE,
-  PROP_PLAN
+  PROP_PLAN,
+  PROP_OVERLAP
 };
 
 /* bytes of one frame for either media type; same rules as bayer2rgb's
@@ -783,6 +784,8 @@ typedef struct
   gint batch;
   gint autotune;                /* property "autotune": measure the launch plan on the first frames (g_atomic_int_*) */
   gboolean tuned;               /* the context's plan has been settled: measured, or taken from the process cache */
+  gint overlap;                 /* property "overlap": consecutive frames alternate the context's two compute queues */
+  guint frame_no;               /* frames launched one at a time so far: picks the queue */
   gchar plan[160];              /* property "plan" (read-only): the context's launch plan and where it came from */
   gboolean prerolled;           /* a frame has left since start / flush: batching may begin */
   GQueue waiting;               /* Hb2rPair* */
@@ -857,6 +860,9 @@ hb2r_set_property (GObject * object, guint prop_id, const GValue * value,
   else if (prop_id == PROP_AUTOTUNE)
     g_atomic_int_set (&((GstMiHipBayer2RGB *) object)->autotune,
         g_value_get_boolean (value) ? 1 : 0);
+  else if (prop_id == PROP_OVERLAP)
+    g_atomic_int_set (&((GstMiHipBayer2RGB *) object)->overlap,
+        g_value_get_boolean (value) ? 1 : 0);
   else
     G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
 }
@@ -874,6 +880,9 @@ hb2r_get_property (GObject * object, guint prop_id, GValue * value,
   else if (prop_id == PROP_AUTOTUNE)
     g_value_set_boolean (value,
         g_atomic_int_get (&((GstMiHipBayer2RGB *) object)->autotune) != 0);
+  else if (prop_id == PROP_OVERLAP)
+    g_value_set_boolean (value,
+        g_atomic_int_get (&((GstMiHipBayer2RGB *) object)->overlap) != 0);
   else if (prop_id == PROP_PLAN) {
     GST_OBJECT_LOCK (object);
     g_value_set_string (value, ((GstMiHipBayer2RGB *) object)->plan);
@@ -1020,17 +1029,26 @@ hb2r_device_of (GstMiHipBayer2RGB * self, GstBuffer * inbuf, gint * device)
 }
 
 /* the context's plan, for the read-only "plan" property and the debug log */
+/* frames per launch in the steady state: the launch class the plan is looked up, measured and reported for */
+static int
+hb2r_launch_frames (GstMiHipBayer2RGB * self)
+{
+  return MIN (MAX (g_atomic_int_get (&self->batch), 1), HB2R_MAX_BATCH);
+}
+
 static void
 hb2r_note_plan (GstMiHipBayer2RGB * self)
 {
   static const char *const source[] = { "default", "measured", "cached", "set" };
-  int variant = 0, band = 0, align = 0;
-  const int src = mibayer_plan_source (self->ctx);
+  int variant = 0, band = 0, align = 0, src = -1;
+  const char *name;
 
-  (void) mibayer_get_plan (self->ctx, &variant, &band, &align);
+  /* the plan of the launches this element issues: `batch` frames each (ABI v5: one plan per launch class) */
+  (void) mibayer_get_plan_for (self->ctx, hb2r_launch_frames (self), &variant, &band, &align, &src);
+  name = mibayer_variant_name (variant);
   GST_OBJECT_LOCK (self);
   g_snprintf (self->plan, sizeof self->plan, "%s band=%d align=%d source=%s",
-      mibayer_ctx_variant_name (self->ctx), band == G_MININT32 ? -999 : band, align,
+      name ? name : "?", band == G_MININT32 ? -999 : band, align,
       (src >= 0 && src < 4) ? source[src] : "?");
   GST_OBJECT_UNLOCK (self);
   GST_INFO_OBJECT (self, "launch plan: %s", self->plan);
@@ -1086,8 +1104,13 @@ hb2r_autotune_once (GstMiHipBayer2RGB * self, const void *const *srcs,
   if (self->tuned || HB2R_INVERSE (self))
     return;
   self->tuned = TRUE;
-  if (mibayer_plan_source (self->ctx) != MIBAYER_PLAN_DEFAULT)
-    return;                     /* the process cache had a plan when the context was created */
+  {
+    int src = MIBAYER_PLAN_DEFAULT;
+
+    (void) mibayer_get_plan_for (self->ctx, (int) n, NULL, NULL, NULL, &src);
+    if (src != MIBAYER_PLAN_DEFAULT)
+      return;                   /* the process cache had a plan for this launch class when the context was created */
+  }
   if (mibayer_plan_from_cache (self->ctx) == 1) {
     hb2r_note_plan (self);      /* ... or has one now: another element measured since */
     return;
@@ -1208,6 +1231,16 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
    * after it.  The next user either orders its own stream after that event or
    * -- any plain map, hipdownload, a CPU map -- waits for it on the host. */
   stream = mibayer_ctx_stream (self->ctx);
+  /* Frames are independent and each is handed over by its own events, so consecutive ones alternate the context's
+   * two compute queues: a one-frame launch is a single round of workgroups, and on the other queue the ramp-up of
+   * frame n+1 overlaps the drain of frame n (4K: 54.8 -> 63.4 % of HBM peak, profiles/r05_single_frame.md).  The
+   * frame that settles the plan (it may run mibayer_autotune_list on the first queue) stays on the first queue. */
+  if (self->tuned && g_atomic_int_get (&self->overlap) && (self->frame_no++ & 1)) {
+    gpointer second = mibayer_ctx_stream2 (self->ctx);
+
+    if (second != NULL)
+      stream = second;
+  }
   if (!gst_mi_hip_memory_order_after ((GstMiHipMemory *) in_mem, stream)
       || !gst_mi_hip_memory_order_after ((GstMiHipMemory *) out_mem, stream)) {
     /* could not order on the device: fall back to waiting on the host */
@@ -1453,6 +1486,14 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
           "the static default plan, or the cached one if some element measured "
           "before.  No effect on hiprgb2bayer",
           FALSE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (object_class, PROP_OVERLAP,
+      g_param_spec_boolean ("overlap", "Overlap consecutive frames",
+          "Frame-by-frame mode (batch=1): deal consecutive frames alternately over "
+          "two compute queues, so that the start of frame n+1 overlaps the tail of "
+          "frame n (a one-frame launch never reaches a steady state by itself).  "
+          "Frames are handed over by per-buffer events either way; off = every "
+          "launch behind the previous one",
+          TRUE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_PLAN,
       g_param_spec_string ("plan", "Launch plan",
           "The launch plan of the current stream and where it came from "
@@ -1485,6 +1526,8 @@ gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
   self->out_pool_device = 0;
   self->batch = 1;
   self->autotune = 0;
+  self->overlap = 1;
+  self->frame_no = 0;
   self->tuned = FALSE;
   self->plan[0] = '\0';
   self->prerolled = FALSE;

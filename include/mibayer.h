@@ -49,7 +49,17 @@ extern "C" {
  * mibayer_plan_source), the process-wide plan cache behind mibayer_autotune and
  * mibayer_create (mibayer_plan_cache_clear), mibayer_autotune_list, the host-wait
  * policy (mibayer_set_wait_spin), MIBAYER_FLAG_HIPGRAPH_CHAIN, mibayer_is_lab_build. */
-#define MIBAYER_ABI_VERSION 4
+/* NOTE on 4: the numeric kernel-variant ids were renumbered in that version (4 used to be lds_1x8_r4_dpp and became
+ * lds_4x2_r4_dpp; the former 20-24 became 4-9; ids >= 10 exist in the lab build only) -- the one non-additive change
+ * of the ABI's history.  Every id is bit-exact, so a caller that kept a number got a different speed, not different
+ * bytes, or MIBAYER_ERR_ARG for an id the product build no longer has.  Look variants up by NAME
+ * (mibayer_variant_name) rather than keeping numbers across versions. */
+/* 5: additive over 4 -- one launch plan per LAUNCH CLASS (launches of a few rounds of workgroups: one frame per
+ * launch, vs. batch launches): mibayer_get_plan_for / mibayer_set_plan_for, the plan cache keyed by class;
+ * mibayer_ctx_stream2 (a second compute queue of the context for independent frames), covered by mibayer_sync.
+ * mibayer_get_plan / mibayer_plan_source / mibayer_ctx_variant_name keep describing the batch-class plan,
+ * mibayer_set_plan / mibayer_copy_plan pin every class. */
+#define MIBAYER_ABI_VERSION 5
 
 /* Bayer order; numbering identical to the reference's anonymous enum
  * GST_BAYER_2_RGB_FORMAT_*, gstbayer2rgb.c:95-101. */
@@ -308,9 +318,18 @@ int mibayer_process_device_list (mibayer_ctx *ctx, const void *const *d_srcs,
     void *const *d_dsts, int nframes, void *hip_stream);
 /* the context's compute stream (a hipStream_t), created non-blocking */
 void *mibayer_ctx_stream (mibayer_ctx *ctx);
+/* A second compute stream, the context's own (created by the first call; NULL if that fails).  A launch over ONE frame
+ * is a single round of workgroups -- ramp-up, one burst of loads, one burst of stores, drain: 4K 9.4 us against 6.5 us
+ * per frame inside a batch -- so a caller that converts frame after frame (one GstBuffer at a time) and whose frames
+ * do not depend on each other deals them alternately over mibayer_ctx_stream() and this stream: the ramp-up of frame
+ * n+1 overlaps the drain of frame n (4K: 54.8 -> 63.4 % of HBM peak; what hipbayer2rgb does).  The two streams are
+ * not ordered against each other: order consumers with events (mibayer_dev_event_record / _stream_wait_event) or
+ * mibayer_sync(), which covers both. */
+void *mibayer_ctx_stream2 (mibayer_ctx *ctx);
 /* Waits (with the context's deadline) for what THIS context has in flight: its
  * pending host-path frames and the device-resident work queued through
- * mibayer_process_device[_list] / mibayer_fill_synthetic on mibayer_ctx_stream().
+ * mibayer_process_device[_list] / mibayer_fill_synthetic on mibayer_ctx_stream() and
+ * mibayer_process_device[_list] on mibayer_ctx_stream2().
  * Work a caller put on that stream by other means (its own kernels, copies) is
  * NOT covered -- the queue may be shared with the other contexts of the device --
  * and neither is work on a caller-supplied stream: synchronise those yourself. */
@@ -358,9 +377,23 @@ int mibayer_copy_plan (mibayer_ctx *dst, const mibayer_ctx *src);
 int mibayer_get_plan (const mibayer_ctx *ctx, int *variant, int *band,
     int *align_stores);
 int mibayer_set_plan (mibayer_ctx *ctx, int variant, int band, int align_stores);
+/* Launch classes (v5).  A context keeps one plan per class of launch:
+ *   batch class -- launches that keep every workgroup slot of the device busy for many rounds (the 64-frame batch);
+ *   frame class -- launches of at most 4 rounds of workgroups (on 256 CUs: up to 33.5 Mpixel per launch = one 8K
+ *                  frame, four 4K frames): what an element or the host path issues, one frame per launch.  Its default
+ *                  shape is the production shape whose grid needs the FEWEST ROUNDS of the device's workgroup slots
+ *                  (a 4K frame in 1024x8 tiles is 1080 workgroups on 1024 slots -- a second round that is 5 % full --
+ *                  in 256x32 tiles 1020: 54.8 vs 47.9 % of peak frame by frame), the widest among equals.
+ * Which class a launch over `nframes` frames falls into follows from the geometry alone.  mibayer_autotune[_list]
+ * measures -- and the plan cache records -- the class of the launches it was given; mibayer_get_plan,
+ * mibayer_plan_source and mibayer_ctx_variant_name describe the batch class; mibayer_set_plan / mibayer_copy_plan pin
+ * every class.  The two below address the class of an `nframes`-frame launch; `source` receives MIBAYER_PLAN_*. */
+int mibayer_get_plan_for (const mibayer_ctx *ctx, int nframes, int *variant, int *band, int *align_stores,
+    int *source);
+int mibayer_set_plan_for (mibayer_ctx *ctx, int nframes, int variant, int band, int align_stores);
 
 /* Process-wide plan cache.  mibayer_autotune / mibayer_autotune_list record what
- * they measured under (device, width, height, src_stride, dst_stride);
+ * they measured under (device, width, height, src_stride, dst_stride, launch class);
  * mibayer_create of a stream with that geometry on that device (cfg.variant == 0)
  * starts from the recorded plan instead of the static default -- the second element
  * instance, the context after a renegotiation, the other three Bayer orders of one

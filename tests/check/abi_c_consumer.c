@@ -66,6 +66,20 @@ main (void)
       return 7;
     }
   }
+  {
+    /* ABI v5 from C: the plan of a launch class, the second compute stream */
+    int variant = -1, band = 0, align = -1, source = -1;
+
+    if (mibayer_get_plan_for (ctx, 1, &variant, &band, &align, &source) != MIBAYER_OK || variant < 1
+        || source != MIBAYER_PLAN_SET || mibayer_set_plan_for (ctx, 1, variant, band, align) != MIBAYER_OK
+        || mibayer_get_plan_for (ctx, 0, NULL, NULL, NULL, NULL) != MIBAYER_ERR_ARG
+        || mibayer_ctx_stream2 (ctx) == NULL || mibayer_ctx_stream2 (ctx) == mibayer_ctx_stream (ctx)
+        || mibayer_ctx_stream2 (ctx) != mibayer_ctx_stream2 (ctx)) {
+      fprintf (stderr, "ABI v5 calls: unexpected answer (variant %d band %d align %d source %d)\n", variant, band,
+          align, source);
+      return 9;
+    }
+  }
   memset (out, 0, sizeof out);
   rc = mibayer_process_host (ctx, frame, out);
   {

@@ -667,6 +667,23 @@ mibayer_ctx_variant_name (const mibayer_ctx * c)
   return c ? "mock_plan" : NULL;
 }
 
+/* ABI v5: one plan per launch class -- the double keeps one plan for all of them */
+int
+mibayer_get_plan_for (const mibayer_ctx * c, int nframes, int *variant, int *band, int *align_stores, int *source)
+{
+  if (!c || nframes < 1)
+    return MIBAYER_ERR_ARG;
+  if (source)
+    *source = c->plan_source;
+  return mibayer_get_plan (c, variant, band, align_stores);
+}
+
+const char *
+mibayer_variant_name (int variant)
+{
+  return variant == 1 ? "mock_plan" : NULL;
+}
+
 int
 mibayer_autotune_list (mibayer_ctx * c, const void *const *d_srcs, void *const *d_dsts, int nframes, char *report,
     size_t report_len)
@@ -689,6 +706,15 @@ void *
 mibayer_ctx_stream (mibayer_ctx * c)
 {
   return c;                     /* any non-NULL token */
+}
+
+/* the second compute queue: another token.  The double executes every queued operation in ONE global order when
+ * something ordered after it completes -- a legal schedule for any number of queues as long as the element orders
+ * each launch after the last access of its buffers, which is what the tests check */
+void *
+mibayer_ctx_stream2 (mibayer_ctx * c)
+{
+  return c ? (char *) c + 1 : NULL;
 }
 
 int

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(pkg):
 
 def test_version_strerror_variants(pkg):
     L = pkg.lib()
-    assert L.mibayer_abi_version() == 4
+    assert L.mibayer_abi_version() == 5
     for code in range(-8, 1):
         assert L.mibayer_strerror(code)
     names = pkg.variant_names()

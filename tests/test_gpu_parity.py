@@ -423,65 +423,127 @@ def test_config4_and_5_every_ranks_share(gpu_pkg, oracle):
 
 
 def test_plan_cache_hands_the_measured_plan_to_later_contexts(gpu_pkg, oracle):
-    """what mibayer_autotune measured is kept per (device, geometry) for the process; the next context
-    of that geometry starts from it (plan_source CACHED) without measuring, other geometries do not, the bytes are
-    the oracle's before and after, a context created earlier can pick the plan up (mibayer_plan_from_cache), and
-    mibayer_plan_cache_clear() / MIBAYER_PLAN_CACHE=0 bring the default back."""
+    """what mibayer_autotune measured is kept per (device, geometry, LAUNCH CLASS) for the process; the
+    next context of that geometry starts from it (source CACHED) without measuring, other geometries do not, the bytes
+    are the oracle's before and after, a context created earlier can pick the plan up (mibayer_plan_from_cache), and
+    mibayer_plan_cache_clear() / MIBAYER_PLAN_CACHE=0 bring the default back.  ADVICE r04: a plan measured on one
+    launch class (here: launches of 8 1080p frames, the frame class) never becomes the default of the other."""
     w, h, n = 1920, 1080, 8
+    big = 64                    # a launch over 64 frames falls into the batch class
     L = gpu_pkg.lib()
     L.mibayer_plan_cache_clear()
     src = oracle.fill_synthetic(w, h, n, seed=5)
     want = oracle.bayer2rgb_batch(src, w, "rggb", 2, 1, 0, nthreads=4)
+    D, M, C = gpu_pkg.PLAN_DEFAULT, gpu_pkg.PLAN_MEASURED, gpu_pkg.PLAN_CACHED
     with gpu_pkg.Context(w, h, "rggb", "BGRx") as first, gpu_pkg.Context(w, h, "gbrg", "BGRx") as early:
-        assert first.plan_source == gpu_pkg.PLAN_DEFAULT and early.plan_source == gpu_pkg.PLAN_DEFAULT
-        default_plan = first.get_plan()
+        assert first.get_plan_for(n)[3] == D and early.get_plan_for(n)[3] == D and first.plan_source == D
+        default_plan, default_big = first.get_plan_for(n)[:3], first.get_plan_for(big)
+        assert first.get_plan() == default_big[:3]          # mibayer_get_plan describes the batch class
         assert np.array_equal(first.process_batch_via_device(src), want)
         d_src = first.device_alloc(n * first.src_bytes)
         d_dst = first.device_alloc(n * first.dst_bytes)
         first.to_device(d_src, src)
         report = first.autotune(d_src, d_dst, n)
-        assert first.plan_source == gpu_pkg.PLAN_MEASURED and "band" in report
-        measured = first.get_plan()
+        assert first.get_plan_for(n)[3] == M and "band" in report
+        assert first.get_plan_for(big) == default_big and first.plan_source == D     # the other class: untouched
+        measured = first.get_plan_for(n)[:3]
         assert np.array_equal(first.from_device(d_dst, n * first.dst_bytes).reshape(want.shape), want)
         # a later context of the same geometry (another Bayer order: same kernel): the measured plan, not measured again
         with gpu_pkg.Context(w, h, "bggr", "RGBx") as second:
-            assert second.plan_source == gpu_pkg.PLAN_CACHED and second.get_plan() == measured
+            assert second.get_plan_for(n) == measured + (C,) and second.get_plan_for(1) == measured + (C,)
+            assert second.get_plan_for(big) == default_big and second.plan_source == D
             assert np.array_equal(second.process_batch_via_device(src[:2]),
                                   oracle.bayer2rgb_batch(src[:2], w, "bggr", 0, 1, 2, nthreads=2))
         # one created before the measurement picks it up on request
-        assert early.get_plan() == default_plan and early.plan_from_cache() and early.get_plan() == measured
-        assert early.plan_source == gpu_pkg.PLAN_CACHED
+        assert early.get_plan_for(n)[:3] == default_plan and early.plan_from_cache()
+        assert early.get_plan_for(n) == measured + (C,) and early.get_plan_for(big) == default_big
         # another geometry, another stride: not this entry
         with gpu_pkg.Context(w, h + 2, "rggb", "BGRx") as other, \
                 gpu_pkg.Context(w, h, "rggb", "BGRx", dst_stride=4 * w + 64) as padded:
-            assert other.plan_source == gpu_pkg.PLAN_DEFAULT and padded.plan_source == gpu_pkg.PLAN_DEFAULT
+            assert other.get_plan_for(n)[3] == D and padded.get_plan_for(n)[3] == D
             assert not other.plan_from_cache()
         # an explicit variant is never overridden
         with gpu_pkg.Context(w, h, "rggb", "BGRx", variant=3) as pinned:
-            assert pinned.plan_source == gpu_pkg.PLAN_DEFAULT and pinned.variant_name == "lds_1x8_r4_dpp_nt"
+            assert pinned.get_plan_for(n)[3] == D and pinned.get_plan_for(n)[0] == 3
+            assert pinned.variant_name == "lds_1x8_r4_dpp_nt"
         # the list form measures over separate allocations and records too
         L.mibayer_plan_cache_clear()
         with gpu_pkg.Context(w, h, "rggb", "BGRx") as third:
-            assert third.plan_source == gpu_pkg.PLAN_DEFAULT
+            assert third.get_plan_for(4)[3] == D
             srcs = [d_src + f * third.src_bytes for f in range(4)]
             dsts = [d_dst + f * third.dst_bytes for f in range(4)]
             third.autotune_list(srcs, dsts)
-            assert third.plan_source == gpu_pkg.PLAN_MEASURED
+            assert third.get_plan_for(4)[3] == M
             assert np.array_equal(third.from_device(d_dst, 4 * third.dst_bytes).reshape(want[:4].shape), want[:4])
             with gpu_pkg.Context(w, h, "rggb", "BGRx") as fourth:
-                assert fourth.plan_source == gpu_pkg.PLAN_CACHED and fourth.get_plan() == third.get_plan()
+                assert fourth.get_plan_for(4) == third.get_plan_for(4)[:3] + (C,)
+        # an explicit pin (mibayer_set_plan) holds for every class; mibayer_set_plan_for for one
+        with gpu_pkg.Context(w, h, "rggb", "BGRx") as pin:
+            pin.set_plan(2, 0)
+            assert pin.get_plan_for(1) == (2, 0, 0, gpu_pkg.PLAN_SET) == pin.get_plan_for(big)
+            pin.set_plan_for(1, 3, 1)
+            assert pin.get_plan_for(1)[:2] == (3, 1) and pin.get_plan_for(big)[:2] == (2, 0)
+            assert pin.launch_geometry(1)["tile_w"] == 256 and pin.launch_geometry(big)["tile_w"] == 512
+            assert np.array_equal(pin.process_batch_via_device(src[:3]), want[:3])
         L.mibayer_plan_cache_clear()
         with gpu_pkg.Context(w, h, "rggb", "BGRx") as again:
-            assert again.plan_source == gpu_pkg.PLAN_DEFAULT and again.get_plan() == default_plan
+            assert again.get_plan_for(n) == default_plan + (D,)
         first.device_free(d_src)
         first.device_free(d_dst)
     code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as e; p = e.load_package(); "
             "c = p.Context(640, 480, 'rggb', 'BGRx'); d = c.device_alloc(c.src_bytes); o = c.device_alloc(c.dst_bytes); "
             "c.fill_synthetic(d, 1, 1); c.autotune(d, o, 1); c2 = p.Context(640, 480, 'rggb', 'BGRx'); "
-            "print('source', c2.plan_source)" % ROOT)
+            "print('source', c.get_plan_for(1)[3], c2.get_plan_for(1)[3])" % ROOT)
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
                          env=dict(os.environ, MIBAYER_PLAN_CACHE="0"))
-    assert res.returncode == 0 and "source 0" in res.stdout, res.stdout + res.stderr[-1500:]
+    assert res.returncode == 0 and "source 1 0" in res.stdout, res.stdout + res.stderr[-1500:]
+
+
+def test_frame_class_plan_and_the_second_compute_queue(gpu_pkg, oracle):
+    """Round 5: (1) a launch over ONE frame runs in the production shape whose grid needs the fewest rounds of the
+    device's workgroup slots (4K: 256x32 tiles = 1020 workgroups on 1024 slots, where 1024x8 tiles need 1080), batch
+    launches keep the batch plan; the two classes give the same bytes.  (2) mibayer_ctx_stream2: independent frames
+    dealt alternately over the context's two compute queues -- what hipbayer2rgb does -- come out bit-exact, and
+    mibayer_sync covers both queues."""
+    w, h = 3840, 2160
+    with gpu_pkg.Context(w, h, "rggb", "BGRx") as ctx:
+        slots = 4 * 256
+        g1, g64 = ctx.launch_geometry(1), ctx.launch_geometry(64)
+        assert g64["tile_w"] == 1024 and ctx.get_plan_for(64)[0] == 1
+        if g1["tile_w"] == 256:       # a 256-CU device (the rule uses the device's own CU count)
+            assert g1["grid_blocks"] == 1020 <= slots and ctx.get_plan_for(1)[0] == 3
+        assert ctx.get_plan_for(4)[0] == ctx.get_plan_for(1)[0] and ctx.get_plan_for(5)[0] == 1
+        n = 6
+        src = oracle.fill_synthetic(w, h, n, seed=77)
+        want = oracle.bayer2rgb_batch(src, w, "rggb", 2, 1, 0, nthreads=6)
+        srcs = [ctx.device_alloc(ctx.src_bytes) for _ in range(n)]
+        dsts = [ctx.device_alloc(ctx.dst_bytes) for _ in range(n)]
+        for f in range(n):
+            ctx.to_device(srcs[f], src[f])
+        s2 = ctx.stream2
+        assert s2 and s2 != ctx.stream and ctx.stream2 == s2
+        for rep in range(3):
+            for f in range(n):
+                ctx.process_device(srcs[f], dsts[f], 1, stream=(s2 if f & 1 else "ctx"))
+        ctx.sync()                    # both queues
+        for f in range(n):
+            assert np.array_equal(ctx.from_device(dsts[f], ctx.dst_bytes).reshape(want[f].shape), want[f]), f
+        # the batch-class plan on the same single frames: same bytes
+        ctx.set_plan_for(1, *ctx.get_plan_for(64)[:3])
+        assert ctx.launch_geometry(1)["tile_w"] == 1024
+        for f in range(n):
+            ctx.to_device(dsts[f], np.zeros(16, np.uint8))
+            ctx.process_device(srcs[f], dsts[f], 1, stream=(s2 if f & 1 else "ctx"))
+        ctx.sync()
+        for f in range(n):
+            assert np.array_equal(ctx.from_device(dsts[f], ctx.dst_bytes).reshape(want[f].shape), want[f]), f
+        for p in srcs + dsts:
+            ctx.device_free(p)
+    # the rule across geometries: fewest rounds, widest tile among equals; rows of one tile keep the narrow-tile rule
+    for (gw, gh, tile_w) in ((3264, 2448, 256), (7680, 4320, 512), (2592, 1944, 1024), (4096, 2160, 1024),
+                             (640, 480, 1024), (1920, 1080, 1024), (500, 300, 512)):
+        with gpu_pkg.Context(gw, gh, "bggr", "RGBx") as c2:     # (MI355X: 256 CUs x 4 workgroups)
+            assert c2.launch_geometry(1)["tile_w"] == tile_w, (gw, gh, c2.launch_geometry(1))
 
 
 def test_host_waits_nap_when_other_frames_are_queued(gpu_pkg, oracle):

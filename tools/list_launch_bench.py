@@ -44,6 +44,16 @@ with (pkg.Context(W, H, "rggb", (1, 2, 3), flags=pkg.FLAG_RGB2BAYER) if INVERSE
         for s, d in zip(srcs, dsts):
             ctx.process_device(s, d, 1)
 
+    s2 = ctx.stream2
+
+    def per_frame_two_queues():         # what hipbayer2rgb does by default (property overlap=true); ctx.sync covers both
+        for i, (s, d) in enumerate(zip(srcs, dsts)):
+            ctx.process_device(s, d, 1, stream=(s2 if i & 1 else "ctx"))
+
+    def per_frame_batch_plan():         # the rounds-unaware shape of rounds 1-4 (the batch-class plan on one frame)
+        for s, d in zip(srcs, dsts):
+            ctx.process_device(s, d, 1)
+
     def lists(k):
         def fn():
             for i in range(0, N, k):
@@ -52,7 +62,19 @@ with (pkg.Context(W, H, "rggb", (1, 2, 3), flags=pkg.FLAG_RGB2BAYER) if INVERSE
 
     print("# direction: %s" % ("rgb2bayer (inverse)" if INVERSE else "bayer2rgb"))
     print("# 64 device-resident 4K frames per pass, wall time per pass incl. launch issue (python ctypes caller), %d passes" % REPS)
-    for label, fn in [("one launch per frame (batch=1)", per_frame)] + \
+    rows = [("one launch per frame (batch=1), one queue", per_frame),
+            ("one launch per frame, alternating two queues", per_frame_two_queues)]
+    if not INVERSE:
+        frame_plan, batch_plan = ctx.get_plan_for(1)[:3], ctx.get_plan_for(N)[:3]
+        print("# frame-class plan %s, batch-class plan %s" % (frame_plan, batch_plan))
+        if frame_plan != batch_plan:
+            ctx.set_plan_for(1, *batch_plan)
+            t = timed(per_frame_batch_plan)
+            print("%-56s %8.3f ms  %8.1f fps  %9.1f Mpix/s  %6.1f GB/s (%4.1f %% of 8 TB/s)" % (
+                "one launch per frame, rounds 1-4 shape (batch plan)", t * 1e3, N / t, N * W * H / t / 1e6,
+                5.0 * N * W * H / t / 1e9, 5.0 * N * W * H / t / 1e9 / 80), flush=True)
+            ctx.set_plan_for(1, *frame_plan)
+    for label, fn in rows + \
                      [("list launches of %2d separately allocated frames" % k, lists(k)) for k in (2, 4, 8, 16)] + \
                      [("one launch over a contiguous 64-frame batch", lambda: ctx.process_device(big_src, big_dst, N))]:
         t = timed(fn)

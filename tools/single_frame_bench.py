@@ -19,7 +19,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-W, H, N, REPS = 3840, 2160, 64, 20
+W, H = (int(v) for v in os.environ.get("SFB_GEOMETRY", "3840x2160").split("x"))
+N = max(8, min(256, int(64 * 3840 * 2160 / (W * H))))
+REPS = 20
 INT32_MIN = -2 ** 31
 
 
@@ -101,18 +103,22 @@ def main():
             print("arm %s (%s): %.3f ms per pass of %d frames" % (sys.argv[2], ctx.variant_name, t * 1e3, N))
             return
         v0, b0, _ = ctx.get_plan()
-        print("# 64 device-resident 4K frames, ONE launch per frame, wall time per pass incl. launch issue, %d passes" % REPS)
+        print("# %d device-resident %dx%d frames, ONE launch per frame, wall time per pass incl. launch issue, %d passes"
+              % (N, W, H, REPS))
         print("# the context's default plan: %s band %s; grid per frame: %s" % (
             names[v0], "default" if b0 == INT32_MIN else b0, ctx.launch_geometry(1)))
+        variants = [int(v) for v in os.environ.get("SFB_VARIANTS", "1,2,3").split(",")]
+        queues = [int(v) for v in os.environ.get("SFB_QUEUES", "1,2,3,4").split(",")]
+        bands = [INT32_MIN if v == "d" else int(v) for v in os.environ.get("SFB_BANDS", "d,0").split(",")]
         for rnd in range(2):
-            for variant in (1, 2, 3):
-                for band in (INT32_MIN, 0):
+            for variant in variants:
+                for band in bands:
                     ctx.set_plan(variant, band, 0)
                     g = ctx.launch_geometry(1)
-                    for nq in (1, 2, 3, 4):
+                    for nq in queues:
                         t = arm(variant, band, nq)
                         print("round %d  %-22s band %-7s grid %5d  queues %d  %8.3f ms  %8.1f fps  %6.1f GB/s (%4.1f %% of 8 TB/s)" % (
-                            rnd, names[variant], "default" if band == INT32_MIN else band, g["grid"], nq, t * 1e3,
+                            rnd, names[variant], "default" if band == INT32_MIN else band, g["grid_blocks"], nq, t * 1e3,
                             N / t, 5.0 * N * W * H / t / 1e9, 5.0 * N * W * H / t / 1e9 / 80), flush=True)
 
 
