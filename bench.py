@@ -37,6 +37,7 @@ FORMAT = "BGRx"
 SEED = 2                         # config 3 uses seed 2
 BYTES_PER_PIXEL = 5              # algorithmic: 1 B mosaic read + 4 B RGBx written
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PLAN_SOURCES = ("default", "measured", "cached", "set")      # MIBAYER_PLAN_*
 
 
 # ----------------------------------------------------------------------------------------------
@@ -501,10 +502,13 @@ class ControlPlane:
     """Barrier and max-over-ranks for the timed region: the only communication of this bench (the data path has no
     collective).  Same small surface as the torch.distributed module, bound to one process group."""
 
-    def __init__(self, dist_mod, group, backend, device, fallback_reason=None):
+    def __init__(self, dist_mod, group, backend, device, fallback_reason=None, rccl_nranks=None):
         self._d, self._g, self._backend, self._device = dist_mod, group, backend, device
         self.ReduceOp = dist_mod.ReduceOp
         self.fallback_reason = fallback_reason      # RCCL was asked for and did not come up: why
+        # what a sum-of-ones all-reduce on DEVICE tensors over the RCCL group returned when the plane was brought up
+        # (= the number of ranks RCCL itself saw); None when the plane is not RCCL
+        self.rccl_nranks = rccl_nranks
 
     def max_over_ranks(self, value):
         """MAX of one float over the ranks, on the plane's own transport (a device tensor over RCCL)."""
@@ -572,7 +576,7 @@ def setup_distributed(args):
                 torch.cuda.synchronize()
                 if int(probe.item()) != world:
                     raise RuntimeError("all_reduce over RCCL returned %r for %d ranks" % (probe.item(), world))
-                plane = ControlPlane(dist_mod, group, "nccl", device)
+                plane = ControlPlane(dist_mod, group, "nccl", device, rccl_nranks=int(probe.item()))
                 plane.barrier()                     # the very call of the timed region, once outside it
                 torch.cuda.synchronize()
             except Exception as exc:        # noqa: BLE001 -- any RCCL bring-up failure: keep the gloo plane, loudly
@@ -581,6 +585,37 @@ def setup_distributed(args):
                                  "max-reduction run over gloo\n" % (rank, why))
                 plane = ControlPlane(dist_mod, None, "gloo", device, fallback_reason=why)
     return world, rank, device, plane
+
+
+def gpu_identity(pkg, device, rank):
+    """What this rank runs on, by hardware identity rather than by ordinal: PCI bus id of the HIP device, its NUMA
+    node, the name and CU count the runtime reports.  Gathered into `per_gpu` so that the N > 1 line answers "did the
+    ranks sit on N distinct GPUs" by itself."""
+    ident = {"rank": rank, "device": device, "pci_bus_id": pkg.device_pci_bus_id(device),
+             "numa_node": pkg.lib().mibayer_device_numa_node(device), "host": os.uname().nodename}
+    try:
+        import torch
+        prop = torch.cuda.get_device_properties(device)
+        ident["name"] = prop.name
+        ident["compute_units"] = prop.multi_processor_count
+        uuid = getattr(prop, "uuid", None)
+        if uuid is not None:
+            ident["uuid"] = str(uuid)
+    except Exception:       # noqa: BLE001 -- identity is best effort beyond the bus id
+        pass
+    return ident
+
+
+def check_distinct_gpus(identities, world, share_gpu):
+    """(distinct_gpus, error or None) over the ranks' (host, PCI bus id) pairs.  Two ranks on one card halve each
+    other's numbers silently, so that is refused unless --share-gpu (a testing mode) says it is meant."""
+    keys = [(i.get("host"), i.get("pci_bus_id") or "ordinal-%s" % i.get("device")) for i in identities]
+    distinct = len(set(keys))
+    if distinct < world and not share_gpu:
+        dup = sorted(set(k for k in keys if keys.count(k) > 1))
+        return distinct, ("bench.py: %d ranks but only %d distinct GPUs (shared: %s); pass --share-gpu if that is "
+                          "intended" % (world, distinct, ", ".join("%s/%s" % k for k in dup)))
+    return distinct, None
 
 
 def pin_to_device_node(pkg, device):
@@ -609,6 +644,13 @@ def run_stream(args):
     import __graft_entry__ as entry
     pkg = entry.load_package()
     world, rank, local_rank, dist = setup_distributed(args)
+    ident = gpu_identity(pkg, local_rank, rank)
+    identities = dist.gather_objects(ident) if dist is not None else [ident]
+    distinct_gpus, dup_error = check_distinct_gpus(identities, world, args.share_gpu)
+    if dup_error:
+        if dist is not None:
+            dist.destroy_process_group()
+        raise SystemExit(dup_error)
     node = pin_to_device_node(pkg, local_rank)
     total = 1000
     mine = len(shard_frames(total, world, rank))
@@ -641,8 +683,7 @@ def run_stream(args):
     parity = "bit-exact vs oracle on global frame %d (rggb->%s, host path)" % (gframe, FORMAT)
     per_gpu = None
     if dist is not None:
-        per_gpu = dist.gather_objects({"rank": rank, "device": local_rank, "numa_node": node, "frames": mine,
-                                       "parity": parity})
+        per_gpu = dist.gather_objects(dict(ident, pinned_to_numa_node=node, frames=mine, parity=parity))
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -661,6 +702,7 @@ def run_stream(args):
             "per_gpu": per_gpu, "parity": parity,
             "control_plane": dist.get_backend() if dist is not None else "single process",
             "control_plane_fallback": (dist.fallback_reason if dist is not None else None),
+            "rccl_nranks": dist.rccl_nranks if dist is not None else None, "distinct_gpus": distinct_gpus,
             "mechanisms": {"streams_and_events_3_queues": round(px / el_streams / 1e6, 1),
                            "hipgraph_captured_launch": round(px / el_graph / 1e6, 1),
                            "hipgraph_whole_chain_per_slot": round(px / el_chain / 1e6, 1)},
@@ -679,6 +721,13 @@ def run(args):
     if pkg.device_count() < 1:
         raise SystemExit("bench.py: no MI355X visible; the bayer2rgb path has no CPU fallback")
     world, rank, local_rank, dist = setup_distributed(args)
+    ident = gpu_identity(pkg, local_rank, rank)
+    identities = dist.gather_objects(ident) if dist is not None else [ident]
+    distinct_gpus, dup_error = check_distinct_gpus(identities, world, args.share_gpu)
+    if dup_error:               # every rank sees the same list: all of them leave
+        if dist is not None:
+            dist.destroy_process_group()
+        raise SystemExit(dup_error)
 
     variant = args.variant
     ctxs = {o: pkg.Context(WIDTH, HEIGHT, o, FORMAT, device=local_rank, variant=variant) for o in ORDERS}
@@ -770,10 +819,15 @@ def run(args):
         "control_plane_fallback": (dist.fallback_reason if dist is not None else None),
         "barrier_ms": round(barrier_ms, 4),
         "value_kernel_only": round(pixels * world / (kernel_ms_max * 1e-3) / 1e6, 1),
+        # hardware identity of the run: ranks RCCL itself counted (sum-of-ones all-reduce on device tensors; null
+        # when the plane is not RCCL) and distinct (host, PCI bus id) pairs over the ranks -- both must equal n_gpus
+        "rccl_nranks": dist.rccl_nranks if dist is not None else None,
+        "distinct_gpus": distinct_gpus,
         "config": {"workload": "3840x2160 x 64 frames per GPU, bggr/rggb/grbg/gbrg -> BGRx cycled per step "
                                "(BASELINE.json configs[2]), one launch per step, frames sharded round-robin "
                                "over ranks, no collective",
                    "kernel_variant": ctx0.variant_name, "launch_plan": ctx0.launch_geometry(BATCH),
+                   "plan_source": PLAN_SOURCES[ctx0.get_plan_for(BATCH)[3]],
                    "autotune": tune.get(ORDERS[0], "off"), "parity": parity,
                    "control_plane": dist.get_backend() if dist is not None else "single process"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -790,7 +844,6 @@ def run(args):
     # `traffic` is a measurement of THIS run or null: PMC counters need a rocprofv3 wrapper around the process, so
     # the unwrapped bench line says null and carries the last profiled figure under its own name, with the
     # plan, the box and the build it was taken on (tools/summarize_profiles.py writes the file)
-    result["roofline"]["traffic_profiled"] = profiled_traffic(ctx0.launch_geometry(BATCH)["band"], ctx0.variant_name)
     if rank == 0 and world == 1 and not args.no_traffic:
         # measured in THIS run: a profiled child of this very script, same batch, same plan, after the timed region
         torch.cuda.synchronize()
@@ -800,11 +853,16 @@ def run(args):
         result["roofline"]["traffic"] = traffic
         if traffic is None:
             result["roofline"]["traffic_note"] = why
+    if result["roofline"]["traffic"] is None:
+        # ONE traffic figure per record: only when nothing was measured in this run does the last
+        # committed figure travel, under its own name, with the box and the build it was taken on
+        result["roofline"]["traffic_profiled"] = profiled_traffic(ctx0.launch_geometry(BATCH)["band"],
+                                                                  ctx0.variant_name)
     if dist is not None:
         # per-GPU breakdown (SURVEY.md section 5 "metrics"): `roofline` above is rank 0's kernel, this is every rank's
-        mine = {"rank": rank, "device": local_rank, "kernel_ms": round(kernel_ms, 4),
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "kernel_variant": ctx0.variant_name,
-                "band": ctx0.launch_geometry(BATCH)["band"], "parity": parity}
+        mine = dict(ident, kernel_ms=round(kernel_ms, 4), frac=round(achieved / HBM_PEAK_GBPS, 4),
+                    kernel_variant=ctx0.variant_name, band=ctx0.launch_geometry(BATCH)["band"],
+                    plan_source=PLAN_SOURCES[ctx0.get_plan_for(BATCH)[3]], parity=parity)
         result["per_gpu"] = dist.gather_objects(mine)
     if rank == 0 and world == 1:
         if not args.no_host_path:

@@ -99,6 +99,7 @@ _lib = None
 # every symbol include/mibayer.h declares: name -> (restype, argtypes)
 ABI = {
     "mibayer_abi_version": (ctypes.c_int, []),
+    "mibayer_device_pci_bus_id": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]),
     "mibayer_is_lab_build": (ctypes.c_int, []),
     "mibayer_device_count": (ctypes.c_int, []),
     "mibayer_strerror": (ctypes.c_char_p, [ctypes.c_int]),
@@ -191,6 +192,14 @@ ABI = {
                                                ctypes.POINTER(ctypes.c_int64)]),
     "mibayer_block_to_tile": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
 }
+
+
+def device_pci_bus_id(device):
+    """'0000:c1:00.0' of a HIP ordinal (None if the runtime does not say)."""
+    buf = ctypes.create_string_buffer(32)
+    if lib().mibayer_device_pci_bus_id(device, buf, len(buf)) != OK:
+        return None
+    return buf.value.decode()
 
 
 def build(quiet=True):

@@ -935,6 +935,20 @@ extern "C" int mibayer_device_count (void)
   return device_count_cached ();
 }
 
+/* "0000:c1:00.0" of a HIP ordinal: which physical card a rank / shard / element runs on (bench.py's per_gpu identity,
+ * the elements' start-up log) */
+extern "C" int mibayer_device_pci_bus_id (int device, char *out, size_t len)
+{
+  if (!out || len < 13)
+    return MIBAYER_ERR_ARG;
+  out[0] = 0;
+  if (device < 0 || device >= device_count_cached ())
+    return MIBAYER_ERR_NO_DEVICE;
+  if (hip_failed (hipDeviceGetPCIBusId (out, (int) len, device), "hipDeviceGetPCIBusId"))
+    return MIBAYER_ERR_HIP;
+  return MIBAYER_OK;
+}
+
 extern "C" const char *mibayer_strerror (int status)
 {
   switch (status) {

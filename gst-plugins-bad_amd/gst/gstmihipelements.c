@@ -782,7 +782,8 @@ typedef struct
   /* batch mode (property "batch" > 1): input / output buffer pairs waiting for ONE launch over all of
    * them, and converted outputs waiting to be handed to the base class one by one */
   gint batch;
-  gint autotune;                /* property "autotune": measure the launch plan on the first frames (g_atomic_int_*) */
+  gint autotune;                /* property "autotune": measure the launch plan on the first frames (g_atomic_int_*);
+                                   -1 = not set by anybody: on for batch >= 4, off below (HB2R_AUTOTUNE_ON) */
   gboolean tuned;               /* the context's plan has been settled: measured, or taken from the process cache */
   gint overlap;                 /* property "overlap": consecutive frames alternate the context's two compute queues */
   guint frame_no;               /* frames launched one at a time so far: picks the queue */
@@ -798,6 +799,15 @@ typedef struct
 } Hb2rPair;
 
 #define HB2R_MAX_BATCH 16       /* frames of one list launch (mibayer_process_device_list) */
+/* Does this instance measure its launch plan?  Whoever set the property decides; otherwise batch mode from 4 frames per
+ * launch on measures (the static default is up to 5 points off on some widths, profiles/
+ * r04_plan_sweep_530Mpix.log, a measurement costs one first batch per geometry per PROCESS thanks to the plan cache,
+ * and a stream that asked for batch >= 4 has traded latency for throughput already), frame-by-frame mode does not
+ * (its first frame would wait 0.1-0.2 s). */
+#define HB2R_AUTOTUNE_MIN_BATCH 4
+#define HB2R_AUTOTUNE_ON(self) (g_atomic_int_get (&(self)->autotune) >= 0 \
+    ? g_atomic_int_get (&(self)->autotune) != 0 \
+    : g_atomic_int_get (&(self)->batch) >= HB2R_AUTOTUNE_MIN_BATCH)
 
 /* hiprgb2bayer, the sibling direction (the plugin's second element, reference gst/bayer/gstrgb2bayer.c), is the
  * same element with the pad roles swapped: a subclass whose class carries `inverse` -- exactly how plugin `bayer`
@@ -878,8 +888,7 @@ hb2r_get_property (GObject * object, guint prop_id, GValue * value,
     g_value_set_int (value,
         g_atomic_int_get (&((GstMiHipBayer2RGB *) object)->batch));
   else if (prop_id == PROP_AUTOTUNE)
-    g_value_set_boolean (value,
-        g_atomic_int_get (&((GstMiHipBayer2RGB *) object)->autotune) != 0);
+    g_value_set_boolean (value, HB2R_AUTOTUNE_ON ((GstMiHipBayer2RGB *) object));
   else if (prop_id == PROP_OVERLAP)
     g_value_set_boolean (value,
         g_atomic_int_get (&((GstMiHipBayer2RGB *) object)->overlap) != 0);
@@ -1115,8 +1124,8 @@ hb2r_autotune_once (GstMiHipBayer2RGB * self, const void *const *srcs,
     hb2r_note_plan (self);      /* ... or has one now: another element measured since */
     return;
   }
-  if (!g_atomic_int_get (&self->autotune))
-    return;                     /* nobody asked */
+  if (!HB2R_AUTOTUNE_ON (self))
+    return;                     /* nobody asked, and not a batch mode that measures by default */
   rc = mibayer_autotune_list (self->ctx, srcs, dsts, (int) n, report, sizeof report);
   if (rc != MIBAYER_OK) {
     GST_WARNING_OBJECT (self, "plan measurement failed (%s); the default plan stays", mibayer_strerror (rc));
@@ -1484,7 +1493,8 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
           "process-wide plan cache; later contexts of that geometry on that GPU "
           "-- in any element -- take the measured plan without measuring.  Off: "
           "the static default plan, or the cached one if some element measured "
-          "before.  No effect on hiprgb2bayer",
+          "before.  Unless set, on for batch >= 4 (the first full batch measures) "
+          "and off below.  No effect on hiprgb2bayer",
           FALSE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_OVERLAP,
       g_param_spec_boolean ("overlap", "Overlap consecutive frames",
@@ -1525,7 +1535,7 @@ gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
   self->out_pool = NULL;
   self->out_pool_device = 0;
   self->batch = 1;
-  self->autotune = 0;
+  self->autotune = -1;
   self->overlap = 1;
   self->frame_no = 0;
   self->tuned = FALSE;

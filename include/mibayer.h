@@ -56,7 +56,8 @@ extern "C" {
  * (mibayer_variant_name) rather than keeping numbers across versions. */
 /* 5: additive over 4 -- one launch plan per LAUNCH CLASS (launches of a few rounds of workgroups: one frame per
  * launch, vs. batch launches): mibayer_get_plan_for / mibayer_set_plan_for, the plan cache keyed by class;
- * mibayer_ctx_stream2 (a second compute queue of the context for independent frames), covered by mibayer_sync.
+ * mibayer_ctx_stream2 (a second compute queue of the context for independent frames), covered by mibayer_sync;
+ * mibayer_device_pci_bus_id.
  * mibayer_get_plan / mibayer_plan_source / mibayer_ctx_variant_name keep describing the batch-class plan,
  * mibayer_set_plan / mibayer_copy_plan pin every class. */
 #define MIBAYER_ABI_VERSION 5
@@ -144,6 +145,9 @@ typedef struct mibayer_ctx mibayer_ctx;
 /* ---- global ------------------------------------------------------------- */
 
 int mibayer_abi_version (void);
+/* PCI bus id ("0000:c1:00.0", NUL-terminated; len >= 13) of a HIP ordinal: the physical identity of the card a
+ * context, pool shard or bench rank runs on (v5). */
+int mibayer_device_pci_bus_id (int device, char *out, size_t len);
 /* 1 = this library was built with -DMIBAYER_LAB (`make lab`): the experiment
  * kernel arms and the tuning environment variables of DESIGN.md are compiled in.
  * 0 = the product build: the three production tile shapes with their store-policy

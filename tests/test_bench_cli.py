@@ -16,6 +16,22 @@ def test_defaults_and_workload_constants():
     assert set(bench.ORDERS) == {"bggr", "rggb", "grbg", "gbrg"}
 
 
+def test_distinct_gpu_check_refuses_ranks_that_share_a_card():
+    """the N > 1 line must prove what it ran on -- distinct (host, PCI bus id) pairs are counted, and
+    ranks that share a card are refused unless --share-gpu says it is meant."""
+    ids = [{"rank": r, "device": r, "pci_bus_id": "0000:%02x:00.0" % (0x10 + r), "host": "n0"} for r in range(8)]
+    assert bench.check_distinct_gpus(ids, 8, False) == (8, None)
+    two = [dict(ids[0]), dict(ids[0], rank=1)]
+    n, err = bench.check_distinct_gpus(two, 2, False)
+    assert n == 1 and "only 1 distinct GPUs" in err and "0000:10:00.0" in err and "--share-gpu" in err
+    assert bench.check_distinct_gpus(two, 2, True) == (1, None)
+    # the same bus id on two hosts is two cards; a runtime that reports no bus id falls back to the ordinal
+    assert bench.check_distinct_gpus([dict(ids[0]), dict(ids[0], host="n1")], 2, False) == (2, None)
+    anon = [{"rank": 0, "device": 0, "pci_bus_id": None, "host": "n0"}, {"rank": 1, "device": 1, "pci_bus_id": None, "host": "n0"}]
+    assert bench.check_distinct_gpus(anon, 2, False) == (2, None)
+    assert bench.PLAN_SOURCES == ("default", "measured", "cached", "set")
+
+
 def test_without_a_gpu_the_benchmark_refuses(pkg):
     if pkg.device_count() > 0:
         import pytest

@@ -1500,6 +1500,29 @@ def test_bench_two_ranks_batch_mode():
     assert abs(j["value"] - want) / want < 0.01, (j["value"], want)
     assert j["config"]["control_plane"] == "gloo" and j["roofline"]["bound"] == "hbm"
     assert 0.2 < j["roofline"]["frac"] < 1.0                    # two ranks share one GPU: about half each
+    # the line says what it ran on -- here two ranks on ONE card (--share-gpu), no RCCL
+    assert j["distinct_gpus"] == 1 and j["rccl_nranks"] is None
+    for p in j["per_gpu"]:
+        assert p["pci_bus_id"] and len(p["pci_bus_id"].split(":")) == 3 and p["numa_node"] >= -1
+        assert p["plan_source"] in ("measured", "cached") and p["kernel_variant"] and "compute_units" in p
+    assert len(set(p["pci_bus_id"] for p in j["per_gpu"])) == 1
+
+
+def test_bench_refuses_two_ranks_on_one_card_unless_told():
+    """Two ranks on one GPU without --share-gpu: refused before anything is timed, no JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29613", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-host-path"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HIP_VISIBLE_DEVICES="0,0")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    out = res.stdout + res.stderr
+    if "distinct GPUs" not in out:
+        # the runtime may refuse the duplicated ordinal itself (one visible device, LOCAL_RANK 1 has no GPU)
+        assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")], out[-3000:]
+        return
+    assert res.returncode != 0 and "--share-gpu" in out
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_bench_two_ranks_stream_mode():

@@ -265,7 +265,8 @@ def test_autotune_property_measures_once_and_later_contexts_take_the_cached_plan
     frames(n, w * h, first=11).tofile(inp)
     exe, env, _ = rig
     chain = "hipupload ! hipbayer2rgb %s ! hiprgb2bayer ! hipbayer2rgb %s ! hipdownload"
-    for props, frames_measured in (("autotune=true", 1), ("autotune=true batch=4", 4)):
+    # round 5: batch >= 4 measures by default (nobody set the property); batch < 4 and autotune=false do not
+    for props, frames_measured in (("autotune=true", 1), ("autotune=true batch=4", 4), ("batch=4", 4), ("batch=8", 8)):
         res = subprocess.run([exe, "convert", chain % (props, props),
                               B2R % ("bggr", w, h), str(inp), str(w * h), str(outp)], capture_output=True, text=True,
                              env=dict(env, MOCK_MIBAYER_LOG_AUTOTUNE="1", GST_DEBUG="mihip:4"), timeout=120)
@@ -283,6 +284,11 @@ def test_autotune_property_measures_once_and_later_contexts_take_the_cached_plan
                          timeout=120)
     assert res.returncode == 0 and "autotune #" not in res.stdout + res.stderr
     assert "source=default" in res.stdout + res.stderr
+    for props in ("batch=3", "autotune=false batch=4"):
+        res = subprocess.run([exe, "convert", chain % (props, props), B2R % ("bggr", w, h), str(inp), str(w * h), str(outp)],
+                             capture_output=True, text=True,
+                             env=dict(env, MOCK_MIBAYER_LOG_AUTOTUNE="1", GST_DEBUG="mihip:4"), timeout=120)
+        assert res.returncode == 0 and "autotune #" not in res.stdout + res.stderr, props
 
 
 def test_device_memory_rgb2bayer_shares_the_converter_logic(rig, tmp_path):
