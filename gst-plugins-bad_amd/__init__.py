@@ -37,6 +37,7 @@ FORMATS = {
 }
 
 PLAN_DEFAULT, PLAN_MEASURED, PLAN_CACHED, PLAN_SET = 0, 1, 2, 3
+FRAME_QUEUES = 4                # MIBAYER_FRAME_QUEUES
 OK = 0
 ERR_ARG, ERR_GEOMETRY, ERR_LAYOUT, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_BUSY, ERR_EMPTY, ERR_TIMEOUT = (
     -1, -2, -3, -4, -5, -6, -7, -8, -9)
@@ -150,7 +151,7 @@ ABI = {
     "mibayer_set_plan": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "mibayer_get_plan_for": (ctypes.c_int, [_vp, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 4),
     "mibayer_set_plan_for": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
-    "mibayer_ctx_stream2": (_vp, [_vp]),
+    "mibayer_ctx_frame_queue": (_vp, [_vp, ctypes.c_int]),
     "mibayer_plan_source": (ctypes.c_int, [_vp]),
     "mibayer_plan_from_cache": (ctypes.c_int, [_vp]),
     "mibayer_plan_cache_clear": (None, []),
@@ -517,13 +518,17 @@ class Context:
     def set_plan_for(self, nframes, variant, band, align=0):
         _check(lib().mibayer_set_plan_for(self._h, nframes, variant, band, align), "mibayer_set_plan_for")
 
-    @property
-    def stream2(self):
-        """The context's second compute stream (hipStream_t as an int), created on first use."""
-        s = lib().mibayer_ctx_stream2(self._h)
+    def frame_queue(self, k):
+        """Frame queue k of the context's device (hipStream_t as an int): FRAME_QUEUES compute streams on hardware
+        queues of their own, for independent one-frame launches; created on first use."""
+        s = lib().mibayer_ctx_frame_queue(self._h, k)
         if not s:
-            raise MibayerError(ERR_HIP, "mibayer_ctx_stream2")
+            raise MibayerError(ERR_HIP, "mibayer_ctx_frame_queue(%d)" % k)
         return s
+
+    @property
+    def frame_queues(self):
+        return [self.frame_queue(k) for k in range(FRAME_QUEUES)]
 
     def set_plan(self, variant, band, align=0):
         _check(lib().mibayer_set_plan(self._h, variant, band, align), "mibayer_set_plan")

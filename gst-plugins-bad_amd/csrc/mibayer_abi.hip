@@ -194,6 +194,24 @@ struct DeviceQueues {
 static std::mutex g_queues_mu;
 static DeviceQueues g_queues[64];
 
+/* Frame queues: MIBAYER_FRAME_QUEUES compute streams per DEVICE, each on a HARDWARE QUEUE OF ITS OWN, for independent
+ * one-frame launches.  A launch over one frame is a single round of workgroups -- ramp-up, one burst of loads, one
+ * burst of stores, drain: 4K 9.4 us against 6.5 us per frame inside a batch -- and never reaches a steady state by
+ * itself; dealt round-robin over four queues, the ramp-up of frame n+1..n+3 overlaps the drain of frame n (4K: 54 %
+ * of HBM peak on one queue, 63 % on two, 66-67 % on four; rgb2bayer 55 / 70 / 77-78 %; profiles/r05_single_frame.md).
+ * Ordinary HIP streams do not do: the runtime multiplexes them onto a small pool of hardware queues (four per process
+ * by default, shared with the copy queues), so "four streams" are two or three queues with launches serialised behind
+ * each other again (3 streams measured WORSE than 2).  A stream made by hipExtStreamCreateWithCUMask owns its hardware
+ * queue; the mask given is "every CU" -- a lone frame still gets the whole device -- partitioning the CUs instead
+ * (queue k owns the CUs with index % 4 == k) measured within a point of it.  Hardware queues are a finite resource
+ * (59 of them in one process slowed every launch of that process by 2x), hence per device, shared by its contexts,
+ * created on first use and released with the last context of the device. */
+struct FrameQueues {
+  hipStream_t q[MIBAYER_FRAME_QUEUES] = {};
+  bool tried = false;
+};
+static FrameQueues g_frame_queues[64];  /* g_queues_mu */
+
 /* Device frames of contexts that were destroyed, kept for the next context of the same geometry on that device
  * (renegotiation, one element after another): hipFree waits for EVERY queue of the device to drain, so a context
  * that frees its ring on the way out would wait for its neighbours' batches.  Bounded (kCacheMax blocks per device);
@@ -303,12 +321,10 @@ struct mibayer_ctx {
   hipStream_t s_compute = nullptr;
   hipStream_t s_d2h = nullptr;
   bool shared_queues = false;           /* the three above belong to g_queues[device] */
-  /* A second compute queue, the context's own, created by the first mibayer_ctx_stream2(): device-resident callers
-   * deal consecutive, independent single-frame launches alternately over s_compute and this one, so that the ramp-up
-   * of frame n+1 overlaps the drain of frame n (a one-frame launch is one round of workgroups: it never reaches a
-   * steady state by itself; profiles/r05_single_frame.md) */
-  hipStream_t s_compute2 = nullptr;
-  bool dirty_compute2 = false;          /* as dirty_compute, for s_compute2 */
+  /* Frame queues (g_frame_queues[device], mibayer_ctx_frame_queue): which of them this context has queued
+   * device-resident work on since the last mibayer_sync, and whether it has ever asked for them (wedge fences) */
+  bool dirty_frame[MIBAYER_FRAME_QUEUES] = {};
+  bool uses_frame_queues = false;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_fence = nullptr;        /* fence of mibayer_sync / of a failed submit */
   /* Deadline of every host-side wait for the device (mibayer_wait, the synchronous frame call, sync, destroy):
@@ -471,7 +487,12 @@ static void on_deadline (mibayer_ctx *c)
   if (!w)
     return;
   w->device = c->device;
-  std::vector<hipStream_t> queues = { c->s_h2d, c->s_compute, c->s_d2h, c->s_compute2 };
+  std::vector<hipStream_t> queues = { c->s_h2d, c->s_compute, c->s_d2h };
+  if (c->uses_frame_queues && c->device < 64) {
+    std::lock_guard<std::mutex> lk (g_queues_mu);
+    for (hipStream_t q : g_frame_queues[c->device].q)
+      queues.push_back (q);
+  }
   for (Slot &sl : c->ring)
     if (sl.s_graph)
       queues.push_back (sl.s_graph);
@@ -598,7 +619,14 @@ static void fence_queues (mibayer_ctx *c)
 {
   if (c->wedged || !c->ev_fence)
     return;
-  for (hipStream_t q : { c->s_h2d, c->s_compute, c->s_d2h, c->s_compute2 }) {
+  std::vector<hipStream_t> own = { c->s_h2d, c->s_compute, c->s_d2h };
+  if (c->uses_frame_queues && c->device < 64) {
+    std::lock_guard<std::mutex> lk (g_queues_mu);
+    for (int k = 0; k < MIBAYER_FRAME_QUEUES; k++)
+      if (c->dirty_frame[k])
+        own.push_back (g_frame_queues[c->device].q[k]);
+  }
+  for (hipStream_t q : own) {
     if (!q)
       continue;
     if (hipEventRecord (c->ev_fence, q) != hipSuccess) {
@@ -1346,16 +1374,25 @@ extern "C" void mibayer_destroy (mibayer_ctx *c)
         q = DeviceQueues ();
       }
     }
-    if (c->device < 64 && c->counted && --g_cache[c->device].contexts == 0 && !leak) {
-      trim.swap (g_cache[c->device].bufs);
-      g_cache[c->device].bytes = 0;
+    if (c->device < 64 && c->counted && --g_cache[c->device].contexts == 0) {
+      /* the last context of the device: its frame queues go too (to the wedge registry if the device does not answer) */
+      FrameQueues &fq = g_frame_queues[c->device];
+      for (hipStream_t &st : fq.q) {
+        if (st && how == RELEASE_ORPHAN)
+          c->wedge->streams.push_back (st);
+        else if (st && !leak)
+          (void) hipStreamDestroy (st);
+        st = nullptr;
+      }
+      fq.tried = false;
+      if (!leak) {
+        trim.swap (g_cache[c->device].bufs);
+        g_cache[c->device].bytes = 0;
+      }
     }
   }
-  {
-    std::vector<hipStream_t> own = { c->s_compute2 };
-    if (!c->shared_queues)
-      own.insert (own.end (), { c->s_h2d, c->s_compute, c->s_d2h });
-    for (hipStream_t st : own) {
+  if (!c->shared_queues) {
+    for (hipStream_t st : { c->s_h2d, c->s_compute, c->s_d2h }) {
       if (!st)
         continue;
       if (how == RELEASE_ORPHAN)
@@ -2059,6 +2096,20 @@ extern "C" int mibayer_set_wait_timeout (mibayer_ctx *c, int ms)
 
 /* ---- device-resident batch path ------------------------------------------------------ */
 
+/* device-resident work is about to be queued on `s` through this context: remember which of the context's queues
+ * mibayer_sync has to fence */
+static void mark_dirty (mibayer_ctx *c, hipStream_t s)
+{
+  if (s == c->s_compute) {
+    c->dirty_compute = true;
+  } else if (s && c->uses_frame_queues && c->device < 64) {
+    const FrameQueues &fq = g_frame_queues[c->device];  /* the pointers are stable while this context lives */
+    for (int k = 0; k < MIBAYER_FRAME_QUEUES; k++)
+      if (fq.q[k] == s)
+        c->dirty_frame[k] = true;
+  }
+}
+
 extern "C" int mibayer_process_device (mibayer_ctx *c, const void *d_src,
     size_t src_frame_bytes, void *d_dst, size_t dst_frame_bytes, int nframes,
     void *hip_stream)
@@ -2075,10 +2126,7 @@ extern "C" int mibayer_process_device (mibayer_ctx *c, const void *d_src,
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
   Range r ("mibayer:process_device");
-  if ((hipStream_t) hip_stream == c->s_compute)
-    c->dirty_compute = true;
-  else if (hip_stream && (hipStream_t) hip_stream == c->s_compute2)
-    c->dirty_compute2 = true;
+  mark_dirty (c, (hipStream_t) hip_stream);
   return launch (c, d_src, src_frame_bytes, d_dst, dst_frame_bytes, nframes,
       (hipStream_t) hip_stream);
 }
@@ -2103,10 +2151,7 @@ extern "C" int mibayer_process_device_list (mibayer_ctx *c,
   if (!guard.ok)
     return MIBAYER_ERR_HIP;
   Range r ("mibayer:process_device_list");
-  if ((hipStream_t) hip_stream == c->s_compute)
-    c->dirty_compute = true;
-  else if (hip_stream && (hipStream_t) hip_stream == c->s_compute2)
-    c->dirty_compute2 = true;
+  mark_dirty (c, (hipStream_t) hip_stream);
   if (c->inverse) {
     /* the sibling direction (reference loop gst/bayer/gstrgb2bayer.c:254-268): up to kMaxList separately allocated
      * frames per launch of the flat kernel; the tile kernel (MIBAYER_R2B_FLAT=0, tuning) has no table and goes
@@ -2192,18 +2237,36 @@ extern "C" void *mibayer_ctx_stream (mibayer_ctx *c)
   return c ? (void *) c->s_compute : NULL;
 }
 
-extern "C" void *mibayer_ctx_stream2 (mibayer_ctx *c)
+extern "C" void *mibayer_ctx_frame_queue (mibayer_ctx *c, int k)
 {
-  if (!c)
+  if (!c || k < 0 || k >= MIBAYER_FRAME_QUEUES || c->device >= 64)
     return NULL;
-  if (!c->s_compute2) {
-    DeviceGuard guard (c->device);
-    if (!guard.ok || hip_failed (hipStreamCreateWithFlags (&c->s_compute2, hipStreamNonBlocking), "hipStreamCreate")) {
-      c->s_compute2 = nullptr;
-      return NULL;
+  DeviceGuard guard (c->device);
+  if (!guard.ok)
+    return NULL;
+  std::lock_guard<std::mutex> lk (g_queues_mu);
+  FrameQueues &fq = g_frame_queues[c->device];
+  if (!fq.tried) {
+    fq.tried = true;
+    /* "every CU" as a mask: what makes the stream own a hardware queue is the call, not the partition */
+    uint32_t mask[32];
+    const int words = (c->num_cus + 31) / 32 < 32 ? (c->num_cus + 31) / 32 : 32;
+    for (int w = 0; w < words; w++) {
+      const int bits = c->num_cus - 32 * w;
+      mask[w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
     }
+    for (hipStream_t &st : fq.q)
+      if (hipExtStreamCreateWithCUMask (&st, (uint32_t) words, mask) != hipSuccess) {
+        (void) hipGetLastError ();
+        st = nullptr;
+        /* no dedicated hardware queue to be had: an ordinary stream still overlaps some */
+        if (hip_failed (hipStreamCreateWithFlags (&st, hipStreamNonBlocking), "hipStreamCreate"))
+          st = nullptr;
+      }
   }
-  return (void *) c->s_compute2;
+  if (fq.q[k])
+    c->uses_frame_queues = true;
+  return (void *) fq.q[k];
 }
 
 /* Waits for what THIS context has in flight: the download events of its own pending frames and, if it queued
@@ -2219,8 +2282,15 @@ extern "C" int mibayer_sync (mibayer_ctx *c)
   int rc = wait_own_frames (c);
   if (rc != MIBAYER_OK)
     return rc;
-  struct { hipStream_t q; bool *dirty; } own[2] = {
-    { c->s_compute, &c->dirty_compute }, { c->s_compute2, &c->dirty_compute2 } };
+  struct { hipStream_t q; bool *dirty; } own[1 + MIBAYER_FRAME_QUEUES] = { { c->s_compute, &c->dirty_compute } };
+  if (c->uses_frame_queues && c->device < 64) {
+    std::lock_guard<std::mutex> lk (g_queues_mu);
+    for (int k = 0; k < MIBAYER_FRAME_QUEUES; k++)
+      own[1 + k] = { g_frame_queues[c->device].q[k], &c->dirty_frame[k] };
+  } else {
+    for (int k = 0; k < MIBAYER_FRAME_QUEUES; k++)
+      own[1 + k] = { nullptr, &c->dirty_frame[k] };
+  }
   for (auto &o : own) {
     if (!*o.dirty || !o.q)
       continue;

@@ -785,7 +785,7 @@ typedef struct
   gint autotune;                /* property "autotune": measure the launch plan on the first frames (g_atomic_int_*);
                                    -1 = not set by anybody: on for batch >= 4, off below (HB2R_AUTOTUNE_ON) */
   gboolean tuned;               /* the context's plan has been settled: measured, or taken from the process cache */
-  gint overlap;                 /* property "overlap": consecutive frames alternate the context's two compute queues */
+  gint overlap;                 /* property "overlap": consecutive frames go round-robin over the device's frame queues */
   guint frame_no;               /* frames launched one at a time so far: picks the queue */
   gchar plan[160];              /* property "plan" (read-only): the context's launch plan and where it came from */
   gboolean prerolled;           /* a frame has left since start / flush: batching may begin */
@@ -1240,15 +1240,16 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
    * after it.  The next user either orders its own stream after that event or
    * -- any plain map, hipdownload, a CPU map -- waits for it on the host. */
   stream = mibayer_ctx_stream (self->ctx);
-  /* Frames are independent and each is handed over by its own events, so consecutive ones alternate the context's
-   * two compute queues: a one-frame launch is a single round of workgroups, and on the other queue the ramp-up of
-   * frame n+1 overlaps the drain of frame n (4K: 54.8 -> 63.4 % of HBM peak, profiles/r05_single_frame.md).  The
-   * frame that settles the plan (it may run mibayer_autotune_list on the first queue) stays on the first queue. */
-  if (self->tuned && g_atomic_int_get (&self->overlap) && (self->frame_no++ & 1)) {
-    gpointer second = mibayer_ctx_stream2 (self->ctx);
+  /* Frames are independent and each is handed over by its own events, so consecutive ones go round-robin over the
+   * device's frame queues (hardware queues of their own): a one-frame launch is a single round of workgroups, and on
+   * the other queues the ramp-up of the next frames overlaps the drain of frame n (4K: 54 -> 66 % of HBM peak,
+   * rgb2bayer 55 -> 77 %; profiles/r05_single_frame.md).  The frame that settles the plan (it may run
+   * mibayer_autotune_list on the context's stream) stays on the context's stream. */
+  if (self->tuned && g_atomic_int_get (&self->overlap)) {
+    gpointer fq = mibayer_ctx_frame_queue (self->ctx, (int) (self->frame_no++ % MIBAYER_FRAME_QUEUES));
 
-    if (second != NULL)
-      stream = second;
+    if (fq != NULL)
+      stream = fq;
   }
   if (!gst_mi_hip_memory_order_after ((GstMiHipMemory *) in_mem, stream)
       || !gst_mi_hip_memory_order_after ((GstMiHipMemory *) out_mem, stream)) {
@@ -1498,11 +1499,11 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
           FALSE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_OVERLAP,
       g_param_spec_boolean ("overlap", "Overlap consecutive frames",
-          "Frame-by-frame mode (batch=1): deal consecutive frames alternately over "
-          "two compute queues, so that the start of frame n+1 overlaps the tail of "
-          "frame n (a one-frame launch never reaches a steady state by itself).  "
-          "Frames are handed over by per-buffer events either way; off = every "
-          "launch behind the previous one",
+          "Frame-by-frame mode (batch=1): deal consecutive frames round-robin over "
+          "four compute queues (hardware queues of their own), so that the start of "
+          "the next frames overlaps the tail of frame n (a one-frame launch never "
+          "reaches a steady state by itself).  Frames are handed over by per-buffer "
+          "events either way; off = every launch behind the previous one",
           TRUE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_PLAN,
       g_param_spec_string ("plan", "Launch plan",

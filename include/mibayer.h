@@ -56,7 +56,8 @@ extern "C" {
  * (mibayer_variant_name) rather than keeping numbers across versions. */
 /* 5: additive over 4 -- one launch plan per LAUNCH CLASS (launches of a few rounds of workgroups: one frame per
  * launch, vs. batch launches): mibayer_get_plan_for / mibayer_set_plan_for, the plan cache keyed by class;
- * mibayer_ctx_stream2 (a second compute queue of the context for independent frames), covered by mibayer_sync;
+ * mibayer_ctx_frame_queue (four compute queues per device on hardware queues of their own, for independent one-frame
+ * launches), covered by mibayer_sync;
  * mibayer_device_pci_bus_id.
  * mibayer_get_plan / mibayer_plan_source / mibayer_ctx_variant_name keep describing the batch-class plan,
  * mibayer_set_plan / mibayer_copy_plan pin every class. */
@@ -322,18 +323,22 @@ int mibayer_process_device_list (mibayer_ctx *ctx, const void *const *d_srcs,
     void *const *d_dsts, int nframes, void *hip_stream);
 /* the context's compute stream (a hipStream_t), created non-blocking */
 void *mibayer_ctx_stream (mibayer_ctx *ctx);
-/* A second compute stream, the context's own (created by the first call; NULL if that fails).  A launch over ONE frame
- * is a single round of workgroups -- ramp-up, one burst of loads, one burst of stores, drain: 4K 9.4 us against 6.5 us
- * per frame inside a batch -- so a caller that converts frame after frame (one GstBuffer at a time) and whose frames
- * do not depend on each other deals them alternately over mibayer_ctx_stream() and this stream: the ramp-up of frame
- * n+1 overlaps the drain of frame n (4K: 54.8 -> 63.4 % of HBM peak; what hipbayer2rgb does).  The two streams are
- * not ordered against each other: order consumers with events (mibayer_dev_event_record / _stream_wait_event) or
- * mibayer_sync(), which covers both. */
-void *mibayer_ctx_stream2 (mibayer_ctx *ctx);
+/* Frame queues (v5): MIBAYER_FRAME_QUEUES compute streams per DEVICE, each on a hardware queue of its own, shared by
+ * the contexts of the device, created on first use (NULL: k out of range, or no stream could be made).  A launch over
+ * ONE frame is a single round of workgroups -- ramp-up, one burst of loads, one burst of stores, drain: 4K 9.4 us
+ * against 6.5 us per frame inside a batch -- so a caller that converts frame after frame (one GstBuffer at a time) and
+ * whose frames do not depend on each other deals them round-robin over the frame queues: the ramp-up of the next
+ * frames overlaps the drain of frame n (4K: 54 % of HBM peak on one queue, 66-67 % on four; rgb2bayer 55 -> 77 %;
+ * what hipbayer2rgb / hiprgb2bayer do).  Ordinary HIP streams share a small pool of hardware queues and serialise
+ * behind each other again; these do not.  The queues are not ordered against each other or against
+ * mibayer_ctx_stream(): order consumers with events (mibayer_dev_event_record / mibayer_dev_stream_wait_event) or with
+ * mibayer_sync(), which covers every frame queue this context launched on. */
+#define MIBAYER_FRAME_QUEUES 4
+void *mibayer_ctx_frame_queue (mibayer_ctx *ctx, int k);
 /* Waits (with the context's deadline) for what THIS context has in flight: its
  * pending host-path frames and the device-resident work queued through
  * mibayer_process_device[_list] / mibayer_fill_synthetic on mibayer_ctx_stream() and
- * mibayer_process_device[_list] on mibayer_ctx_stream2().
+ * mibayer_process_device[_list] on the frame queues (mibayer_ctx_frame_queue).
  * Work a caller put on that stream by other means (its own kernels, copies) is
  * NOT covered -- the queue may be shared with the other contexts of the device --
  * and neither is work on a caller-supplied stream: synchronise those yourself. */

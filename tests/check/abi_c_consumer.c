@@ -67,14 +67,16 @@ main (void)
     }
   }
   {
-    /* ABI v5 from C: the plan of a launch class, the second compute stream */
+    /* ABI v5 from C: the plan of a launch class, the frame queues */
     int variant = -1, band = 0, align = -1, source = -1;
 
     if (mibayer_get_plan_for (ctx, 1, &variant, &band, &align, &source) != MIBAYER_OK || variant < 1
         || source != MIBAYER_PLAN_SET || mibayer_set_plan_for (ctx, 1, variant, band, align) != MIBAYER_OK
         || mibayer_get_plan_for (ctx, 0, NULL, NULL, NULL, NULL) != MIBAYER_ERR_ARG
-        || mibayer_ctx_stream2 (ctx) == NULL || mibayer_ctx_stream2 (ctx) == mibayer_ctx_stream (ctx)
-        || mibayer_ctx_stream2 (ctx) != mibayer_ctx_stream2 (ctx)) {
+        || mibayer_ctx_frame_queue (ctx, 0) == NULL || mibayer_ctx_frame_queue (ctx, 0) == mibayer_ctx_stream (ctx)
+        || mibayer_ctx_frame_queue (ctx, MIBAYER_FRAME_QUEUES - 1) == mibayer_ctx_frame_queue (ctx, 0)
+        || mibayer_ctx_frame_queue (ctx, 1) != mibayer_ctx_frame_queue (ctx, 1)
+        || mibayer_ctx_frame_queue (ctx, MIBAYER_FRAME_QUEUES) != NULL || mibayer_ctx_frame_queue (ctx, -1) != NULL) {
       fprintf (stderr, "ABI v5 calls: unexpected answer (variant %d band %d align %d source %d)\n", variant, band,
           align, source);
       return 9;

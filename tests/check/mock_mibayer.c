@@ -708,13 +708,13 @@ mibayer_ctx_stream (mibayer_ctx * c)
   return c;                     /* any non-NULL token */
 }
 
-/* the second compute queue: another token.  The double executes every queued operation in ONE global order when
- * something ordered after it completes -- a legal schedule for any number of queues as long as the element orders
- * each launch after the last access of its buffers, which is what the tests check */
+/* the frame queues: more tokens.  The double executes every queued operation in ONE global order when something
+ * ordered after it completes -- a legal schedule for any number of queues as long as the element orders each launch
+ * after the last access of its buffers, which is what the tests check */
 void *
-mibayer_ctx_stream2 (mibayer_ctx * c)
+mibayer_ctx_frame_queue (mibayer_ctx * c, int k)
 {
-  return c ? (char *) c + 1 : NULL;
+  return (c && k >= 0 && k < MIBAYER_FRAME_QUEUES) ? (char *) c + 1 + k : NULL;
 }
 
 int

@@ -502,9 +502,9 @@ def test_plan_cache_hands_the_measured_plan_to_later_contexts(gpu_pkg, oracle):
 def test_frame_class_plan_and_the_second_compute_queue(gpu_pkg, oracle):
     """Round 5: (1) a launch over ONE frame runs in the production shape whose grid needs the fewest rounds of the
     device's workgroup slots (4K: 256x32 tiles = 1020 workgroups on 1024 slots, where 1024x8 tiles need 1080), batch
-    launches keep the batch plan; the two classes give the same bytes.  (2) mibayer_ctx_stream2: independent frames
-    dealt alternately over the context's two compute queues -- what hipbayer2rgb does -- come out bit-exact, and
-    mibayer_sync covers both queues."""
+    launches keep the batch plan; the two classes give the same bytes.  (2) mibayer_ctx_frame_queue: independent frames
+    dealt round-robin over the device's four frame queues (hardware queues of their own, shared by the contexts of the
+    device) -- what hipbayer2rgb does -- come out bit-exact, and mibayer_sync covers every queue the context used."""
     w, h = 3840, 2160
     with gpu_pkg.Context(w, h, "rggb", "BGRx") as ctx:
         slots = 4 * 256
@@ -520,12 +520,16 @@ def test_frame_class_plan_and_the_second_compute_queue(gpu_pkg, oracle):
         dsts = [ctx.device_alloc(ctx.dst_bytes) for _ in range(n)]
         for f in range(n):
             ctx.to_device(srcs[f], src[f])
-        s2 = ctx.stream2
-        assert s2 and s2 != ctx.stream and ctx.stream2 == s2
+        fq = ctx.frame_queues
+        assert len(set(fq)) == gpu_pkg.FRAME_QUEUES == 4 and ctx.stream not in fq and ctx.frame_queues == fq
+        with gpu_pkg.Context(w, h, "bggr", "RGBx") as other:        # per device, not per context
+            assert other.frame_queues == fq
+        with pytest.raises(gpu_pkg.MibayerError):
+            ctx.frame_queue(4)
         for rep in range(3):
             for f in range(n):
-                ctx.process_device(srcs[f], dsts[f], 1, stream=(s2 if f & 1 else "ctx"))
-        ctx.sync()                    # both queues
+                ctx.process_device(srcs[f], dsts[f], 1, stream=fq[f % 4])
+        ctx.sync()                    # every frame queue this context launched on
         for f in range(n):
             assert np.array_equal(ctx.from_device(dsts[f], ctx.dst_bytes).reshape(want[f].shape), want[f]), f
         # the batch-class plan on the same single frames: same bytes
@@ -533,7 +537,7 @@ def test_frame_class_plan_and_the_second_compute_queue(gpu_pkg, oracle):
         assert ctx.launch_geometry(1)["tile_w"] == 1024
         for f in range(n):
             ctx.to_device(dsts[f], np.zeros(16, np.uint8))
-            ctx.process_device(srcs[f], dsts[f], 1, stream=(s2 if f & 1 else "ctx"))
+            ctx.process_device(srcs[f], dsts[f], 1, stream=fq[(f + 1) % 4])
         ctx.sync()
         for f in range(n):
             assert np.array_equal(ctx.from_device(dsts[f], ctx.dst_bytes).reshape(want[f].shape), want[f]), f

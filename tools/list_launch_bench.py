@@ -44,11 +44,15 @@ with (pkg.Context(W, H, "rggb", (1, 2, 3), flags=pkg.FLAG_RGB2BAYER) if INVERSE
         for s, d in zip(srcs, dsts):
             ctx.process_device(s, d, 1)
 
-    s2 = ctx.stream2
+    fq = ctx.frame_queues
 
-    def per_frame_two_queues():         # what hipbayer2rgb does by default (property overlap=true); ctx.sync covers both
+    def per_frame_frame_queues():       # what hipbayer2rgb does by default (property overlap=true); ctx.sync covers them
         for i, (s, d) in enumerate(zip(srcs, dsts)):
-            ctx.process_device(s, d, 1, stream=(s2 if i & 1 else "ctx"))
+            ctx.process_device(s, d, 1, stream=fq[i % len(fq)])
+
+    def per_frame_two_queues():
+        for i, (s, d) in enumerate(zip(srcs, dsts)):
+            ctx.process_device(s, d, 1, stream=fq[i & 1])
 
     def per_frame_batch_plan():         # the rounds-unaware shape of rounds 1-4 (the batch-class plan on one frame)
         for s, d in zip(srcs, dsts):
@@ -63,7 +67,8 @@ with (pkg.Context(W, H, "rggb", (1, 2, 3), flags=pkg.FLAG_RGB2BAYER) if INVERSE
     print("# direction: %s" % ("rgb2bayer (inverse)" if INVERSE else "bayer2rgb"))
     print("# 64 device-resident 4K frames per pass, wall time per pass incl. launch issue (python ctypes caller), %d passes" % REPS)
     rows = [("one launch per frame (batch=1), one queue", per_frame),
-            ("one launch per frame, alternating two queues", per_frame_two_queues)]
+            ("one launch per frame, over two of the frame queues", per_frame_two_queues),
+            ("one launch per frame, round-robin over the 4 frame queues", per_frame_frame_queues)]
     if not INVERSE:
         frame_plan, batch_plan = ctx.get_plan_for(1)[:3], ctx.get_plan_for(N)[:3]
         print("# frame-class plan %s, batch-class plan %s" % (frame_plan, batch_plan))
