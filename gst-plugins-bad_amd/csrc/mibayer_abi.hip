@@ -1151,11 +1151,19 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
       pb.band = -1;
     }
   }
+  if (f.variant == 0 && !c->inverse && !c->rows_off_sector) {
+    int kv = 0, kb = 0;
+    if (known_width_plan (f.width, &kv, &kb)) {         /* common sensor widths with a measured winner */
+      pb.var = &variant (kv);
+      pb.band = kb;
+    }
+  }
   /* One frame per launch (PLAN_FRAME): the same plan, except that for sector-aligned geometries "auto" takes the
    * shape whose grid needs the fewest rounds of workgroups (frame_class_variant) */
   c->plan[PLAN_FRAME] = pb;
   if (f.variant == 0 && !c->inverse && !c->rows_off_sector)
-    c->plan[PLAN_FRAME].var = &variant (frame_class_variant (f.width, f.height, c->num_cus * 4));
+    c->plan[PLAN_FRAME] = Plan { &variant (frame_class_variant (f.width, f.height, c->num_cus * 4)), INT32_MIN, 0,
+      MIBAYER_PLAN_DEFAULT };
   /* a plan measured earlier in this process for this geometry and launch class on this device (mibayer_autotune)
    * replaces the default */
   (void) plan_cache_load (c);

@@ -178,6 +178,8 @@ struct Variant {
 int variant_count ();
 const Variant &variant (int id);
 int resolve_variant (int id, int width);        /* 0 ("auto") -> a concrete id */
+/* batch-class default (variant id 1-3, band) of a frame width with a measured winner the rules miss; false: none */
+bool known_width_plan (int width, int *variant, int *band);
 /* "auto" for a launch of one frame: the production shape whose grid needs the fewest rounds of `slots` workgroups */
 int frame_class_variant (int width, int height, int slots);
 /* the plain-store (write-back) arm of a production shape (ids 1-3), for output rows that start off a

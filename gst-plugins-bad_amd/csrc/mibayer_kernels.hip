@@ -1078,6 +1078,38 @@ int resolve_variant (int id, int width)
   return best + 1;
 }
 
+/* Batch-class default for widths whose measured winner the rules above do not find.  Every entry beat the rule's pick
+ * by the margin noted, on two boxes in two rounds (profiles/r04_plan_sweep_530Mpix.log, r05_plan_sweep_530Mpix.log:
+ * ~530-Mpixel batches, 3 shapes x {band 1, identity}; the chunk order is left out on purpose -- whether it is fast
+ * follows the allocation, DESIGN.md section 5 -- and stays the measured plan's business).  The rules cannot see these:
+ * which block order collides in the memory channels depends on the row pitch in ways the sweeps show (3264 px in
+ * 1024x8 tiles, identity order: 69 %; 2592 px in 512x16: 71 %) but nothing here models.  Sector-aligned geometries
+ * with cfg.variant == 0 only; anything measured (mibayer_autotune, the plan cache) still overrides it. */
+bool known_width_plan (int width, int *variant, int *band)
+{
+  static const struct { int width, variant, band; } kKnown[] = {
+    { 2048, 3, 1 },     /* 256x32 band 1: 83.3 / 84.1 % against 82.3 / 82.6 (1024x8 identity) */
+    { 4096, 3, 1 },     /*                83.3 / 83.7          81.0 / 81.2                     */
+    { 8192, 3, 1 },     /*                81.9 / 82.7          81.1 / 82.0                     */
+    { 2304, 2, 0 },     /* 512x16 identity: 80.7 / 80.6 against 78.8 / 78.8 (256x32 identity)  */
+    { 3264, 2, 0 },     /*                  80.1 / 79.2          78.4 / 77.9                   */
+    { 2560, 1, 0 },     /* 1024x8 identity: 81.1 / 81.2 against 79.2 / 78.9 (512x16 identity)  */
+    { 2592, 1, 0 },     /*                  81.3 / 81.7          79.3 / 79.6 (256x32 identity) */
+    { 2688, 1, 0 },     /*                  82.4 / 82.4          77.4 / 77.5 (256x32 identity) */
+    { 4608, 1, 0 },     /*                  82.4 / 81.2          79.5 / 79.4 (512x16 identity) */
+    { 4112, 2, 1 },     /* 512x16 band 1:   79.6 / 79.9 against 77.8 / 77.0 (256x32 identity)  */
+    { 4208, 2, 1 },     /*                  78.9 / 79.8          77.1 / 77.3                   */
+    { 6000, 2, 1 },     /*                  78.0 / 77.9          76.8 / 75.4 (1024x8 band 1)   */
+  };
+  for (const auto &k : kKnown)
+    if (k.width == width) {
+      *variant = k.variant;
+      *band = k.band;
+      return true;
+    }
+  return false;
+}
+
 /* Variant 0 for a launch of ONE frame (PLAN_FRAME, mibayer_abi.hip): such a launch is a handful of rounds of
  * workgroups at most -- a 4K frame in 1024x8 tiles is 1080 workgroups on the 1024 slots of 256 CUs x 4, i.e. a second
  * round that is 5 % full -- so the shape whose grid needs the fewest rounds wins (4K: 256x32 tiles = 1020 workgroups,

@@ -543,6 +543,21 @@ def test_frame_class_plan_and_the_second_compute_queue(gpu_pkg, oracle):
             assert np.array_equal(ctx.from_device(dsts[f], ctx.dst_bytes).reshape(want[f].shape), want[f]), f
         for p in srcs + dsts:
             ctx.device_free(p)
+    # batch-class defaults of common sensor widths with a measured winner (known_width_plan, mibayer_kernels.hip);
+    # the frame class keeps its own rule, generic geometries and explicit variants are not touched
+    for (gw, gh, variant, band) in ((2688, 1520, 1, 0), (4096, 2160, 3, 1), (2304, 1296, 2, 0), (4112, 3008, 2, 1),
+                                    (3840, 2160, 1, -2 ** 31), (2690, 1520, None, None)):
+        with gpu_pkg.Context(gw, gh, "grbg", "BGRx") as c3:
+            if variant is not None:
+                assert c3.get_plan_for(4096)[:2] == (variant, band), (gw, c3.get_plan_for(4096))
+                assert c3.get_plan_for(1)[1] == -2 ** 31
+            else:
+                assert gpu_pkg.variant_names()[c3.get_plan_for(4096)[0]].endswith("_dpp")      # write-back twin
+            src = np.random.default_rng(gw).integers(0, 256, (5, gh, (gw + 3) & ~3), dtype=np.uint8)
+            assert np.array_equal(c3.process_batch_via_device(src),
+                                  oracle.bayer2rgb_batch(src, gw, "grbg", 2, 1, 0, nthreads=5)), gw
+    with gpu_pkg.Context(2688, 1520, "grbg", "BGRx", variant=3) as c4:
+        assert c4.get_plan_for(4096)[:2] == (3, -2 ** 31)
     # the rule across geometries: fewest rounds, widest tile among equals; rows of one tile keep the narrow-tile rule
     for (gw, gh, tile_w) in ((3264, 2448, 256), (7680, 4320, 512), (2592, 1944, 1024), (4096, 2160, 1024),
                              (640, 480, 1024), (1920, 1080, 1024), (500, 300, 512)):
