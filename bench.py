@@ -746,7 +746,14 @@ def run(args):
     # measured launch-plan selection (product API mibayer_autotune), once per stream context, outside
     # the timed region: MI355X boxes differ in which block->tile order streams best
     tune = {}
-    if not args.no_autotune:
+    if args.plan:
+        # an explicit plan (the profiled twin of a bench line: tools/evidence_pass.sh pins the plan the unprofiled run
+        # reported, so that the rocprofv3 --stats table's dominant kernel IS that run's kernel)
+        vname, band, align = args.plan.rsplit(":", 2)
+        for c in ctxs.values():
+            c.set_plan(pkg.variant_names().index(vname), int(band), int(align))
+        tune[ORDERS[0]] = "pinned by --plan %s" % args.plan
+    elif not args.no_autotune:
         tune[ORDERS[0]] = ctx0.autotune(d_src.data_ptr(), d_dst.data_ptr(), BATCH)
         for o in ORDERS[1:]:        # same geometry, same kernel: one plan for all four orders
             ctxs[o].copy_plan_from(ctx0)
@@ -828,6 +835,8 @@ def run(args):
                                "over ranks, no collective",
                    "kernel_variant": ctx0.variant_name, "launch_plan": ctx0.launch_geometry(BATCH),
                    "plan_source": PLAN_SOURCES[ctx0.get_plan_for(BATCH)[3]],
+                   "plan": "%s:%d:%d" % ((pkg.variant_names()[ctx0.get_plan_for(BATCH)[0]],)
+                                         + tuple(ctx0.get_plan_for(BATCH)[1:3])),
                    "autotune": tune.get(ORDERS[0], "off"), "parity": parity,
                    "control_plane": dist.get_backend() if dist is not None else "single process"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -890,6 +899,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--plan", default=None, metavar="VARIANT:BAND:ALIGN",
+                    help="pin the launch plan (as config.plan of an earlier line reports it) instead of measuring it")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed time-based GPU pre-warm before the W warm-up steps (reported as prewarm_ms)")
     ap.add_argument("--no-step-events", action="store_true",

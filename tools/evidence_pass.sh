@@ -3,7 +3,7 @@
 # own timeout so that one hung tool cannot eat the GPU budget.
 # Usage (GPU box, via gpurun): bash tools/evidence_pass.sh rNN [quick]
 set +e
-TAG=${1:-r04}
+TAG=${1:-r05}
 QUICK=$2
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
@@ -20,8 +20,18 @@ step "pytest -m gpu (lab build as the library under test)"
 MIBAYER_LIB_PATH=$R/gst-plugins-bad_amd/libmibayer_lab.so timeout 900 python -m pytest tests -m gpu -q --timeout 600 2>&1 | tail -25 | tee $O/pytest_gpu_lab.log | tail -3
 step "bench, the driver's arguments"
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 2> $O/bench.err | grep '^{' | tail -1 | tee $O/bench.json | cut -c1-400
-step "rocprofv3 --kernel-trace --stats of the same command"
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-host-path --no-traffic 2>&1 | grep -v "^W20" | tail -1 | cut -c1-300)
+PLAN=$(python -c "import json; print(json.load(open('$O/bench.json'))['config']['plan'])" 2>/dev/null)
+step "rocprofv3 --kernel-trace --stats of the same command, pinned to the plan that line ran ($PLAN)"
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-host-path --no-traffic ${PLAN:+--plan $PLAN} 2>&1 | grep -v "^W20" | tail -1 | cut -c1-300)
+step "one launch per frame: C caller, list launches, kernel traces"
+gcc -O2 -Wall -I include tools/csrc/frame_launch_bench.c -o /tmp/frame_launch_bench -Lgst-plugins-bad_amd -lmibayer -Wl,-rpath,$R/gst-plugins-bad_amd
+(for g in "3840 2160" "1920 1080" "7680 4320" "2592 1944" "4056 3040" "3838 2160"; do timeout 60 /tmp/frame_launch_bench $g; done; timeout 60 /tmp/frame_launch_bench 3840 2160 inverse) > $O/frame_launch_c.log 2>&1; grep -c "queue" $O/frame_launch_c.log
+timeout 300 python tools/list_launch_bench.py > $O/list_launch.log 2>&1; timeout 300 python tools/list_launch_bench.py inverse > $O/list_launch_inverse.log 2>&1; head -8 $O/list_launch.log | cut -c1-150
+for arm in 1:d:1 auto:d:1 auto:d:4; do
+  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/trace_$arm -o t -- python $R/tools/single_frame_bench.py trace $arm 2>&1 | grep -v "^W20" | tail -1)
+  (echo "## arm $arm (variant:band:queues)"; python tools/single_frame_bench.py gaps $O/trace_$arm) >> $O/single_frame_gaps.txt 2>&1
+done
+find $O -name "t_kernel_trace.csv" -size +3M -delete
 step "force-dist (RCCL group of one rank)"
 timeout 300 python bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-cpu --no-host-path --no-traffic 2>> $O/bench.err | grep '^{' | tail -1 > $O/bench_force_dist.json
 step "stream mode (configs[4])"
@@ -40,5 +50,18 @@ if [ -z "$QUICK" ]; then
   step "parity fuzz soak"
   MIBAYER_FUZZ_SEED=404 MIBAYER_FUZZ_CASES=1200 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k randomised 2>&1 | tail -3 | tee $O/fuzz_soak.log
   MIBAYER_LIB_PATH=$R/gst-plugins-bad_amd/libmibayer_lab.so MIBAYER_FUZZ_SEED=405 MIBAYER_FUZZ_CASES=1200 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k randomised 2>&1 | tail -3 | tee -a $O/fuzz_soak.log
+fi
+step "HBM-side traffic per block order (product build, --plan), calibration probe"
+[ -x $R/tools/hbm_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $R/tools/hbm_probe $R/tools/hbm_probe.hip
+for c in FETCH_SIZE WRITE_SIZE; do
+  for plan in band1:1 chunk:-1 identity:0; do
+    name=${plan%%:*}; band=${plan##*:}
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_bench_${name}_$c -o $TAG -- python $R/bench.py --steps 8 --warmup 2 --prewarm-ms 0 --no-cpu --no-host-path --no-traffic --plan lds_4x2_r4_dpp_nt:$band:0 2>&1 | grep -v "^W20" | tail -1 | cut -c1-120)
+  done
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_probe_$c -o $TAG -- $R/tools/hbm_probe 2 32768 2>&1 | grep -v "^W20" | tail -1)
+done
+if [ -z "$QUICK" ]; then
+  step "HBM-side traffic per geometry and plan (lab build)"
+  MIBAYER_LIB_PATH=$R/gst-plugins-bad_amd/libmibayer_lab.so timeout 1500 bash tools/geometry_counters.sh $TAG 2>&1 | tail -3
 fi
 step done; find $O -type f | wc -l

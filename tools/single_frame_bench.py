@@ -2,8 +2,9 @@
 """The launch the elements actually issue: ONE frame per launch (hipbayer2rgb batch=1, every
 mibayer_process_device(..., nframes=1) caller).  64 device-resident 4K frames, each its own allocation.
 
-  python tools/single_frame_bench.py                 table: shape x block order x number of compute queues the
-                                                     frames are dealt over (1 = every launch behind the previous one)
+  python tools/single_frame_bench.py                 table: shape x block order x number of frame queues the frames
+                                                     are dealt over (1 = the context's stream, every launch behind
+                                                     the previous one; 2-4 = mibayer_ctx_frame_queue)
   python tools/single_frame_bench.py trace ARM       a few passes of one arm, for rocprofv3 --kernel-trace
                                                      (ARM = variant:band:queues, e.g. 1:d:1; band d = the plan's default)
   python tools/single_frame_bench.py gaps DIR        kernel durations and gaps out of a rocprofv3 kernel trace
@@ -66,19 +67,15 @@ def main():
         for p in srcs:
             ctx.fill_synthetic(p, 1, seed=2)
         ctx.sync()
-        extra = [L.mibayer_dev_stream_create(0) for _ in range(3)]
-        evs = [L.mibayer_dev_event_create(0) for _ in range(3)]
+        fq = ctx.frame_queues         # hardware queues of their own (mibayer_ctx_frame_queue); ctx.sync covers them
 
         def sync_all(nq):
             ctx.sync()
-            for k in range(nq - 1):
-                L.mibayer_dev_event_record(0, ctypes.c_void_p(evs[k]), ctypes.c_void_p(extra[k]))
-                L.mibayer_dev_event_wait(0, ctypes.c_void_p(evs[k]))
 
         def one_pass(nq):
-            qs = ["ctx"] + extra[:nq - 1]
+            qs = ["ctx"] if nq == 1 else fq[:nq]
             for i, (s, d) in enumerate(zip(srcs, dsts)):
-                ctx.process_device(s, d, 1, stream=qs[i % nq])
+                ctx.process_device(s, d, 1, stream=qs[i % len(qs)])
 
         def timed(nq, reps=REPS):
             for _ in range(3):
@@ -97,12 +94,12 @@ def main():
         if len(sys.argv) > 2 and sys.argv[1] == "trace":
             v, b, nq = sys.argv[2].split(":")
             if v == "auto":
-                v = ctx.get_plan()[0]
+                v = ctx.get_plan_for(1)[0]
             ctx.set_plan(int(v), INT32_MIN if b == "d" else int(b), 0)
             t = timed(int(nq), reps=6)
             print("arm %s (%s): %.3f ms per pass of %d frames" % (sys.argv[2], ctx.variant_name, t * 1e3, N))
             return
-        v0, b0, _ = ctx.get_plan()
+        v0, b0, _, _ = ctx.get_plan_for(1)
         print("# %d device-resident %dx%d frames, ONE launch per frame, wall time per pass incl. launch issue, %d passes"
               % (N, W, H, REPS))
         print("# the context's default plan: %s band %s; grid per frame: %s" % (
