@@ -204,8 +204,12 @@ static DeviceQueues g_queues[64];
  * each other again (3 streams measured WORSE than 2).  A stream made by hipExtStreamCreateWithCUMask owns its hardware
  * queue; the mask given is "every CU" -- a lone frame still gets the whole device -- partitioning the CUs instead
  * (queue k owns the CUs with index % 4 == k) measured within a point of it.  Hardware queues are a finite resource
- * (59 of them in one process slowed every launch of that process by 2x), hence per device, shared by its contexts,
- * created on first use and released with the last context of the device. */
+ * (59 of them in one process slowed every launch of that process by 2x), hence per device and shared by its contexts.
+ * Created on first use and NEVER destroyed -- they live as long as the process, like the runtime's own queue pool:
+ * hipStreamDestroy of a CU-masked stream hangs intermittently in ROCm 7.2 (a context that made the four queues, ran
+ * one host-path frame and was destroyed hung in 8 of 24 fresh processes, in 3 of 24 with a hipStreamSynchronize before
+ * each destroy, in 0 of 24 when the queues were kept; a bare HIP program that destroys such streams with work pending:
+ * 2 of 25; profiles/r05_frame_queue_teardown.log).  Four idle hardware queues per device are what that costs. */
 struct FrameQueues {
   hipStream_t q[MIBAYER_FRAME_QUEUES] = {};
   bool tried = false;
@@ -1383,16 +1387,7 @@ extern "C" void mibayer_destroy (mibayer_ctx *c)
       }
     }
     if (c->device < 64 && c->counted && --g_cache[c->device].contexts == 0) {
-      /* the last context of the device: its frame queues go too (to the wedge registry if the device does not answer) */
-      FrameQueues &fq = g_frame_queues[c->device];
-      for (hipStream_t &st : fq.q) {
-        if (st && how == RELEASE_ORPHAN)
-          c->wedge->streams.push_back (st);
-        else if (st && !leak)
-          (void) hipStreamDestroy (st);
-        st = nullptr;
-      }
-      fq.tried = false;
+      /* the last context of the device.  (Its frame queues stay: see FrameQueues.) */
       if (!leak) {
         trim.swap (g_cache[c->device].bufs);
         g_cache[c->device].bytes = 0;

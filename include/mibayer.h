@@ -324,7 +324,8 @@ int mibayer_process_device_list (mibayer_ctx *ctx, const void *const *d_srcs,
 /* the context's compute stream (a hipStream_t), created non-blocking */
 void *mibayer_ctx_stream (mibayer_ctx *ctx);
 /* Frame queues (v5): MIBAYER_FRAME_QUEUES compute streams per DEVICE, each on a hardware queue of its own, shared by
- * the contexts of the device, created on first use (NULL: k out of range, or no stream could be made).  A launch over
+ * the contexts of the device, created on first use (NULL: k out of range, or no stream could be made) and kept for the
+ * life of the process (destroying such a stream hangs intermittently in ROCm 7.2).  A launch over
  * ONE frame is a single round of workgroups -- ramp-up, one burst of loads, one burst of stores, drain: 4K 9.4 us
  * against 6.5 us per frame inside a batch -- so a caller that converts frame after frame (one GstBuffer at a time) and
  * whose frames do not depend on each other deals them round-robin over the frame queues: the ramp-up of the next

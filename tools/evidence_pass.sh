@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end evidence pass (round 4 on): everything the round's profiles/rNN_* files come from, each step bounded by its
 # own timeout so that one hung tool cannot eat the GPU budget.
-# Usage (GPU box, via gpurun): bash tools/evidence_pass.sh rNN [quick]
+# Usage (GPU box, via gpurun): bash tools/evidence_pass.sh rNN [quick | notests]   (notests: quick, and the two pytest runs are skipped)
 set +e
 TAG=${1:-r05}
 QUICK=$2
@@ -14,10 +14,12 @@ step() { echo "== $1 ($(date +%T))"; }
 step box;    (rocm-smi --showmemorypartition --showcomputepartition --showclocks --showpower --showmaxpower --showserial 2>&1 | grep -v "^$" | head -60) > $O/box.txt
 python -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.build_hash())" > $O/build_hash.txt
 step smoke;  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/smoke.log
+if [ "$QUICK" != "notests" ]; then
 step "pytest -m gpu (product build)"
 timeout 900 python -m pytest tests -m gpu -q --timeout 600 2>&1 | tail -25 | tee $O/pytest_gpu.log | tail -3
 step "pytest -m gpu (lab build as the library under test)"
 MIBAYER_LIB_PATH=$R/gst-plugins-bad_amd/libmibayer_lab.so timeout 900 python -m pytest tests -m gpu -q --timeout 600 2>&1 | tail -25 | tee $O/pytest_gpu_lab.log | tail -3
+fi
 step "bench, the driver's arguments"
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 2> $O/bench.err | grep '^{' | tail -1 | tee $O/bench.json | cut -c1-400
 PLAN=$(python -c "import json; print(json.load(open('$O/bench.json'))['config']['plan'])" 2>/dev/null)
