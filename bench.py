@@ -362,6 +362,8 @@ def profiled_traffic(band, variant_name=None):
         plan = "band1" if band == 1 else ("chunk" if band > 1 else "identity")
         key = "%dx%dx%d/%s" % (WIDTH, HEIGHT, BATCH, plan)
         entry = (t.get("by_geometry_and_plan") or {}).get(key)
+        if t.get("build") == build_hash() and t.get("by_geometry_build") != build_hash() and plan in (t.get("plans") or {}):
+            entry = None        # the per-plan pass of the bench batch was taken on THIS build, the per-geometry one was not
         if entry is not None:
             return {"bytes": entry["hbm_bytes_per_launch"], "read_bytes": entry.get("read_bytes"),
                     "write_bytes": entry.get("write_bytes"), "key": key, "kernel": entry.get("kernel"),

@@ -786,7 +786,10 @@ typedef struct
                                    -1 = not set by anybody: on for batch >= 4, off below (HB2R_AUTOTUNE_ON) */
   gboolean tuned;               /* the context's plan has been settled: measured, or taken from the process cache */
   gint overlap;                 /* property "overlap": consecutive frames go round-robin over the device's frame queues */
-  guint frame_no;               /* frames launched one at a time so far: picks the queue */
+  guint frame_no;               /* frames dealt over the frame queues so far: picks the queue */
+  gpointer launch_ev;           /* recorded behind every frame-by-frame launch: "is the previous conversion still running?" */
+  gint launch_ev_device;
+  guint busy_run;               /* consecutive frames that arrived while the previous conversion was still running */
   gchar plan[160];              /* property "plan" (read-only): the context's launch plan and where it came from */
   gboolean prerolled;           /* a frame has left since start / flush: batching may begin */
   GQueue waiting;               /* Hb2rPair* */
@@ -841,6 +844,11 @@ G_DEFINE_TYPE (GstMiHipBayer2RGB, gst_mi_hip_bayer2rgb, GST_TYPE_BASE_TRANSFORM)
 static void
 hb2r_drop_ctx (GstMiHipBayer2RGB * self)
 {
+  if (self->launch_ev) {
+    mibayer_dev_event_destroy (self->launch_ev_device, self->launch_ev);
+    self->launch_ev = NULL;
+  }
+  self->busy_run = 0;
   if (self->ctx) {
     mibayer_destroy (self->ctx);
     self->ctx = NULL;
@@ -1245,11 +1253,22 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
    * the other queues the ramp-up of the next frames overlaps the drain of frame n (4K: 54 -> 66 % of HBM peak,
    * rgb2bayer 55 -> 77 %; profiles/r05_single_frame.md).  The frame that settles the plan (it may run
    * mibayer_autotune_list on the context's stream) stays on the context's stream. */
+  /* ... but only UNDER BACK-PRESSURE: while the previous conversion is still running when the next frame arrives
+   * (a device-resident producer that is faster than one kernel per frame).  A stream whose frames arrive slower than
+   * they are converted -- anything fed over PCIe: `hipupload ! hipbayer2rgb` is bound by the 1 B/px upload -- gains
+   * nothing from overlapping kernels that never meet, and pays for waking an idle hardware queue per frame (6050 fps
+   * on the context's stream against 4900 fps dealt over the frame queues, profiles/r05_gst_pipeline_bench.log). */
   if (self->tuned && g_atomic_int_get (&self->overlap)) {
-    gpointer fq = mibayer_ctx_frame_queue (self->ctx, (int) (self->frame_no++ % MIBAYER_FRAME_QUEUES));
+    const gboolean busy = self->launch_ev != NULL
+        && mibayer_dev_event_query (self->launch_ev_device, self->launch_ev) == 0;
 
-    if (fq != NULL)
-      stream = fq;
+    self->busy_run = busy ? self->busy_run + 1 : 0;
+    if (self->busy_run >= 2) {
+      gpointer fq = mibayer_ctx_frame_queue (self->ctx, (int) (self->frame_no++ % MIBAYER_FRAME_QUEUES));
+
+      if (fq != NULL)
+        stream = fq;
+    }
   }
   if (!gst_mi_hip_memory_order_after ((GstMiHipMemory *) in_mem, stream)
       || !gst_mi_hip_memory_order_after ((GstMiHipMemory *) out_mem, stream)) {
@@ -1271,6 +1290,17 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
           && gst_mi_hip_memory_mark_access ((GstMiHipMemory *) out_mem,
               stream)))
     rc = mibayer_sync (self->ctx);      /* no event: finish before anyone looks */
+  if (rc == MIBAYER_OK && g_atomic_int_get (&self->overlap)) {
+    if (self->launch_ev == NULL) {
+      self->launch_ev_device = self->ctx_device;
+      self->launch_ev = mibayer_dev_event_create (self->ctx_device);
+    }
+    if (self->launch_ev != NULL
+        && mibayer_dev_event_record (self->launch_ev_device, self->launch_ev, stream) != MIBAYER_OK) {
+      mibayer_dev_event_destroy (self->launch_ev_device, self->launch_ev);
+      self->launch_ev = NULL;
+    }
+  }
   if (rc != MIBAYER_OK) {
     GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
         ("%s: GPU conversion failed", HB2R_LABEL (self)),
@@ -1499,11 +1529,12 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
           FALSE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_OVERLAP,
       g_param_spec_boolean ("overlap", "Overlap consecutive frames",
-          "Frame-by-frame mode (batch=1): deal consecutive frames round-robin over "
-          "four compute queues (hardware queues of their own), so that the start of "
-          "the next frames overlaps the tail of frame n (a one-frame launch never "
-          "reaches a steady state by itself).  Frames are handed over by per-buffer "
-          "events either way; off = every launch behind the previous one",
+          "Frame-by-frame mode (batch=1): while frames arrive faster than they are "
+          "converted, deal them round-robin over four compute queues (hardware "
+          "queues of their own), so that the start of the next frames overlaps the "
+          "tail of frame n (a one-frame launch never reaches a steady state by "
+          "itself).  Frames are handed over by per-buffer events either way; off = "
+          "every launch behind the previous one",
           TRUE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_PLAN,
       g_param_spec_string ("plan", "Launch plan",
@@ -1539,6 +1570,9 @@ gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
   self->autotune = -1;
   self->overlap = 1;
   self->frame_no = 0;
+  self->launch_ev = NULL;
+  self->launch_ev_device = 0;
+  self->busy_run = 0;
   self->tuned = FALSE;
   self->plan[0] = '\0';
   self->prerolled = FALSE;

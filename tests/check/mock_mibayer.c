@@ -474,6 +474,8 @@ typedef struct
 } mock_op;
 
 static mock_op g_ops[MOCK_MAX_OPS];
+static const void *g_queues_seen[16];
+static int g_nqueues_seen;
 static uint32_t g_nops;         /* launches and asynchronous copies queued so far, in device order */
 static uint32_t g_nlaunches;    /* launches among them == stamp of the next launch */
 
@@ -607,6 +609,8 @@ mibayer_destroy (mibayer_ctx * c)
 {
   if (!c)
     return;
+  if (getenv ("MOCK_MIBAYER_LOG_QUEUES"))
+    fprintf (stderr, "mock_mibayer: device-resident launches went to %d distinct queue(s)\n", g_nqueues_seen);
   if (c->hung && !c->abandoned && c->count > 0) {
     fprintf (stderr, "mock_mibayer: destroy would block for ever on a device that never answers\n");
     abort ();
@@ -727,6 +731,13 @@ mibayer_process_device (mibayer_ctx * c, const void *d_src,
   if (!c || !d_src || !d_dst || nframes != 1)
     return MIBAYER_ERR_ARG;
   pthread_mutex_lock (&g_lock);
+  {
+    int k;                      /* which queues the element launches on (MOCK_MIBAYER_LOG_QUEUES) */
+
+    for (k = 0; k < g_nqueues_seen && g_queues_seen[k] != hip_stream; k++);
+    if (k == g_nqueues_seen && g_nqueues_seen < 16)
+      g_queues_seen[g_nqueues_seen++] = hip_stream;
+  }
   op = &g_ops[g_nops % MOCK_MAX_OPS];
   op->ctx = c;
   op->src = d_src;

@@ -291,6 +291,29 @@ def test_autotune_property_measures_once_and_later_contexts_take_the_cached_plan
         assert res.returncode == 0 and "autotune #" not in res.stdout + res.stderr, props
 
 
+def test_frames_go_over_the_frame_queues_under_back_pressure_only(rig, tmp_path):
+    """Round 5: hipbayer2rgb deals its frames round-robin over the device's four frame queues WHILE the previous
+    conversion is still running when the next frame arrives (the double's events say "not yet" once per record, i.e.
+    permanent back-pressure): the context's stream for the frames that settle the plan and detect the pressure, then
+    all four frame queues; `overlap=false` keeps every launch on the context's stream.  Every frame once, in order,
+    last-access events honoured (the double aborts on a buffer used before its launch completed)."""
+    w, h, n = 64, 48, 14
+    inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
+    frames(n, w * h, first=41).tofile(inp)
+    exe, env, _ = rig
+    for props, queues in (("", 5), ("overlap=false", 1)):
+        res = subprocess.run([exe, "convert", "hipupload ! hipbayer2rgb %s ! hipdownload" % props, B2R % ("bggr", w, h),
+                              str(inp), str(w * h), str(outp)], capture_output=True, text=True,
+                             env=dict(env, MOCK_MIBAYER_LOG_QUEUES="1"), timeout=120)
+        out = res.stdout + res.stderr
+        assert res.returncode == 0 and "AddressSanitizer" not in out, out[-3000:]
+        assert "launches went to %d distinct queue(s)" % queues in out, out[-1500:]
+        kv = dict(item.split("=") for item in res.stdout.split() if "=" in item and item.count("=") == 1)
+        assert kv["pushed"] == str(n) and kv["pulled"] == str(n)
+        _, fill = stamps(outp, n, 4 * w * h)
+        assert len(fill) == n
+
+
 def test_device_memory_rgb2bayer_shares_the_converter_logic(rig, tmp_path):
     """hiprgb2bayer = hipbayer2rgb with the pad roles swapped (a subclass whose class carries the direction): frame
     by frame and batched, every frame once, in order, mosaic-sized output, last-access events honoured."""

@@ -22,6 +22,12 @@ DEV='video/x-raw(memory:HIPMemory),format=BGRx'
 # (ten times the frames: this pipeline is fast enough for process start-up noise to matter)
 a=$(run 20 "hipupload ! hipbayer2rgb" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb" "$DEV")
 line "hipupload ! hipbayer2rgb (stays on GPU)" $a $b $((10*N))
+a=$(run 20 "hipupload ! hipbayer2rgb overlap=false" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb overlap=false" "$DEV")
+line "hipupload ! hipbayer2rgb overlap=false" $a $b $((10*N))
+a=$(run 20 "hipupload ! hipbayer2rgb" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb" "$DEV")
+line "hipupload ! hipbayer2rgb (second pass)" $a $b $((10*N))
+a=$(run 20 "hipupload ! hipbayer2rgb overlap=false" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb overlap=false" "$DEV")
+line "hipupload ! hipbayer2rgb overlap=false (2nd)" $a $b $((10*N))
 a=$(run 20 "hipupload async=false ! hipbayer2rgb" "$DEV"); b=$(run $((10*N+20)) "hipupload async=false ! hipbayer2rgb" "$DEV")
 line "hipupload async=false ! hipbayer2rgb" $a $b $((10*N))
 a=$(run 20 "hipupload ! hipbayer2rgb ! hipdownload"); b=$(run $((N+20)) "hipupload ! hipbayer2rgb ! hipdownload")

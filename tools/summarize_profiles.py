@@ -76,8 +76,9 @@ if os.path.exists(bench):
 stats = glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
-    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-host-path --no-traffic` "
-              "(the driver's arguments)", "",
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-host-path --no-traffic "
+              "--plan <config.plan of the line above>` (the driver's arguments, pinned to the plan the unprofiled line ran, so "
+              "the dominant kernel of this table IS that line's kernel)", "",
               "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---:|---:|---:|---:|---:|"]
     for r in csv.DictReader(open(stats[0])):
         lines.append("| `%s` | %s | %.0f | %s | %s | %s |" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]),
@@ -92,7 +93,7 @@ if stats:
         lines.append("Timed region only (the 20 bayer2rgb dispatches before the final parity launch = the 20 timed steps, kernel `%s`): "
                      "**avg %.0f ns**, min %d, max %d." % (timed[-1]["Kernel_Name"][:60], sum(d) / len(d), min(d), max(d)))
         lines.append("")
-    lines.append("(calls include the launches of `mibayer_autotune` -- three tile shapes x three block orders, five rounds -- and the ~150 ms time-based pre-warm; "
+    lines.append("(calls include the ~150 ms time-based pre-warm and the warm-up steps; "
                  "profiled runs clock ~2 % lower than unprofiled ones, MI355X_MICROARCH.md \"DVFS\")")
     lines.append("")
 
@@ -116,7 +117,7 @@ if plans:
     lines += ["", "=> FETCH_SIZE reports exactly 1/2 of the bytes fetched (16 B/lane and 4 B/lane loads alike; the gfx950 "
                   "correction of MI355X_MICROARCH.md \"HBM\": double it); WRITE_SIZE is exact.", "",
               "Bench kernel, timed steps only, for the three block orders `mibayer_autotune` chooses between "
-              "(forced with `MIBAYER_XCD_BAND`, `--no-autotune`):", "",
+              "(pinned with `bench.py --plan lds_4x2_r4_dpp_nt:<band>:0`, product build):", "",
               "| block order | read = FETCH_SIZE x 1024 x 2 | write = WRITE_SIZE x 1024 | total per launch | / algorithmic 2 654 208 000 |",
               "|---|---:|---:|---:|---:|"]
     out = {}
