@@ -1093,7 +1093,8 @@ bool known_width_plan (int width, int *variant, int *band)
     { 8192, 3, 1 },     /*                81.9 / 82.7          81.1 / 82.0                     */
     { 2304, 2, 0 },     /* 512x16 identity: 80.7 / 80.6 against 78.8 / 78.8 (256x32 identity)  */
     { 3264, 2, 0 },     /*                  80.1 / 79.2          78.4 / 77.9                   */
-    { 2560, 1, 0 },     /* 1024x8 identity: 81.1 / 81.2 against 79.2 / 78.9 (512x16 identity)  */
+    { 2448, 1, 0 },     /* 1024x8 identity: 79.5 / 79.8 against 77.7 / 78.3 (512x16 identity); 2448x2048: 79.1 / 76.8 */
+    { 2560, 1, 0 },     /*                  81.1 / 81.2          79.2 / 78.9                   */
     { 2592, 1, 0 },     /*                  81.3 / 81.7          79.3 / 79.6 (256x32 identity) */
     { 2688, 1, 0 },     /*                  82.4 / 82.4          77.4 / 77.5 (256x32 identity) */
     { 4608, 1, 0 },     /*                  82.4 / 81.2          79.5 / 79.4 (512x16 identity) */
