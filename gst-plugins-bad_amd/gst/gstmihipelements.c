@@ -1231,6 +1231,54 @@ hb2r_map_pair (GstMiHipBayer2RGB * self, GstBuffer * inbuf, GstBuffer * outbuf,
   return TRUE;
 }
 
+/* The compute stream of the next launch.  Frames (and list launches) are independent and every buffer is handed over
+ * by its own "last access" event, so consecutive launches may go round-robin over the device's frame queues (hardware
+ * queues of their own): a one-frame launch is a single round of workgroups, and on the other queues the ramp-up of the
+ * next launches overlaps the drain of launch n (one 4K frame per launch: 54 -> 66 % of HBM peak, rgb2bayer 55 -> 77 %;
+ * list launches of 4: 65 -> 74 %, of 16: 78 -> 81 %; profiles/r05_single_frame.md).  But only UNDER BACK-PRESSURE:
+ * while the previous conversion is still running when the next one is issued (a device-resident producer that is
+ * faster than one kernel per frame).  A stream whose frames arrive slower than they are converted -- anything fed
+ * over PCIe: `hipupload ! hipbayer2rgb` is bound by the 1 B/px upload -- gains nothing from overlapping kernels that
+ * never meet, and pays for waking an idle hardware queue per frame (6050 fps on the context's stream against 4900 fps
+ * dealt over the frame queues, profiles/r05_gst_pipeline_overlap_ab.log).  The launch that settles the plan (it may run
+ * mibayer_autotune_list on the context's stream) stays on the context's stream. */
+static gpointer
+hb2r_next_stream (GstMiHipBayer2RGB * self)
+{
+  gpointer stream = mibayer_ctx_stream (self->ctx);
+
+  if (self->tuned && g_atomic_int_get (&self->overlap)) {
+    const gboolean busy = self->launch_ev != NULL
+        && mibayer_dev_event_query (self->launch_ev_device, self->launch_ev) == 0;
+
+    self->busy_run = busy ? self->busy_run + 1 : 0;
+    if (self->busy_run >= 2) {
+      gpointer fq = mibayer_ctx_frame_queue (self->ctx, (int) (self->frame_no++ % MIBAYER_FRAME_QUEUES));
+
+      if (fq != NULL)
+        stream = fq;
+    }
+  }
+  return stream;
+}
+
+/* ... and the event that tells the next call whether this launch is still running */
+static void
+hb2r_note_launch (GstMiHipBayer2RGB * self, gpointer stream)
+{
+  if (!g_atomic_int_get (&self->overlap))
+    return;
+  if (self->launch_ev == NULL) {
+    self->launch_ev_device = self->ctx_device;
+    self->launch_ev = mibayer_dev_event_create (self->ctx_device);
+  }
+  if (self->launch_ev != NULL
+      && mibayer_dev_event_record (self->launch_ev_device, self->launch_ev, stream) != MIBAYER_OK) {
+    mibayer_dev_event_destroy (self->launch_ev_device, self->launch_ev);
+    self->launch_ev = NULL;
+  }
+}
+
 static GstFlowReturn
 hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
 {
@@ -1247,29 +1295,7 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
    * was last queued on the two memories, and both are marked with an event
    * after it.  The next user either orders its own stream after that event or
    * -- any plain map, hipdownload, a CPU map -- waits for it on the host. */
-  stream = mibayer_ctx_stream (self->ctx);
-  /* Frames are independent and each is handed over by its own events, so consecutive ones go round-robin over the
-   * device's frame queues (hardware queues of their own): a one-frame launch is a single round of workgroups, and on
-   * the other queues the ramp-up of the next frames overlaps the drain of frame n (4K: 54 -> 66 % of HBM peak,
-   * rgb2bayer 55 -> 77 %; profiles/r05_single_frame.md).  The frame that settles the plan (it may run
-   * mibayer_autotune_list on the context's stream) stays on the context's stream. */
-  /* ... but only UNDER BACK-PRESSURE: while the previous conversion is still running when the next frame arrives
-   * (a device-resident producer that is faster than one kernel per frame).  A stream whose frames arrive slower than
-   * they are converted -- anything fed over PCIe: `hipupload ! hipbayer2rgb` is bound by the 1 B/px upload -- gains
-   * nothing from overlapping kernels that never meet, and pays for waking an idle hardware queue per frame (6050 fps
-   * on the context's stream against 4900 fps dealt over the frame queues, profiles/r05_gst_pipeline_bench.log). */
-  if (self->tuned && g_atomic_int_get (&self->overlap)) {
-    const gboolean busy = self->launch_ev != NULL
-        && mibayer_dev_event_query (self->launch_ev_device, self->launch_ev) == 0;
-
-    self->busy_run = busy ? self->busy_run + 1 : 0;
-    if (self->busy_run >= 2) {
-      gpointer fq = mibayer_ctx_frame_queue (self->ctx, (int) (self->frame_no++ % MIBAYER_FRAME_QUEUES));
-
-      if (fq != NULL)
-        stream = fq;
-    }
-  }
+  stream = hb2r_next_stream (self);
   if (!gst_mi_hip_memory_order_after ((GstMiHipMemory *) in_mem, stream)
       || !gst_mi_hip_memory_order_after ((GstMiHipMemory *) out_mem, stream)) {
     /* could not order on the device: fall back to waiting on the host */
@@ -1290,17 +1316,8 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
           && gst_mi_hip_memory_mark_access ((GstMiHipMemory *) out_mem,
               stream)))
     rc = mibayer_sync (self->ctx);      /* no event: finish before anyone looks */
-  if (rc == MIBAYER_OK && g_atomic_int_get (&self->overlap)) {
-    if (self->launch_ev == NULL) {
-      self->launch_ev_device = self->ctx_device;
-      self->launch_ev = mibayer_dev_event_create (self->ctx_device);
-    }
-    if (self->launch_ev != NULL
-        && mibayer_dev_event_record (self->launch_ev_device, self->launch_ev, stream) != MIBAYER_OK) {
-      mibayer_dev_event_destroy (self->launch_ev_device, self->launch_ev);
-      self->launch_ev = NULL;
-    }
-  }
+  if (rc == MIBAYER_OK)
+    hb2r_note_launch (self, stream);
   if (rc != MIBAYER_OK) {
     GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
         ("%s: GPU conversion failed", HB2R_LABEL (self)),
@@ -1352,7 +1369,7 @@ hb2r_convert_waiting (GstMiHipBayer2RGB * self)
   }
   if (n == 0)
     return ret;
-  stream = mibayer_ctx_stream (self->ctx);
+  stream = hb2r_next_stream (self);     /* list launches, too, go over the frame queues under back-pressure */
   for (i = 0; i < n; i++) {
     if (!gst_mi_hip_memory_order_after ((GstMiHipMemory *) in_mem[i], stream)
         || !gst_mi_hip_memory_order_after ((GstMiHipMemory *) out_mem[i],
@@ -1374,6 +1391,8 @@ hb2r_convert_waiting (GstMiHipBayer2RGB * self)
         && marked;
   if (rc == MIBAYER_OK && !marked)
     rc = mibayer_sync (self->ctx);      /* no event: finish before anyone looks */
+  if (rc == MIBAYER_OK && ret == GST_FLOW_OK)
+    hb2r_note_launch (self, stream);
   if (rc != MIBAYER_OK) {
     GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
         ("%s: GPU conversion failed", HB2R_LABEL (self)),
@@ -1529,12 +1548,12 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
           FALSE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_OVERLAP,
       g_param_spec_boolean ("overlap", "Overlap consecutive frames",
-          "Frame-by-frame mode (batch=1): while frames arrive faster than they are "
-          "converted, deal them round-robin over four compute queues (hardware "
-          "queues of their own), so that the start of the next frames overlaps the "
-          "tail of frame n (a one-frame launch never reaches a steady state by "
-          "itself).  Frames are handed over by per-buffer events either way; off = "
-          "every launch behind the previous one",
+          "While frames arrive faster than they are converted, deal consecutive "
+          "launches (one frame each, or one batch each) round-robin over four compute "
+          "queues (hardware queues of their own), so that the start of the next "
+          "launches overlaps the tail of launch n (a one-frame launch never reaches "
+          "a steady state by itself).  Frames are handed over by per-buffer events "
+          "either way; off = every launch behind the previous one",
           TRUE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_PLAN,
       g_param_spec_string ("plan", "Launch plan",

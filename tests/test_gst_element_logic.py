@@ -297,11 +297,13 @@ def test_frames_go_over_the_frame_queues_under_back_pressure_only(rig, tmp_path)
     permanent back-pressure): the context's stream for the frames that settle the plan and detect the pressure, then
     all four frame queues; `overlap=false` keeps every launch on the context's stream.  Every frame once, in order,
     last-access events honoured (the double aborts on a buffer used before its launch completed)."""
-    w, h, n = 64, 48, 14
+    w, h, n = 64, 48, 22
     inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
     frames(n, w * h, first=41).tofile(inp)
     exe, env, _ = rig
-    for props, queues in (("", 5), ("overlap=false", 1)):
+    # batch=4: list launches go over the frame queues the same way (1 + 4 + 4 + 4 + 4 + 4 + 1 frames: the first three
+    # launches on the context's stream -- preroll, the batch that settles the plan, the one that detects the pressure)
+    for props, queues in (("", 5), ("overlap=false", 1), ("batch=4", 5), ("batch=4 overlap=false", 1)):
         res = subprocess.run([exe, "convert", "hipupload ! hipbayer2rgb %s ! hipdownload" % props, B2R % ("bggr", w, h),
                               str(inp), str(w * h), str(outp)], capture_output=True, text=True,
                              env=dict(env, MOCK_MIBAYER_LOG_QUEUES="1"), timeout=120)

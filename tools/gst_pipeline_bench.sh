@@ -28,6 +28,8 @@ a=$(run 20 "hipupload ! hipbayer2rgb" "$DEV"); b=$(run $((10*N+20)) "hipupload !
 line "hipupload ! hipbayer2rgb (second pass)" $a $b $((10*N))
 a=$(run 20 "hipupload ! hipbayer2rgb overlap=false" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb overlap=false" "$DEV")
 line "hipupload ! hipbayer2rgb overlap=false (2nd)" $a $b $((10*N))
+a=$(run 20 "hipupload ! hipbayer2rgb batch=8" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb batch=8" "$DEV")
+line "hipupload ! hipbayer2rgb batch=8" $a $b $((10*N))
 a=$(run 20 "hipupload async=false ! hipbayer2rgb" "$DEV"); b=$(run $((10*N+20)) "hipupload async=false ! hipbayer2rgb" "$DEV")
 line "hipupload async=false ! hipbayer2rgb" $a $b $((10*N))
 a=$(run 20 "hipupload ! hipbayer2rgb ! hipdownload"); b=$(run $((N+20)) "hipupload ! hipbayer2rgb ! hipdownload")

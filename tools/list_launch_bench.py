@@ -64,6 +64,12 @@ with (pkg.Context(W, H, "rggb", (1, 2, 3), flags=pkg.FLAG_RGB2BAYER) if INVERSE
                 ctx.process_device_list(srcs[i:i + k], dsts[i:i + k])
         return fn
 
+    def lists_fq(k):
+        def fn():
+            for j, i in enumerate(range(0, N, k)):
+                ctx.process_device_list(srcs[i:i + k], dsts[i:i + k], stream=fq[j % len(fq)])
+        return fn
+
     print("# direction: %s" % ("rgb2bayer (inverse)" if INVERSE else "bayer2rgb"))
     print("# 64 device-resident 4K frames per pass, wall time per pass incl. launch issue (python ctypes caller), %d passes" % REPS)
     rows = [("one launch per frame (batch=1), one queue", per_frame),
@@ -81,6 +87,7 @@ with (pkg.Context(W, H, "rggb", (1, 2, 3), flags=pkg.FLAG_RGB2BAYER) if INVERSE
             ctx.set_plan_for(1, *frame_plan)
     for label, fn in rows + \
                      [("list launches of %2d separately allocated frames" % k, lists(k)) for k in (2, 4, 8, 16)] + \
+                     [("list launches of %2d frames, dealt over the 4 frame queues" % k, lists_fq(k)) for k in (2, 4, 8, 16)] + \
                      [("one launch over a contiguous 64-frame batch", lambda: ctx.process_device(big_src, big_dst, N))]:
         t = timed(fn)
         print("%-56s %8.3f ms  %8.1f fps  %9.1f Mpix/s  %6.1f GB/s (%4.1f %% of 8 TB/s)" % (
