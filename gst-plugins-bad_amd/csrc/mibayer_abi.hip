@@ -2430,7 +2430,10 @@ extern "C" int mibayer_plan_from_cache (mibayer_ctx *c)
     return MIBAYER_ERR_ARG;
   if (c->band_forced || !c->align_tunable)      /* (lab builds) a plan pinned from the environment stays */
     return 0;
-  return plan_cache_load (c) ? 1 : 0;
+  if (!plan_cache_load (c))
+    return 0;
+  c->host_bands = choose_host_bands (c);        /* the frame-class tile height may have changed */
+  return 1;
 }
 
 extern "C" int mibayer_plan_source (const mibayer_ctx *c)

@@ -565,6 +565,43 @@ def test_frame_class_plan_and_the_second_compute_queue(gpu_pkg, oracle):
             assert c2.launch_geometry(1)["tile_w"] == tile_w, (gw, gh, c2.launch_geometry(1))
 
 
+def test_plan_change_on_a_host_path_context_recuts_the_bands_and_rebuilds_the_graphs(gpu_pkg, oracle):
+    """A frame-class plan that changes after the host path has run -- mibayer_set_plan[_for], the plan cache picked up
+    later, mibayer_autotune -- changes the tile height the synchronous path cuts its bands in and the kernel node of the
+    graphs captured per slot: bands are cut again and graphs of an older plan epoch rebuilt; the bytes stay the
+    oracle's in the synchronous, the queued and both hipGraph forms."""
+    w, h = 3840, 2160
+    src = oracle.fill_synthetic(w, h, 1, seed=31)[0]
+    want = oracle.bayer2rgb(src, w, "gbrg", 2, 1, 0)
+    for flags in (0, gpu_pkg.FLAG_HIPGRAPH, gpu_pkg.FLAG_HIPGRAPH | gpu_pkg.FLAG_HIPGRAPH_CHAIN):
+        with gpu_pkg.Context(w, h, "gbrg", "BGRx", inflight=2, flags=flags) as ctx:
+            assert np.array_equal(ctx.process_host(src), want), flags
+            for variant in (1, 2, 3, 1):
+                ctx.set_plan_for(1, variant, -2 ** 31)
+                assert ctx.launch_geometry(1)["tile_h"] == {1: 8, 2: 16, 3: 32}[variant]
+                assert np.array_equal(ctx.process_host(src), want), (flags, variant)
+                outs = [np.zeros_like(want) for _ in range(3)]
+                for i, o in enumerate(outs):
+                    if ctx.pending() == 2:
+                        ctx.wait()
+                    ctx.submit(src, o, tag=i + 1)
+                while ctx.pending():
+                    ctx.wait()
+                assert all(np.array_equal(o, want) for o in outs), (flags, variant)
+    # ... and through the plan cache: a context created BEFORE a measurement picks the plan up on request
+    gpu_pkg.lib().mibayer_plan_cache_clear()
+    with gpu_pkg.Context(w, h, "gbrg", "BGRx", inflight=2) as early, gpu_pkg.Context(w, h, "rggb", "BGRx") as tuner:
+        assert np.array_equal(early.process_host(src), want)
+        d_src, d_dst = tuner.device_alloc(tuner.src_bytes), tuner.device_alloc(tuner.dst_bytes)
+        tuner.to_device(d_src, src)
+        tuner.autotune(d_src, d_dst, 1)                 # the frame class of this geometry is in the cache now
+        assert early.plan_from_cache() and early.get_plan_for(1)[3] == gpu_pkg.PLAN_CACHED
+        assert np.array_equal(early.process_host(src), want)
+        tuner.device_free(d_src)
+        tuner.device_free(d_dst)
+    gpu_pkg.lib().mibayer_plan_cache_clear()
+
+
 def test_host_waits_nap_when_other_frames_are_queued(gpu_pkg, oracle):
     """VERDICT r03 #4 / ADVICE r03: a wait spins only while the frame waited for is alone in flight; with other frames
     queued behind it the thread naps (a few wake-ups per frame), so the CPU spent waiting per frame falls far below the
