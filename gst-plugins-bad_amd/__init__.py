@@ -184,6 +184,8 @@ ABI = {
     "mibayer_variant_count": (ctypes.c_int, []),
     "mibayer_variant_name": (ctypes.c_char_p, [ctypes.c_int]),
     "mibayer_auto_variant": (ctypes.c_int, [ctypes.c_int]),
+    "mibayer_frame_class_variant": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "mibayer_known_width_plan": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mibayer_ctx_variant_name": (ctypes.c_char_p, [_vp]),
     "mibayer_plan_selectors": (ctypes.c_int, [ctypes.POINTER(Cfg), ctypes.POINTER(ctypes.c_uint32 * 4),
                                               ctypes.POINTER(ctypes.c_int)]),

@@ -1449,6 +1449,25 @@ extern "C" int mibayer_auto_variant (int width)
   return resolve_variant (0, width);
 }
 
+extern "C" int mibayer_frame_class_variant (int width, int height, int compute_units)
+{
+  if (width < 1 || height < 1 || compute_units < 1)
+    return MIBAYER_ERR_ARG;
+  return frame_class_variant (width, height, compute_units * 4);
+}
+
+extern "C" int mibayer_known_width_plan (int width, int *variant, int *band)
+{
+  int v = 0, b = 0;
+  if (!known_width_plan (width, &v, &b))
+    return 0;
+  if (variant)
+    *variant = v;
+  if (band)
+    *band = b;
+  return 1;
+}
+
 extern "C" const char *mibayer_ctx_variant_name (const mibayer_ctx *c)
 {
   return c ? c->plan[PLAN_BATCH].var->name : NULL;

@@ -504,8 +504,14 @@ int mibayer_fill_synthetic (mibayer_ctx *ctx, void *d_src,
  * production tile shape chosen from the stream width at mibayer_create(). */
 int mibayer_variant_count (void);
 const char *mibayer_variant_name (int variant);
-/* the variant id "auto" (0) resolves to for a frame width (pure host arithmetic) */
+/* the variant id "auto" (0) resolves to for a frame width by the padding rule (pure host arithmetic) */
 int mibayer_auto_variant (int width);
+/* ... for a launch of ONE frame of a sector-aligned geometry on a device with `compute_units` CUs: the production shape
+ * whose grid needs the fewest rounds of the device's workgroup slots (4 per CU), the widest tile among equals (v5) */
+int mibayer_frame_class_variant (int width, int height, int compute_units);
+/* ... and the batch-class default of the common sensor widths whose measured winner the padding rule does not find:
+ * 1 and (variant, band) if `width` is one of them, else 0 (v5) */
+int mibayer_known_width_plan (int width, int *variant, int *band);
 /* name of the concrete variant the context resolved to */
 const char *mibayer_ctx_variant_name (const mibayer_ctx *ctx);
 /* Pure host arithmetic, no device needed: the four v_perm_b32 selectors (output

@@ -180,6 +180,39 @@ def test_auto_variant_minimises_wasted_lanes(pkg):
         assert names[f(w)].startswith(prefix), (w, names[f(w)])
 
 
+def test_frame_class_rule_and_known_widths(pkg):
+    """Round 5, pure host arithmetic (no device): a launch of ONE frame takes the production shape whose grid needs the
+    fewest rounds of the device's workgroup slots (256 CUs x 4), the widest tile among equals; rows that fit one tile
+    keep the narrow-tile rule; thirteen common sensor widths carry a measured batch-class default."""
+    import ctypes
+    L = pkg.lib()
+    names = pkg.variant_names()
+
+    def tiles(w, h, v):
+        tw, th = {1: (1024, 8), 2: (512, 16), 3: (256, 32)}[v]
+        return -(-w // tw) * -(-h // th)
+    want = {(3840, 2160): 3, (3264, 2448): 3, (7680, 4320): 2, (2592, 1944): 1, (4096, 2160): 1, (1920, 1080): 1,
+            (4056, 3040): 1, (640, 480): 1, (500, 300): 2, (200, 100): 3, (5120, 2880): 1}
+    for (w, h), v in want.items():
+        got = L.mibayer_frame_class_variant(w, h, 256)
+        assert got == v, (w, h, names[got])
+        if w > 1024:        # it IS the minimum number of rounds, and no wider tile reaches it
+            rounds = {k: -(-tiles(w, h, k) // 1024) for k in (1, 2, 3)}
+            assert rounds[got] == min(rounds.values()) and all(rounds[k] > rounds[got] for k in range(1, got))
+    assert tiles(3840, 2160, 1) == 1080 and tiles(3840, 2160, 3) == 1020           # the 4K case of DESIGN.md section 5
+    # another device size changes the answer: 4K on 304 CUs (1216 slots) fits 1024x8 tiles in one round
+    assert L.mibayer_frame_class_variant(3840, 2160, 304) == 1
+    assert L.mibayer_frame_class_variant(0, 10, 256) == pkg.ERR_ARG and L.mibayer_frame_class_variant(64, 48, 0) == pkg.ERR_ARG
+    v, b = ctypes.c_int(), ctypes.c_int()
+    known = {2048: (3, 1), 4096: (3, 1), 8192: (3, 1), 2304: (2, 0), 3264: (2, 0), 2448: (1, 0), 2560: (1, 0),
+             2592: (1, 0), 2688: (1, 0), 4608: (1, 0), 4112: (2, 1), 4208: (2, 1), 6000: (2, 1)}
+    for w, plan in known.items():
+        assert L.mibayer_known_width_plan(w, ctypes.byref(v), ctypes.byref(b)) == 1 and (v.value, b.value) == plan, w
+        assert L.mibayer_known_width_plan(w, None, None) == 1
+    for w in (3840, 1920, 7680, 1280, 4000, 2050):
+        assert L.mibayer_known_width_plan(w, ctypes.byref(v), ctypes.byref(b)) == 0
+
+
 def test_every_environment_knob_of_the_library_is_documented():
     """Every MIBAYER_* variable the native sources read is named in DESIGN.md, INTEGRATION.md or the ABI header: a knob
     nobody can find is not a knob.  Two lists: what the PRODUCT library reads -- operational
