@@ -92,7 +92,8 @@ def test_perf_floor_of_the_drivers_command(gpu_pkg):
     """a perf floor in the GPU suite.  The driver's exact command (--gpus 1 --steps 20 --warmup 5; the
     CPU baseline and the host-path note are left out, they do not touch the timed region): the bench kernel must stay
     at >= 78 % of the 8 TB/s HBM peak (driver runs of rounds 2-4: 0.795-0.820; the guide's achievable ceiling is
-    ~79 %), must not waste more than 6 % traffic, and the record carries ONE traffic figure.  A kernel or plan edit
+    ~79 %), must not waste more traffic than its block order implies (band 1: <= 6 %), and the record carries ONE
+    traffic figure.  A kernel or plan edit
     that costs 3 points turns this red instead of waiting for a judge."""
     best = None
     for attempt in range(2):            # a box that is still clocking up gets one more chance; a regression fails both
@@ -104,7 +105,11 @@ def test_perf_floor_of_the_drivers_command(gpu_pkg):
     r = best["roofline"]
     assert r["frac"] >= 0.78, (r["frac"], best["config"]["launch_plan"], r.get("kernel_ms_per_step"))
     assert "bit-exact" in best["config"]["parity"]
-    assert r["traffic"] is not None and r["traffic"]["ratio"] <= 1.06, r.get("traffic") or r.get("traffic_note")
+    # wasted traffic by block order: band 1 re-fetches the halo rows of a tile row through the fabric (1.05 x), the chunk
+    # order nothing (1.00 x), the identity order every halo line (1.10 x for 1024-px tiles, more for narrower ones)
+    band = int(best["config"]["plan"].rsplit(":", 2)[1])
+    ceiling = 1.06 if band == 1 else (1.01 if band < 0 else 1.16)
+    assert r["traffic"] is not None and r["traffic"]["ratio"] <= ceiling, (band, r.get("traffic") or r.get("traffic_note"))
     assert "traffic_profiled" not in r                       # one record, one traffic figure
     assert best["metric"].startswith("bayer2rgb Mpix/s @4K") and best["dtype"] == "u8" and best["n_gpus"] == 1
     assert best["config"]["plan_source"] == "measured"
