@@ -1118,9 +1118,11 @@ hb2r_autotune_once (GstMiHipBayer2RGB * self, const void *const *srcs,
   char report[1024] = "";
   int rc;
 
-  if (self->tuned || HB2R_INVERSE (self))
+  if (self->tuned)
     return;
-  self->tuned = TRUE;
+  self->tuned = TRUE;           /* from here on the launches may leave the context's stream (hb2r_next_stream) */
+  if (HB2R_INVERSE (self))
+    return;                     /* rgb2bayer has one launch shape: nothing to measure */
   {
     int src = MIBAYER_PLAN_DEFAULT;
 

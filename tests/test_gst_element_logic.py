@@ -314,6 +314,14 @@ def test_frames_go_over_the_frame_queues_under_back_pressure_only(rig, tmp_path)
         assert kv["pushed"] == str(n) and kv["pulled"] == str(n)
         _, fill = stamps(outp, n, 4 * w * h)
         assert len(fill) == n
+    # the sibling direction deals its frames the same way
+    frames(n, 4 * w * h, first=43).tofile(inp)
+    res = subprocess.run([exe, "convert", "hipupload ! hiprgb2bayer ! hipdownload", R2B % (w, h), str(inp), str(4 * w * h),
+                          str(outp)], capture_output=True, text=True, env=dict(env, MOCK_MIBAYER_LOG_QUEUES="1"),
+                         timeout=120)
+    out = res.stdout + res.stderr
+    assert res.returncode == 0 and "AddressSanitizer" not in out, out[-3000:]
+    assert "launches went to 5 distinct queue(s)" in out, out[-1500:]
 
 
 def test_device_memory_rgb2bayer_shares_the_converter_logic(rig, tmp_path):
