@@ -356,7 +356,8 @@ int mibayer_time_device (mibayer_ctx *ctx, const void *d_src,
  * and allocations -- differ in which block->tile order streams best (DESIGN.md
  * "XCD map"): this call times the candidate plans on the caller's own buffers with
  * HIP events on the context's compute stream and keeps the fastest for every later
- * launch of this context.  Candidates: the three production tile shapes x {band 1,
+ * launch of this context THAT FALLS INTO THE SAME LAUNCH CLASS as the `nframes`-frame launches it timed (v5: launch
+ * classes, below; a plan measured on 64-frame batches does not become the plan of one-frame launches).  Candidates: the three production tile shapes x {band 1,
  * one chunk per XCD, identity order}; for generic geometries whose output rows sit
  * off the 64-byte sector grid additionally x {streaming, write-back, hybrid}
  * stores, plus the shifted arm (every wave-store on a 128-byte boundary) in the two
