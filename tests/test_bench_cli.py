@@ -32,6 +32,17 @@ def test_distinct_gpu_check_refuses_ranks_that_share_a_card():
     assert bench.PLAN_SOURCES == ("default", "measured", "cached", "set")
 
 
+def test_gpu_identity_degrades_quietly_without_a_device(pkg):
+    """The identity record of a rank is best effort beyond the ordinal: no device, no bus id -- and no exception."""
+    if pkg.device_count() > 0:
+        import pytest
+        pytest.skip("a GPU is visible")
+    ident = bench.gpu_identity(pkg, 0, 3)
+    assert ident["rank"] == 3 and ident["device"] == 0 and ident["pci_bus_id"] is None and ident["host"]
+    assert pkg.device_pci_bus_id(0) is None and pkg.device_pci_bus_id(-1) is None
+    assert bench.check_distinct_gpus([ident, dict(ident, rank=4, device=1)], 2, False) == (2, None)
+
+
 def test_without_a_gpu_the_benchmark_refuses(pkg):
     if pkg.device_count() > 0:
         import pytest
