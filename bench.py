@@ -594,7 +594,11 @@ def gpu_identity(pkg, device, rank):
     node, the name and CU count the runtime reports.  Gathered into `per_gpu` so that the N > 1 line answers "did the
     ranks sit on N distinct GPUs" by itself."""
     ident = {"rank": rank, "device": device, "pci_bus_id": pkg.device_pci_bus_id(device),
-             "numa_node": pkg.lib().mibayer_device_numa_node(device), "host": os.uname().nodename}
+             "numa_node": pkg.lib().mibayer_device_numa_node(device), "host": os.uname().nodename,
+             # what this rank's ordinals are relative to (two ranks with the same mask and different ordinals sit on
+             # different cards whatever the bus ids say)
+             "visible_devices": "|".join(os.environ.get(k, "") for k in
+                                         ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))}
     try:
         import torch
         prop = torch.cuda.get_device_properties(device)
@@ -611,12 +615,26 @@ def gpu_identity(pkg, device, rank):
 def check_distinct_gpus(identities, world, share_gpu):
     """(distinct_gpus, error or None) over the ranks' (host, PCI bus id) pairs.  Two ranks on one card halve each
     other's numbers silently, so that is refused unless --share-gpu (a testing mode) says it is meant."""
-    keys = [(i.get("host"), i.get("pci_bus_id") or "ordinal-%s" % i.get("device")) for i in identities]
+    def key(i):
+        if i.get("pci_bus_id") or i.get("uuid"):
+            return (i.get("host"), i.get("pci_bus_id"), i.get("uuid"))
+        return (i.get("host"), "ordinal-%s" % i.get("device"), None)
+    keys = [key(i) for i in identities]
+    # a runtime that reports ONE bus id for several cards (some virtualised set-ups) must not stop a real multi-GPU run:
+    # ranks of one host that share one visible-device mask and have different ordinals are on different cards
+    by_ordinal = [(i.get("host"), i.get("visible_devices"), i.get("device")) for i in identities]
+
+    def mask_is_plain(i):           # no card listed twice in a device mask (HIP_VISIBLE_DEVICES=0,0 is two ordinals, one card)
+        return all(len(part.split(",")) == len(set(part.split(","))) for part in (i.get("visible_devices") or "").split("|"))
     distinct = len(set(keys))
+    if distinct < world and len(set(by_ordinal)) == world and all(mask_is_plain(i) for i in identities):
+        sys.stderr.write("bench.py: the runtime reports %d distinct bus ids / uuids for %d ranks with distinct ordinals "
+                         "under one device mask; trusting the ordinals\n" % (distinct, world))
+        distinct = world
     if distinct < world and not share_gpu:
-        dup = sorted(set(k for k in keys if keys.count(k) > 1))
+        dup = sorted(set(k for k in keys if keys.count(k) > 1), key=str)
         return distinct, ("bench.py: %d ranks but only %d distinct GPUs (shared: %s); pass --share-gpu if that is "
-                          "intended" % (world, distinct, ", ".join("%s/%s" % k for k in dup)))
+                          "intended" % (world, distinct, ", ".join("%s/%s" % (k[0], k[1] or k[2]) for k in dup)))
     return distinct, None
 
 

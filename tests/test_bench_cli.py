@@ -30,6 +30,20 @@ def test_distinct_gpu_check_refuses_ranks_that_share_a_card():
     anon = [{"rank": 0, "device": 0, "pci_bus_id": None, "host": "n0"}, {"rank": 1, "device": 1, "pci_bus_id": None, "host": "n0"}]
     assert bench.check_distinct_gpus(anon, 2, False) == (2, None)
     assert bench.PLAN_SOURCES == ("default", "measured", "cached", "set")
+    # a runtime that reports one bus id for every card: ranks with distinct ordinals under ONE device mask are trusted
+    # (a false refusal would cost the 8-GPU run); the same ordinal twice (--share-gpu's case) is still refused
+    same = [dict(ids[0], rank=r, device=r, visible_devices="") for r in range(8)]
+    assert bench.check_distinct_gpus(same, 8, False) == (8, None)
+    n, err = bench.check_distinct_gpus([dict(ids[0], visible_devices=""), dict(ids[0], rank=1, visible_devices="")], 2, False)
+    assert n == 1 and err
+    twice = [dict(ids[0], rank=r, device=r, visible_devices="0,0||") for r in range(2)]        # one card listed twice
+    n, err = bench.check_distinct_gpus(twice, 2, False)
+    assert n == 1 and err
+    # one device per rank through per-rank masks (every ordinal 0): the bus ids decide
+    masked = [dict(ids[r], device=0, visible_devices=str(r)) for r in range(4)]
+    assert bench.check_distinct_gpus(masked, 4, False) == (4, None)
+    n, err = bench.check_distinct_gpus([dict(ids[0], device=0, visible_devices="0"), dict(ids[0], rank=1, device=0, visible_devices="0")], 2, False)
+    assert n == 1 and err
 
 
 def test_gpu_identity_degrades_quietly_without_a_device(pkg):
