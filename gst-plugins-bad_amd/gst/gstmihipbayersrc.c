@@ -1,0 +1,271 @@
+/* hipbayersrc -- synthetic Bayer mosaic frames generated IN MI355X device memory (plugin `mihip`).
+ *
+ * The device-memory counterpart of `videotestsrc ! video/x-bayer`: a GstPushSrc whose buffers are GstMiHipMemory and
+ * whose content is the counter-based generator of SURVEY.md Appendix C (mibayer_fill_synthetic: byte (f, y, x) =
+ * fmix32 ((f*H*W + y*W + x) * 2654435761 + seed * 0x9E3779B9) & 0xFF), frame f = the f-th buffer.  Nothing crosses
+ * PCIe, so
+ *
+ *     hipbayersrc ! hipbayer2rgb ! <GPU consumer>
+ *
+ * is a pipeline whose producer is faster than the converter -- the case hipbayer2rgb's frame queues exist for
+ * (gstmihipelements.c: hb2r_next_stream) and that `hipupload ! hipbayer2rgb`, bound by the 1 B/px upload, can never
+ * show -- and every frame is reproducible on the host (oracle.fill_synthetic), so the pipeline is a parity test as
+ * well.  The reference has no such element (its bayer sources are videotestsrc's CPU writer and cameras); the
+ * pattern followed is a plain GstPushSrc with its own pool, as gst-plugins-base's videotestsrc.
+ */
+#ifdef HAVE_CONFIG_H
+#include "config.h"
+#endif
+
+#include <string.h>
+
+#include <gst/gst.h>
+#include <gst/base/gstpushsrc.h>
+
+#include "gstmihipmemory.h"
+#include "mibayer.h"
+
+GST_DEBUG_CATEGORY_STATIC (gst_mi_hip_bayer_src_debug);
+#define GST_CAT_DEFAULT gst_mi_hip_bayer_src_debug
+
+enum
+{
+  PROP_0,
+  PROP_DEVICE_ID,
+  PROP_SEED
+};
+
+typedef struct
+{
+  GstPushSrc parent;
+  gint device_id;
+  guint seed;
+  gint width, height;
+  gint fps_n, fps_d;
+  mibayer_ctx *ctx;             /* a bayer2rgb context of the stream geometry: it owns the generator and a stream */
+  GstBufferPool *pool;
+  guint64 n;                    /* buffers produced so far = index of the next frame */
+} GstMiHipBayerSrc;
+
+typedef struct
+{
+  GstPushSrcClass parent_class;
+} GstMiHipBayerSrcClass;
+
+GType gst_mi_hip_bayer_src_get_type (void);
+G_DEFINE_TYPE (GstMiHipBayerSrc, gst_mi_hip_bayer_src, GST_TYPE_PUSH_SRC);
+
+#define SRC_CAPS "video/x-bayer(" GST_CAPS_FEATURE_MEMORY_HIP ")" \
+  ",format=(string){bggr,grbg,gbrg,rggb}," \
+  "width=(int)[4,MAX],height=(int)[3,MAX],framerate=(fraction)[0/1,MAX]"
+
+static void
+hbs_drop (GstMiHipBayerSrc * self)
+{
+  if (self->pool) {
+    gst_buffer_pool_set_active (self->pool, FALSE);
+    gst_object_unref (self->pool);
+    self->pool = NULL;
+  }
+  if (self->ctx) {
+    mibayer_destroy (self->ctx);
+    self->ctx = NULL;
+  }
+}
+
+static GstCaps *
+hbs_fixate (GstBaseSrc * src, GstCaps * caps)
+{
+  GstStructure *s;
+
+  caps = gst_caps_make_writable (caps);
+  s = gst_caps_get_structure (caps, 0);
+  gst_structure_fixate_field_nearest_int (s, "width", 640);
+  gst_structure_fixate_field_nearest_int (s, "height", 480);
+  gst_structure_fixate_field_nearest_fraction (s, "framerate", 30, 1);
+  gst_structure_fixate_field_string (s, "format", "bggr");
+  return GST_BASE_SRC_CLASS (gst_mi_hip_bayer_src_parent_class)->fixate (src, caps);
+}
+
+static gboolean
+hbs_set_caps (GstBaseSrc * src, GstCaps * caps)
+{
+  GstMiHipBayerSrc *self = (GstMiHipBayerSrc *) src;
+  GstStructure *s = gst_caps_get_structure (caps, 0);
+  GstStructure *config;
+  mibayer_cfg cfg;
+  gint device = g_atomic_int_get (&self->device_id);
+  int rc;
+
+  hbs_drop (self);
+  if (!gst_structure_get_int (s, "width", &self->width)
+      || !gst_structure_get_int (s, "height", &self->height))
+    return FALSE;
+  if (!gst_structure_get_fraction (s, "framerate", &self->fps_n, &self->fps_d)) {
+    self->fps_n = 0;
+    self->fps_d = 1;
+  }
+  /* the generator writes the mosaic's bytes whatever the order is called: any bayer2rgb context of the geometry does */
+  memset (&cfg, 0, sizeof cfg);
+  cfg.struct_size = sizeof cfg;
+  cfg.width = self->width;
+  cfg.height = self->height;
+  cfg.pattern = MIBAYER_BGGR;
+  cfg.r_off = 0;
+  cfg.g_off = 1;
+  cfg.b_off = 2;
+  cfg.device = device;
+  rc = mibayer_create (&cfg, &self->ctx);
+  if (rc != MIBAYER_OK) {
+    GST_ELEMENT_ERROR (self, RESOURCE, NOT_FOUND,
+        ("hipbayersrc: no generator for %dx%d on HIP device %d", self->width, self->height, device),
+        ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
+    self->ctx = NULL;
+    return FALSE;
+  }
+  self->pool = gst_mi_hip_pool_new (device);
+  config = gst_buffer_pool_get_config (self->pool);
+  gst_buffer_pool_config_set_params (config, caps, (guint) ((gsize) GST_ROUND_UP_4 (self->width) * self->height), 4, 0);
+  if (!gst_buffer_pool_set_config (self->pool, config) || !gst_buffer_pool_set_active (self->pool, TRUE)) {
+    GST_ELEMENT_ERROR (self, RESOURCE, NO_SPACE_LEFT, ("hipbayersrc: no device-memory pool"), (NULL));
+    hbs_drop (self);
+    return FALSE;
+  }
+  self->n = 0;
+  return TRUE;
+}
+
+static GstFlowReturn
+hbs_create (GstPushSrc * src, GstBuffer ** out)
+{
+  GstMiHipBayerSrc *self = (GstMiHipBayerSrc *) src;
+  GstBuffer *buf = NULL;
+  GstMemory *mem;
+  GstMapInfo map;
+  GstFlowReturn ret;
+  gpointer stream;
+  int rc;
+
+  if (self->ctx == NULL || self->pool == NULL)
+    return GST_FLOW_NOT_NEGOTIATED;
+  ret = gst_buffer_pool_acquire_buffer (self->pool, &buf, NULL);
+  if (ret != GST_FLOW_OK)
+    return ret;
+  mem = gst_buffer_n_memory (buf) == 1 ? gst_buffer_peek_memory (buf, 0) : NULL;
+  if (mem == NULL || !gst_is_mi_hip_memory (mem)
+      || !gst_memory_map (mem, &map, GST_MAP_WRITE | GST_MAP_HIP | GST_MAP_HIP_ASYNC)) {
+    gst_buffer_unref (buf);
+    return GST_FLOW_ERROR;
+  }
+  /* stream-ordered like every other GPU element of the plugin: after whatever last touched this pool buffer (a
+   * consumer's kernel of four frames ago), and marked for the next user */
+  stream = mibayer_ctx_stream (self->ctx);
+  if (!gst_mi_hip_memory_order_after ((GstMiHipMemory *) mem, stream))
+    gst_mi_hip_memory_wait ((GstMiHipMemory *) mem);
+  rc = mibayer_fill_synthetic (self->ctx, map.data, 0, (uint32_t) self->n, 1, self->seed, stream);
+  if (rc == MIBAYER_OK && !gst_mi_hip_memory_mark_access ((GstMiHipMemory *) mem, stream))
+    rc = mibayer_sync (self->ctx);
+  gst_memory_unmap (mem, &map);
+  if (rc != MIBAYER_OK) {
+    GST_ELEMENT_ERROR (self, RESOURCE, FAILED, ("hipbayersrc: frame generation failed"),
+        ("%s %s", mibayer_strerror (rc), mibayer_last_hip_error ()));
+    gst_buffer_unref (buf);
+    return GST_FLOW_ERROR;
+  }
+  if (self->fps_n > 0) {
+    GST_BUFFER_PTS (buf) = gst_util_uint64_scale (self->n, (guint64) GST_SECOND * self->fps_d, self->fps_n);
+    GST_BUFFER_DURATION (buf) = gst_util_uint64_scale (1, (guint64) GST_SECOND * self->fps_d, self->fps_n);
+  } else {
+    GST_BUFFER_PTS (buf) = 0;
+    GST_BUFFER_DURATION (buf) = GST_CLOCK_TIME_NONE;
+  }
+  GST_BUFFER_OFFSET (buf) = self->n;
+  GST_BUFFER_OFFSET_END (buf) = self->n + 1;
+  self->n++;
+  *out = buf;
+  return GST_FLOW_OK;
+}
+
+static gboolean
+hbs_stop (GstBaseSrc * src)
+{
+  hbs_drop ((GstMiHipBayerSrc *) src);
+  return TRUE;
+}
+
+static void
+hbs_set_property (GObject * object, guint prop_id, const GValue * value, GParamSpec * pspec)
+{
+  GstMiHipBayerSrc *self = (GstMiHipBayerSrc *) object;
+
+  if (prop_id == PROP_DEVICE_ID)
+    g_atomic_int_set (&self->device_id, g_value_get_int (value));
+  else if (prop_id == PROP_SEED)
+    self->seed = g_value_get_uint (value);
+  else
+    G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
+}
+
+static void
+hbs_get_property (GObject * object, guint prop_id, GValue * value, GParamSpec * pspec)
+{
+  GstMiHipBayerSrc *self = (GstMiHipBayerSrc *) object;
+
+  if (prop_id == PROP_DEVICE_ID)
+    g_value_set_int (value, g_atomic_int_get (&self->device_id));
+  else if (prop_id == PROP_SEED)
+    g_value_set_uint (value, self->seed);
+  else
+    G_OBJECT_WARN_INVALID_PROPERTY_ID (object, prop_id, pspec);
+}
+
+static void
+hbs_finalize (GObject * object)
+{
+  hbs_drop ((GstMiHipBayerSrc *) object);
+  G_OBJECT_CLASS (gst_mi_hip_bayer_src_parent_class)->finalize (object);
+}
+
+static void
+gst_mi_hip_bayer_src_class_init (GstMiHipBayerSrcClass * klass)
+{
+  GObjectClass *object_class = G_OBJECT_CLASS (klass);
+  GstElementClass *element_class = GST_ELEMENT_CLASS (klass);
+  GstBaseSrcClass *basesrc_class = GST_BASE_SRC_CLASS (klass);
+  GstPushSrcClass *pushsrc_class = GST_PUSH_SRC_CLASS (klass);
+
+  GST_DEBUG_CATEGORY_INIT (gst_mi_hip_bayer_src_debug, "hipbayersrc", 0, "synthetic mosaic frames in MI355X memory");
+  object_class->set_property = hbs_set_property;
+  object_class->get_property = hbs_get_property;
+  object_class->finalize = hbs_finalize;
+  g_object_class_install_property (object_class, PROP_DEVICE_ID,
+      g_param_spec_int ("device-id", "Device ID", "HIP ordinal of the MI355X the frames are generated on",
+          0, G_MAXINT, 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (object_class, PROP_SEED,
+      g_param_spec_uint ("seed", "Seed", "Seed of the counter-based generator (SURVEY.md Appendix C)",
+          0, G_MAXUINT, 2, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  gst_element_class_add_pad_template (element_class,
+      gst_pad_template_new ("src", GST_PAD_SRC, GST_PAD_ALWAYS, gst_caps_from_string (SRC_CAPS)));
+  gst_element_class_set_static_metadata (element_class,
+      "Bayer test source (HIP device memory)", "Source/Video",
+      "Generates synthetic video/x-bayer frames in MI355X device memory", "gst-plugins-bad_amd");
+  basesrc_class->fixate = GST_DEBUG_FUNCPTR (hbs_fixate);
+  basesrc_class->set_caps = GST_DEBUG_FUNCPTR (hbs_set_caps);
+  basesrc_class->stop = GST_DEBUG_FUNCPTR (hbs_stop);
+  pushsrc_class->create = GST_DEBUG_FUNCPTR (hbs_create);
+}
+
+static void
+gst_mi_hip_bayer_src_init (GstMiHipBayerSrc * self)
+{
+  self->device_id = 0;
+  self->seed = 2;
+  self->width = self->height = 0;
+  self->fps_n = 0;
+  self->fps_d = 1;
+  self->ctx = NULL;
+  self->pool = NULL;
+  self->n = 0;
+  gst_base_src_set_format (GST_BASE_SRC (self), GST_FORMAT_TIME);
+  gst_base_src_set_live (GST_BASE_SRC (self), FALSE);
+}

@@ -4,6 +4,8 @@
  *   hipupload      video/x-raw | video/x-bayer            -> same caps (memory:HIPMemory)
  *   hipdownload    same caps (memory:HIPMemory)           -> system memory
  *   hipbayer2rgb   video/x-bayer(memory:HIPMemory)        -> video/x-raw(memory:HIPMemory)
+ *   hiprgb2bayer   video/x-raw(memory:HIPMemory), ARGB    -> video/x-bayer(memory:HIPMemory)
+ *   hipbayersrc    (gstmihipbayersrc.c) synthetic video/x-bayer(memory:HIPMemory) frames generated in device memory
  *
  * so that   ... ! hipupload ! hipbayer2rgb ! <GPU consumer>   never moves the
  * 4 B/pixel output over PCIe -- the only way a *pipeline* gets near the HBM
@@ -1645,6 +1647,8 @@ gst_mi_hip_rgb2bayer_init (GstMiHipRGB2Bayer * self)
 #define VERSION "0.1.0"
 #endif
 
+GType gst_mi_hip_bayer_src_get_type (void);    /* gstmihipbayersrc.c */
+
 static gboolean
 plugin_init (GstPlugin * plugin)
 {
@@ -1657,7 +1661,9 @@ plugin_init (GstPlugin * plugin)
       && gst_element_register (plugin, "hipbayer2rgb", GST_RANK_NONE,
       gst_mi_hip_bayer2rgb_get_type ())
       && gst_element_register (plugin, "hiprgb2bayer", GST_RANK_NONE,
-      gst_mi_hip_rgb2bayer_get_type ());
+      gst_mi_hip_rgb2bayer_get_type ())
+      && gst_element_register (plugin, "hipbayersrc", GST_RANK_NONE,
+      gst_mi_hip_bayer_src_get_type ());
 }
 
 GST_PLUGIN_DEFINE (GST_VERSION_MAJOR, GST_VERSION_MINOR, mihip,

@@ -762,6 +762,26 @@ mibayer_process_device_list (mibayer_ctx * c, const void *const *d_srcs, void *c
   return rc;
 }
 
+/* the synthetic-frame generator (hipbayersrc): queued like a launch would be too much for what the double checks --
+ * the frame is written at once, its first four bytes carry the frame number */
+int
+mibayer_fill_synthetic (mibayer_ctx * c, void *d_src, size_t src_frame_bytes, uint32_t first_frame, int nframes,
+    uint32_t seed, void *hip_stream)
+{
+  int f;
+
+  if (!c || !d_src || nframes < 0)
+    return MIBAYER_ERR_ARG;
+  for (f = 0; f < nframes; f++) {
+    uint8_t *p = (uint8_t *) d_src + (size_t) f * (src_frame_bytes ? src_frame_bytes : c->src_bytes);
+    const uint32_t stamp = first_frame + (uint32_t) f;
+
+    memset (p, (int) ((seed + stamp) & 0xff), c->src_bytes);
+    memcpy (p, &stamp, 4);
+  }
+  return MIBAYER_OK;
+}
+
 void *
 mibayer_dev_alloc (int device, size_t bytes)
 {

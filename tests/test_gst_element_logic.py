@@ -60,7 +60,7 @@ def rig(tmp_path_factory):
     cc(SAN + ["-fPIC", "-shared", '-DMI_HOST_POOL_TYPE_NAME="GstMiBayerHostPool"'] + INC + srcs
        + ["-o", os.path.join(d, "libgstbayer.so"), "-L" + d, "-lmibayer",
                                                   "-Wl,-rpath," + d] + GSTLIBS)
-    hip = [os.path.join(GSTSRC, f) for f in ("gstmihipelements.c", "gstmihipmemory.c", "gstmihostpool.c")]
+    hip = [os.path.join(GSTSRC, f) for f in ("gstmihipelements.c", "gstmihipbayersrc.c", "gstmihipmemory.c", "gstmihostpool.c")]
     cc(SAN + ["-fPIC", "-shared", '-DMI_HOST_POOL_TYPE_NAME="GstMiHipHostPool"'] + INC + hip
        + ["-o", os.path.join(d, "libgstmihip.so"), "-L" + d, "-lmibayer",
                                                  "-Wl,-rpath," + d] + GSTLIBS)
@@ -335,6 +335,25 @@ def test_device_memory_rgb2bayer_shares_the_converter_logic(rig, tmp_path):
         assert kv["pushed"] == str(n) and kv["pulled"] == str(n), launch
         seq, fill = stamps(outp, n, 132 * h)
         assert fill == list(range(70, 70 + n)) and seq == list(range(n)), launch
+
+
+def test_device_resident_source_feeds_the_converters(rig, tmp_path):
+    """hipbayersrc (round 5): synthetic mosaic frames generated in device memory -- a producer that is faster than the
+    converter, nothing over PCIe.  Over the double under ASan: state cycles of `hipbayersrc ! hipbayer2rgb !
+    hipdownload` (pool, context and last-access events set up and torn down every cycle), caps fixation (640x480 bggr
+    when nothing is asked for), explicit geometries, batch mode and the sibling converter behind it.  (What the frames
+    hold is checked on the GPU against the oracle's generator: tests/test_gst_hipmemory.py.)"""
+    w, h, n = 64, 48, 9
+    kv = run(rig, "states", "hipbayersrc num-buffers=%d ! hipbayer2rgb ! queue ! hipdownload ! fakesink" % n, 3)
+    assert kv["cycles_ok"] == "3"
+    kv = run(rig, "states", "hipbayersrc num-buffers=%d ! video/x-bayer(memory:HIPMemory),format=rggb,width=%d,height=%d,"
+             "framerate=60/1 ! hipbayer2rgb batch=4 ! hiprgb2bayer ! hipdownload ! fakesink" % (n, w, h), 2)
+    assert kv["cycles_ok"] == "2"
+    exe, env, _ = rig
+    res = subprocess.run([exe, "states", "hipbayersrc num-buffers=2 ! video/x-bayer(memory:HIPMemory),width=64,height=48,"
+                          "format=bggr ! hipbayer2rgb ! video/x-raw(memory:HIPMemory),format=BGRx ! hipdownload ! fakesink",
+                          "1"], capture_output=True, text=True, env=env, timeout=60)
+    assert res.returncode == 0 and "cycles_ok=1" in res.stdout, (res.stdout + res.stderr)[-2000:]
 
 
 def test_state_cycles(rig):

@@ -22,7 +22,7 @@ def launch(tmp, pipeline, debug=None):
 def test_mihip_plugin_registers_three_elements(plugin, tmp_path):
     out = subprocess.run([GST_INSPECT, "mihip"], capture_output=True, text=True, env=gst_env(tmp_path),
                          timeout=120).stdout
-    for name in ("hipupload", "hipdownload", "hipbayer2rgb", "hiprgb2bayer"):
+    for name in ("hipupload", "hipdownload", "hipbayer2rgb", "hiprgb2bayer", "hipbayersrc"):
         assert name + ":" in out
     out = subprocess.run([GST_INSPECT, "hiprgb2bayer"], capture_output=True, text=True, env=gst_env(tmp_path),
                          timeout=120).stdout
@@ -51,6 +51,31 @@ def test_upload_convert_download_pipeline(plugin, gpu_pkg, oracle, tmp_path):
     got = np.fromfile(outp, np.uint8).reshape(n, h, 4 * w)
     want = oracle.bayer2rgb_batch(src, w, "rggb", 2, 1, 0, nthreads=2)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("props", ["", "overlap=false", "batch=4"])
+def test_device_resident_source_is_the_oracles_generator_and_converts_bit_exactly(plugin, gpu_pkg, oracle, tmp_path, props):
+    """hipbayersrc (round 5): mosaic frames generated IN device memory by the Appendix C generator -- frame f of the
+    stream is oracle.fill_synthetic(..., first_frame=f) byte for byte -- and converted without ever leaving HBM until
+    the final download: a producer faster than the converter, so hipbayer2rgb's frame queues engage (default), stay
+    out (overlap=false) or carry list launches (batch=4); every frame once, in order, the oracle's bytes."""
+    w, h, n = 1920, 1080, 12
+    mosaic, rgb = str(tmp_path / "mosaic.raw"), str(tmp_path / "rgb.raw")
+    res = launch(tmp_path,
+                 "hipbayersrc num-buffers=%d seed=7 ! video/x-bayer(memory:HIPMemory),format=grbg,width=%d,height=%d,"
+                 "framerate=30/1 ! tee name=t t. ! queue ! hipdownload ! filesink location=%s "
+                 "t. ! queue ! hipbayer2rgb %s ! hipdownload ! video/x-raw,format=xBGR ! filesink location=%s"
+                 % (n, w, h, mosaic, props, rgb))
+    assert res.returncode == 0, res.stderr[-3000:]
+    src = np.fromfile(mosaic, np.uint8).reshape(n, h, w)
+    assert np.array_equal(src, oracle.fill_synthetic(w, h, n, seed=7))
+    got = np.fromfile(rgb, np.uint8).reshape(n, h, 4 * w)
+    assert np.array_equal(got, oracle.bayer2rgb_batch(src, w, "grbg", 3, 2, 1, nthreads=4))
+    # nothing asked for: 640x480 bggr, as videotestsrc fixates small
+    res = launch(tmp_path, "hipbayersrc num-buffers=2 ! hipdownload ! filesink location=%s" % mosaic)
+    assert res.returncode == 0 and os.path.getsize(mosaic) == 2 * 640 * 480, res.stderr[-2000:]
+    assert np.array_equal(np.fromfile(mosaic, np.uint8).reshape(2, 480, 640), oracle.fill_synthetic(640, 480, 2, seed=2))
 
 
 @pytest.mark.gpu
