@@ -1239,7 +1239,12 @@ hb2r_map_pair (GstMiHipBayer2RGB * self, GstBuffer * inbuf, GstBuffer * outbuf,
  * by its own "last access" event, so consecutive launches may go round-robin over the device's frame queues (hardware
  * queues of their own): a one-frame launch is a single round of workgroups, and on the other queues the ramp-up of the
  * next launches overlaps the drain of launch n (one 4K frame per launch: 54 -> 66 % of HBM peak, rgb2bayer 55 -> 77 %;
- * list launches of 4: 65 -> 74 %, of 16: 78 -> 81 %; profiles/r05_single_frame.md).  But only UNDER BACK-PRESSURE:
+ * list launches of 4: 65 -> 74 %, of 16: 78 -> 81 %; profiles/r05_single_frame.md) -- property `overlap`, OFF BY
+ * DEFAULT: those figures are launches without dependencies; in a pipeline every frame waits for an event of its
+ * producer's queue and is waited for by its consumer's, and with the frame queues these become cross-queue
+ * dependencies per frame where on the device's one shared compute queue they are plain stream order (4K frames from
+ * hipbayersrc: 14.5 k fps with the frame queues, 36 k fps without; 1080p 11.6 k vs 53 k; profiles/
+ * r05_gst_device_source.log).  When it is on, it acts only UNDER BACK-PRESSURE:
  * while the previous conversion is still running when the next one is issued (a device-resident producer that is
  * faster than one kernel per frame).  A stream whose frames arrive slower than they are converted -- anything fed
  * over PCIe: `hipupload ! hipbayer2rgb` is bound by the 1 B/px upload -- gains nothing from overlapping kernels that
@@ -1557,8 +1562,12 @@ gst_mi_hip_bayer2rgb_class_init (GstMiHipBayer2RGBClass * klass)
           "queues (hardware queues of their own), so that the start of the next "
           "launches overlaps the tail of launch n (a one-frame launch never reaches "
           "a steady state by itself).  Frames are handed over by per-buffer events "
-          "either way; off = every launch behind the previous one",
-          TRUE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+          "either way; off (the default) = every launch behind the previous one on "
+          "the device's shared compute queue.  Off by default because every frame of "
+          "an element has dependencies on other queues (its producer's and its "
+          "consumer's events), and those cost more than the overlap gains: 4K from a "
+          "device-resident source 14.5 k fps with, 36 k fps without",
+          FALSE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (object_class, PROP_PLAN,
       g_param_spec_string ("plan", "Launch plan",
           "The launch plan of the current stream and where it came from "
@@ -1591,7 +1600,7 @@ gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
   self->out_pool_device = 0;
   self->batch = 1;
   self->autotune = -1;
-  self->overlap = 1;
+  self->overlap = 0;
   self->frame_no = 0;
   self->launch_ev = NULL;
   self->launch_ev_device = 0;

@@ -150,7 +150,11 @@ gst_mi_hip_memory_order_after (GstMiHipMemory * m, gpointer hip_stream)
   gboolean ok = TRUE;
 
   g_mutex_lock (&m->lock);
-  if (m->access_pending)
+  /* Work queued on the stream the last access was queued on runs after it anyway (a stream is in order): no
+   * cross-queue wait to insert.  In a device-resident pipeline every element's context launches on the device's ONE
+   * shared compute queue, so this is the common case, and it saves two runtime calls per frame (hipbayersrc !
+   * hipbayer2rgb at 4K: 33.7 k -> see profiles/r05_gst_device_source.log). */
+  if (m->access_pending && !(hip_stream != NULL && m->access_stream == hip_stream))
     ok = mibayer_dev_stream_wait_event (m->device, hip_stream,
         m->access_event) == MIBAYER_OK;
   g_mutex_unlock (&m->lock);
@@ -168,8 +172,10 @@ gst_mi_hip_memory_mark_access (GstMiHipMemory * m, gpointer hip_stream)
   ok = m->access_event != NULL
       && mibayer_dev_event_record (m->device, m->access_event,
       hip_stream) == MIBAYER_OK;
-  if (ok)
+  if (ok) {
     m->access_pending = TRUE;
+    m->access_stream = hip_stream;
+  }
   m->device_defined = TRUE;
   g_mutex_unlock (&m->lock);
   return ok;

@@ -39,6 +39,8 @@ struct _GstMiHipMemory
                                    WRITE-only CPU map must start from it, not from a stale mirror */
   gpointer access_event;        /* HIP event of the last GPU access queued on this memory, created on first use */
   gboolean access_pending;      /* that event has not been waited for on the host yet */
+  gpointer access_stream;       /* the stream that event was recorded on: a user on the SAME stream is ordered after
+                                   the access by the stream itself and needs no wait (round 5) */
 };
 
 GType gst_mi_hip_allocator_get_type (void);

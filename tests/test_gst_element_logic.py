@@ -292,10 +292,11 @@ def test_autotune_property_measures_once_and_later_contexts_take_the_cached_plan
 
 
 def test_frames_go_over_the_frame_queues_under_back_pressure_only(rig, tmp_path):
-    """Round 5: hipbayer2rgb deals its frames round-robin over the device's four frame queues WHILE the previous
+    """Round 5: with `overlap=true` (off by default: in a pipeline the per-frame cross-queue dependencies cost more than
+    the overlap gains) hipbayer2rgb deals its frames round-robin over the device's four frame queues WHILE the previous
     conversion is still running when the next frame arrives (the double's events say "not yet" once per record, i.e.
     permanent back-pressure): the context's stream for the frames that settle the plan and detect the pressure, then
-    all four frame queues; `overlap=false` keeps every launch on the context's stream.  Every frame once, in order,
+    all four frame queues; without the property every launch stays on the context's stream.  Every frame once, in order,
     last-access events honoured (the double aborts on a buffer used before its launch completed)."""
     w, h, n = 64, 48, 22
     inp, outp = tmp_path / "in.raw", tmp_path / "out.raw"
@@ -303,7 +304,7 @@ def test_frames_go_over_the_frame_queues_under_back_pressure_only(rig, tmp_path)
     exe, env, _ = rig
     # batch=4: list launches go over the frame queues the same way (1 + 4 + 4 + 4 + 4 + 4 + 1 frames: the first three
     # launches on the context's stream -- preroll, the batch that settles the plan, the one that detects the pressure)
-    for props, queues in (("", 5), ("overlap=false", 1), ("batch=4", 5), ("batch=4 overlap=false", 1)):
+    for props, queues in (("overlap=true", 5), ("", 1), ("overlap=false", 1), ("batch=4 overlap=true", 5), ("batch=4", 1)):
         res = subprocess.run([exe, "convert", "hipupload ! hipbayer2rgb %s ! hipdownload" % props, B2R % ("bggr", w, h),
                               str(inp), str(w * h), str(outp)], capture_output=True, text=True,
                              env=dict(env, MOCK_MIBAYER_LOG_QUEUES="1"), timeout=120)
@@ -316,7 +317,7 @@ def test_frames_go_over_the_frame_queues_under_back_pressure_only(rig, tmp_path)
         assert len(fill) == n
     # the sibling direction deals its frames the same way
     frames(n, 4 * w * h, first=43).tofile(inp)
-    res = subprocess.run([exe, "convert", "hipupload ! hiprgb2bayer ! hipdownload", R2B % (w, h), str(inp), str(4 * w * h),
+    res = subprocess.run([exe, "convert", "hipupload ! hiprgb2bayer overlap=true ! hipdownload", R2B % (w, h), str(inp), str(4 * w * h),
                           str(outp)], capture_output=True, text=True, env=dict(env, MOCK_MIBAYER_LOG_QUEUES="1"),
                          timeout=120)
     out = res.stdout + res.stderr

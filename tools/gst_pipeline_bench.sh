@@ -30,7 +30,7 @@ line_dev () {  # label, elapsed(200 frames), elapsed(n+200 frames), n, width, he
 }
 for geo in "3840 2160 40000" "7680 4320 10000" "1920 1080 40000"; do
   set -- $geo
-  for conv in "hipbayer2rgb" "hipbayer2rgb overlap=false" "hipbayer2rgb batch=4" "hipbayer2rgb batch=16"; do
+  for conv in "hipbayer2rgb" "hipbayer2rgb overlap=true" "hipbayer2rgb batch=4" "hipbayer2rgb batch=16" "hipbayer2rgb batch=16 overlap=true"; do
     a=$(run_dev 200 $1 $2 "$conv"); b=$(run_dev $(($3+200)) $1 $2 "$conv")
     line_dev "hipbayersrc $1x$2 ! $conv" $a $b $3 $1 $2
   done
@@ -43,12 +43,8 @@ DEV='video/x-raw(memory:HIPMemory),format=BGRx'
 # (ten times the frames: this pipeline is fast enough for process start-up noise to matter)
 a=$(run 20 "hipupload ! hipbayer2rgb" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb" "$DEV")
 line "hipupload ! hipbayer2rgb (stays on GPU)" $a $b $((10*N))
-a=$(run 20 "hipupload ! hipbayer2rgb overlap=false" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb overlap=false" "$DEV")
-line "hipupload ! hipbayer2rgb overlap=false" $a $b $((10*N))
-a=$(run 20 "hipupload ! hipbayer2rgb" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb" "$DEV")
-line "hipupload ! hipbayer2rgb (second pass)" $a $b $((10*N))
-a=$(run 20 "hipupload ! hipbayer2rgb overlap=false" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb overlap=false" "$DEV")
-line "hipupload ! hipbayer2rgb overlap=false (2nd)" $a $b $((10*N))
+a=$(run 20 "hipupload ! hipbayer2rgb overlap=true" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb overlap=true" "$DEV")
+line "hipupload ! hipbayer2rgb overlap=true" $a $b $((10*N))
 a=$(run 20 "hipupload ! hipbayer2rgb batch=8" "$DEV"); b=$(run $((10*N+20)) "hipupload ! hipbayer2rgb batch=8" "$DEV")
 line "hipupload ! hipbayer2rgb batch=8" $a $b $((10*N))
 a=$(run 20 "hipupload async=false ! hipbayer2rgb" "$DEV"); b=$(run $((10*N+20)) "hipupload async=false ! hipbayer2rgb" "$DEV")
