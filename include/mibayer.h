@@ -329,8 +329,11 @@ void *mibayer_ctx_stream (mibayer_ctx *ctx);
  * ONE frame is a single round of workgroups -- ramp-up, one burst of loads, one burst of stores, drain: 4K 9.4 us
  * against 6.5 us per frame inside a batch -- so a caller that converts frame after frame (one GstBuffer at a time) and
  * whose frames do not depend on each other deals them round-robin over the frame queues: the ramp-up of the next
- * frames overlaps the drain of frame n (4K: 54 % of HBM peak on one queue, 66-67 % on four; rgb2bayer 55 -> 77 %;
- * what hipbayer2rgb / hiprgb2bayer do).  Ordinary HIP streams share a small pool of hardware queues and serialise
+ * frames overlaps the drain of frame n (4K: 54 % of HBM peak on one queue, 66-67 % on four; rgb2bayer 55 -> 77 %).
+ * That is for launches WITHOUT per-frame dependencies on other queues: a frame that must wait for an event of its
+ * producer's queue and is waited for by its consumer's pays more for the cross-queue dependencies than the overlap
+ * gains (hipbayer2rgb from a device-resident source: 14.5 k fps with the frame queues, 36 k without -- the elements'
+ * `overlap` property is therefore off by default).  Ordinary HIP streams share a small pool of hardware queues and serialise
  * behind each other again; these do not.  The queues are not ordered against each other or against
  * mibayer_ctx_stream(): order consumers with events (mibayer_dev_event_record / mibayer_dev_stream_wait_event) or with
  * mibayer_sync(), which covers every frame queue this context launched on. */
