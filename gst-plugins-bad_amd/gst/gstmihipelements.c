@@ -229,7 +229,7 @@ xfer_drop_stream (GstMiHipXfer * self)
 {
   xfer_reap_uploads (self, TRUE, 0);
   if (self->stream) {
-    mibayer_dev_stream_destroy (self->stream_device, self->stream);
+    gst_mi_hip_stream_destroy (self->stream_device, self->stream);      /* synchronises; retires the stream's timeline */
     self->stream = NULL;
   }
 }
@@ -290,7 +290,7 @@ xfer_upload_async (GstMiHipXfer * self, GstBuffer * inbuf, GstMemory * dev_mem)
       || mibayer_dev_event_record (m->device, p->event,
           self->stream) != MIBAYER_OK) {
     /* no event to defer on: finish now */
-    mibayer_dev_stream_destroy (m->device, self->stream);       /* synchronises */
+    gst_mi_hip_stream_destroy (m->device, self->stream);        /* synchronises */
     self->stream = NULL;
     gst_memory_unmap (dev_mem, &dev_map);
     gst_buffer_unmap (inbuf, &p->map);
@@ -384,7 +384,7 @@ xfer_download_async (GstMiHipXfer * self, GstBuffer * inbuf, GstBuffer * outbuf)
       || mibayer_dev_event_record (m->device, p->event,
           self->stream) != MIBAYER_OK) {
     /* whatever was queued must not outlive this call */
-    mibayer_dev_stream_destroy (m->device, self->stream);       /* synchronises */
+    gst_mi_hip_stream_destroy (m->device, self->stream);        /* synchronises */
     self->stream = NULL;
     gst_memory_unmap (dev_mem, &dev_map);
     gst_buffer_unmap (outbuf, &p->map);
@@ -779,6 +779,7 @@ typedef struct
   gint device_id;               /* properties device-id / batch: g_atomic_int_*; -1 = follow the frames */
   mibayer_ctx *ctx;             /* created at the first buffer, on the device its memory lives on */
   gint ctx_device;              /* the device the context was created on */
+  GstMiHipTimeline *tl;         /* the timeline of the context's stream: every launch marks its buffers on it */
   GstBufferPool *out_pool;      /* output frames, on the same device */
   gint out_pool_device;
   /* batch mode (property "batch" > 1): input / output buffer pairs waiting for ONE launch over all of
@@ -852,6 +853,17 @@ hb2r_drop_ctx (GstMiHipBayer2RGB * self)
   }
   self->busy_run = 0;
   if (self->ctx) {
+    /* Nothing this element marked may ask the context's stream for a fence once the context (and, if it was the last
+     * one on the device, the stream) is gone: wait for what the context queued -- microseconds of kernels -- and tell
+     * the timeline how far that was.  (Rounds 2-5 had an event per memory instead, which outlived the stream.) */
+    if (self->tl != NULL) {
+      const guint64 upto = gst_mi_hip_timeline_submitted (self->tl);
+
+      if (mibayer_sync (self->ctx) == MIBAYER_OK)
+        gst_mi_hip_timeline_settle (self->tl, upto);
+      gst_mi_hip_timeline_unref (self->tl);
+      self->tl = NULL;
+    }
     mibayer_destroy (self->ctx);
     self->ctx = NULL;
   }
@@ -1101,6 +1113,7 @@ hb2r_ensure_ctx (GstMiHipBayer2RGB * self, gint device)
     return FALSE;
   }
   self->ctx_device = device;
+  self->tl = gst_mi_hip_timeline_for (device, mibayer_ctx_stream (self->ctx));
   self->tuned = FALSE;
   hb2r_note_plan (self);
   return TRUE;
@@ -1118,6 +1131,7 @@ hb2r_autotune_once (GstMiHipBayer2RGB * self, const void *const *srcs,
     void *const *dsts, guint n)
 {
   char report[1024] = "";
+  int src = MIBAYER_PLAN_DEFAULT;
   int rc;
 
   if (self->tuned)
@@ -1125,16 +1139,18 @@ hb2r_autotune_once (GstMiHipBayer2RGB * self, const void *const *srcs,
   self->tuned = TRUE;           /* from here on the launches may leave the context's stream (hb2r_next_stream) */
   if (HB2R_INVERSE (self))
     return;                     /* rgb2bayer has one launch shape: nothing to measure */
-  {
-    int src = MIBAYER_PLAN_DEFAULT;
-
-    (void) mibayer_get_plan_for (self->ctx, (int) n, NULL, NULL, NULL, &src);
-    if (src != MIBAYER_PLAN_DEFAULT)
-      return;                   /* the process cache had a plan for this launch class when the context was created */
-  }
+  (void) mibayer_get_plan_for (self->ctx, (int) n, NULL, NULL, NULL, &src);
+  if (src != MIBAYER_PLAN_DEFAULT)
+    return;                     /* the process cache had a plan for this launch class when the context was created */
   if (mibayer_plan_from_cache (self->ctx) == 1) {
-    hb2r_note_plan (self);      /* ... or has one now: another element measured since */
-    return;
+    /* ... or has one now: another element measured since.  The cache is keyed by launch class and reports a hit for
+     * EITHER class: only a plan for the class THIS element launches settles the matter -- a batch=16
+     * element's measurement says nothing about one frame per launch, and the other way round. */
+    (void) mibayer_get_plan_for (self->ctx, (int) n, NULL, NULL, NULL, &src);
+    if (src != MIBAYER_PLAN_DEFAULT) {
+      hb2r_note_plan (self);
+      return;
+    }
   }
   if (!HB2R_AUTOTUNE_ON (self))
     return;                     /* nobody asked, and not a batch mode that measures by default */
@@ -1295,18 +1311,24 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
   GstMemory *in_mem, *out_mem;
   GstMapInfo in_map, out_map;
   GstFlowReturn ret = GST_FLOW_OK;
+  GstMiHipTimeline *tl;
   gpointer stream;
   int rc;
 
   if (!hb2r_map_pair (self, inbuf, outbuf, &in_mem, &out_mem, &in_map, &out_map))
     return GST_FLOW_ERROR;
-  /* Stream-ordered, no host round trip: the launch is ordered after whatever
-   * was last queued on the two memories, and both are marked with an event
-   * after it.  The next user either orders its own stream after that event or
-   * -- any plain map, hipdownload, a CPU map -- waits for it on the host. */
+  /* Stream-ordered, no host round trip and -- on the context's own stream, the default -- no runtime call besides the
+   * launch: the launch is ordered after whatever was last queued on the two memories (nothing to do when that was
+   * queued on this stream too), and both are marked on the stream's timeline after it (a counter, gstmihipmemory.h).
+   * The next user either orders its own stream after that access or -- any plain map, hipdownload, a CPU map --
+   * waits for it on the host; the fence is recorded then, by them. */
   stream = hb2r_next_stream (self);
-  if (!gst_mi_hip_memory_order_after ((GstMiHipMemory *) in_mem, stream)
-      || !gst_mi_hip_memory_order_after ((GstMiHipMemory *) out_mem, stream)) {
+  tl = stream == mibayer_ctx_stream (self->ctx) ? self->tl : NULL;
+  if (!(tl ? gst_mi_hip_memory_order_after_tl ((GstMiHipMemory *) in_mem, tl)
+          && gst_mi_hip_memory_order_after_tl ((GstMiHipMemory *) out_mem, tl)
+          : gst_mi_hip_memory_order_after ((GstMiHipMemory *) in_mem, stream)
+          && gst_mi_hip_memory_order_after ((GstMiHipMemory *) out_mem,
+              stream))) {
     /* could not order on the device: fall back to waiting on the host */
     gst_mi_hip_memory_wait ((GstMiHipMemory *) in_mem);
     gst_mi_hip_memory_wait ((GstMiHipMemory *) out_mem);
@@ -1320,13 +1342,16 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
   /* device-resident call: no PCIe traffic at all */
   rc = mibayer_process_device (self->ctx, in_map.data, 0, out_map.data, 0, 1,
       stream);
-  if (rc == MIBAYER_OK
-      && !(gst_mi_hip_memory_mark_access ((GstMiHipMemory *) in_mem, stream)
-          && gst_mi_hip_memory_mark_access ((GstMiHipMemory *) out_mem,
-              stream)))
-    rc = mibayer_sync (self->ctx);      /* no event: finish before anyone looks */
-  if (rc == MIBAYER_OK)
+  if (rc == MIBAYER_OK) {
+    if (tl) {
+      gst_mi_hip_memory_mark_access_tl ((GstMiHipMemory *) in_mem, tl);
+      gst_mi_hip_memory_mark_access_tl ((GstMiHipMemory *) out_mem, tl);
+    } else {
+      gst_mi_hip_memory_mark_access ((GstMiHipMemory *) in_mem, stream);
+      gst_mi_hip_memory_mark_access ((GstMiHipMemory *) out_mem, stream);
+    }
     hb2r_note_launch (self, stream);
+  }
   if (rc != MIBAYER_OK) {
     GST_ELEMENT_ERROR (self, RESOURCE, FAILED,
         ("%s: GPU conversion failed", HB2R_LABEL (self)),
@@ -1358,8 +1383,8 @@ hb2r_convert_waiting (GstMiHipBayer2RGB * self)
   GstMapInfo in_map[HB2R_MAX_BATCH], out_map[HB2R_MAX_BATCH];
   Hb2rPair *pairs[HB2R_MAX_BATCH];
   GstFlowReturn ret = GST_FLOW_OK;
+  GstMiHipTimeline *tl;
   gpointer stream;
-  gboolean marked = TRUE;
   guint n = 0, i;
   int rc;
 
@@ -1379,10 +1404,10 @@ hb2r_convert_waiting (GstMiHipBayer2RGB * self)
   if (n == 0)
     return ret;
   stream = hb2r_next_stream (self);     /* list launches, too, go over the frame queues under back-pressure */
+  tl = gst_mi_hip_timeline_for (self->ctx_device, stream);       /* one look-up per launch */
   for (i = 0; i < n; i++) {
-    if (!gst_mi_hip_memory_order_after ((GstMiHipMemory *) in_mem[i], stream)
-        || !gst_mi_hip_memory_order_after ((GstMiHipMemory *) out_mem[i],
-            stream)) {
+    if (!gst_mi_hip_memory_order_after_tl ((GstMiHipMemory *) in_mem[i], tl)
+        || !gst_mi_hip_memory_order_after_tl ((GstMiHipMemory *) out_mem[i], tl)) {
       gst_mi_hip_memory_wait ((GstMiHipMemory *) in_mem[i]);
       gst_mi_hip_memory_wait ((GstMiHipMemory *) out_mem[i]);
     }
@@ -1394,12 +1419,12 @@ hb2r_convert_waiting (GstMiHipBayer2RGB * self)
   rc = ret == GST_FLOW_OK
       ? mibayer_process_device_list (self->ctx, srcs, dsts, (int) n, stream)
       : MIBAYER_OK;
-  for (i = 0; i < n && rc == MIBAYER_OK; i++)
-    marked = gst_mi_hip_memory_mark_access ((GstMiHipMemory *) in_mem[i], stream)
-        && gst_mi_hip_memory_mark_access ((GstMiHipMemory *) out_mem[i], stream)
-        && marked;
-  if (rc == MIBAYER_OK && !marked)
-    rc = mibayer_sync (self->ctx);      /* no event: finish before anyone looks */
+  /* 2 n counter increments; whoever needs a fence behind this launch records ONE for all 2 n memories */
+  for (i = 0; i < n && rc == MIBAYER_OK; i++) {
+    gst_mi_hip_memory_mark_access_tl ((GstMiHipMemory *) in_mem[i], tl);
+    gst_mi_hip_memory_mark_access_tl ((GstMiHipMemory *) out_mem[i], tl);
+  }
+  gst_mi_hip_timeline_unref (tl);
   if (rc == MIBAYER_OK && ret == GST_FLOW_OK)
     hb2r_note_launch (self, stream);
   if (rc != MIBAYER_OK) {
@@ -1596,6 +1621,7 @@ gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
   self->device_id = -1;
   self->ctx = NULL;
   self->ctx_device = 0;
+  self->tl = NULL;
   self->out_pool = NULL;
   self->out_pool_device = 0;
   self->batch = 1;

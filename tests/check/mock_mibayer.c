@@ -478,6 +478,9 @@ static const void *g_queues_seen[16];
 static int g_nqueues_seen;
 static uint32_t g_nops;         /* launches and asynchronous copies queued so far, in device order */
 static uint32_t g_nlaunches;    /* launches among them == stamp of the next launch */
+static uint32_t g_event_records;        /* mibayer_dev_event_record calls (MOCK_MIBAYER_LOG_RECORDS): what the elements'
+                                           bookkeeping costs the runtime per frame */
+static uint32_t g_stream_waits;         /* mibayer_dev_stream_wait_event calls */
 
 typedef struct
 {
@@ -611,6 +614,9 @@ mibayer_destroy (mibayer_ctx * c)
     return;
   if (getenv ("MOCK_MIBAYER_LOG_QUEUES"))
     fprintf (stderr, "mock_mibayer: device-resident launches went to %d distinct queue(s)\n", g_nqueues_seen);
+  if (getenv ("MOCK_MIBAYER_LOG_RECORDS"))
+    fprintf (stderr, "mock_mibayer: %u launch(es), %u event record(s), %u stream wait(s) so far\n", g_nlaunches,
+        g_event_records, g_stream_waits);
   if (c->hung && !c->abandoned && c->count > 0) {
     fprintf (stderr, "mock_mibayer: destroy would block for ever on a device that never answers\n");
     abort ();
@@ -706,10 +712,14 @@ mibayer_autotune_list (mibayer_ctx * c, const void *const *d_srcs, void *const *
   return MIBAYER_OK;
 }
 
+/* Like the real library's default (DeviceQueues): ONE compute queue per device, shared by every context on it -- the
+ * stages of a device-resident pipeline are ordered by that queue, which is what makes their hand-overs free */
+static char g_queue_tokens[1 + MIBAYER_FRAME_QUEUES];
+
 void *
 mibayer_ctx_stream (mibayer_ctx * c)
 {
-  return c;                     /* any non-NULL token */
+  return c ? &g_queue_tokens[0] : NULL;
 }
 
 /* the frame queues: more tokens.  The double executes every queued operation in ONE global order when something
@@ -718,7 +728,7 @@ mibayer_ctx_stream (mibayer_ctx * c)
 void *
 mibayer_ctx_frame_queue (mibayer_ctx * c, int k)
 {
-  return (c && k >= 0 && k < MIBAYER_FRAME_QUEUES) ? (char *) c + 1 + k : NULL;
+  return (c && k >= 0 && k < MIBAYER_FRAME_QUEUES) ? &g_queue_tokens[1 + k] : NULL;
 }
 
 int
@@ -899,6 +909,7 @@ mibayer_dev_event_record (int device, void *event, void *hip_stream)
   if (!event)
     return MIBAYER_ERR_ARG;
   pthread_mutex_lock (&g_lock);
+  g_event_records++;
   ((mock_event *) event)->marker = g_nops;
   ((mock_event *) event)->queried = 0;
   pthread_mutex_unlock (&g_lock);
@@ -919,5 +930,8 @@ mibayer_dev_event_wait (int device, void *event)
 int
 mibayer_dev_stream_wait_event (int device, void *hip_stream, void *event)
 {
+  pthread_mutex_lock (&g_lock);
+  g_stream_waits++;
+  pthread_mutex_unlock (&g_lock);
   return event ? MIBAYER_OK : MIBAYER_ERR_ARG;  /* one in-order list of launches: nothing to do */
 }

@@ -357,6 +357,75 @@ def test_device_resident_source_feeds_the_converters(rig, tmp_path):
     assert res.returncode == 0 and "cycles_ok=1" in res.stdout, (res.stdout + res.stderr)[-2000:]
 
 
+def _records(out):
+    """the LAST `N launch(es), M event record(s), K stream wait(s)` line the double printed (one per destroyed context)"""
+    import re
+    found = re.findall(r"mock_mibayer: (\d+) launch\(es\), (\d+) event record\(s\), (\d+) stream wait\(s\)", out)
+    assert found, out[-1500:]
+    return tuple(int(x) for x in found[-1])
+
+
+def test_accesses_are_marked_without_a_runtime_call_and_fenced_once_per_launch(rig, tmp_path):
+    """Round 6: marking a memory's GPU access is a counter increment on its stream's timeline, not a
+    hipEventRecord; a fence is recorded only when somebody has to wait across queues or on the host, and ONE fence serves
+    every memory of a launch.  Counted in the double: `hipbayersrc prefill=4 ! hipbayer2rgb ! fakesink` (every stage
+    on the device's one compute queue, nobody ever waits) records NO event while it streams; behind batch=4 a
+    downloader on its own copy queue asks for one fence per LAUNCH (plus its own per-copy event), not two per frame."""
+    exe, env, _ = rig
+    n = 64
+    caps = "video/x-bayer(memory:HIPMemory),format=rggb,width=64,height=48,framerate=0/1"
+    res = subprocess.run([exe, "states", "hipbayersrc prefill=4 num-buffers=%d ! %s ! hipbayer2rgb ! fakesink" % (n, caps), "1"],
+                         capture_output=True, text=True, env=dict(env, MOCK_MIBAYER_LOG_RECORDS="1"), timeout=120)
+    out = res.stdout + res.stderr
+    assert res.returncode == 0 and "cycles_ok=1" in res.stdout and "AddressSanitizer" not in out, out[-3000:]
+    launches, records, waits = _records(out)
+    assert launches == n                       # (the generator's 4 fills are not launches in the double)
+    assert records <= 2 and waits == 0, (records, waits)      # rounds 2-5: 2 per frame = 128
+    # generated per buffer (prefill=0): the generator and the converter share the queue -- still nothing to record
+    res = subprocess.run([exe, "states", "hipbayersrc num-buffers=%d ! %s ! hipbayer2rgb batch=4 ! fakesink" % (n, caps), "1"],
+                         capture_output=True, text=True, env=dict(env, MOCK_MIBAYER_LOG_RECORDS="1"), timeout=120)
+    out = res.stdout + res.stderr
+    assert res.returncode == 0 and "cycles_ok=1" in res.stdout and "AddressSanitizer" not in out, out[-3000:]
+    launches, records, waits = _records(out)
+    assert launches == n and records <= 2 and waits == 0, (launches, records, waits)
+    # a consumer on ANOTHER queue: one fence per list launch serves its four frames (+ the downloader's own event per copy)
+    res = subprocess.run([exe, "states", "hipbayersrc prefill=4 num-buffers=%d ! %s ! hipbayer2rgb batch=4 ! hipdownload ! fakesink"
+                          % (n, caps), "1"],
+                         capture_output=True, text=True, env=dict(env, MOCK_MIBAYER_LOG_RECORDS="1"), timeout=120)
+    out = res.stdout + res.stderr
+    assert res.returncode == 0 and "cycles_ok=1" in res.stdout and "AddressSanitizer" not in out, out[-3000:]
+    launches, records, waits = _records(out)
+    # 1 + 15 x 4 + 3 frames (the first goes out alone: preroll) = 17 launches: one fence per launch on the compute queue
+    # for the downloader (read after write), one per launch on the copy queue when the outputs come back from the pool
+    # (write after read), + the downloader's own 64 copy events (+ teardown).  Rounds 2-5: 4 per frame = 256
+    assert launches == n and records <= n + 2 * 17 + 4, (launches, records)
+    assert waits <= 2 * n + 4, waits
+
+
+def test_prefilled_source_cycles_its_frames_and_every_reader_is_ordered(rig, tmp_path):
+    """hipbayersrc prefill=N hands out the same N device memories round-robin in fresh buffers (no GPU work per buffer).
+    The same memory is then read by several launches in flight at once -- and, behind a tee, by launches on different
+    queues: every one of them is remembered (one access per queue) and the memory is freed only after all
+    have completed (the double aborts on a free under a queued launch).  Stamps: buffer f carries frame f mod N."""
+    w, h, n, k = 64, 48, 13, 3
+    exe, env, d = rig
+    outp = tmp_path / "out.raw"
+    caps = "video/x-bayer(memory:HIPMemory),format=bggr,width=%d,height=%d,framerate=0/1" % (w, h)
+    res = subprocess.run([exe, "states", "hipbayersrc prefill=%d num-buffers=%d ! %s ! hipbayer2rgb ! hipdownload ! "
+                          "filesink location=%s" % (k, n, caps, outp), "1"], capture_output=True, text=True, env=env, timeout=120)
+    out = res.stdout + res.stderr
+    assert res.returncode == 0 and "cycles_ok=1" in res.stdout and "AddressSanitizer" not in out, out[-3000:]
+    got = np.fromfile(outp, np.uint8).reshape(n, 4 * w * h)
+    # the double's generator fills frame f with (seed + f) & 0xff (byte 4 onwards); its launch copies src[0] -- the low byte
+    # of the frame number -- over the output and stamps the launch number into the first four bytes
+    assert [int(got[i, 4]) for i in range(n)] == [i % k for i in range(n)]
+    assert [int.from_bytes(bytes(got[i, :4]), "little") for i in range(n)] == list(range(n))
+    # two branches, two converters, one of them dealing its launches over the frame queues; state cycles tear all of it down
+    kv = run(rig, "states", "hipbayersrc prefill=2 num-buffers=24 ! %s ! tee name=t  t. ! queue ! hipbayer2rgb overlap=true ! "
+             "hipdownload ! fakesink  t. ! queue ! hipbayer2rgb batch=4 ! fakesink" % caps, 3)
+    assert kv["cycles_ok"] == "3"
+
+
 def test_state_cycles(rig):
     kv = run(rig, "states", "videotestsrc num-buffers=9 ! video/x-bayer,format=rggb,width=64,height=48 ! "
              "bayer2rgb inflight=3 ! fakesink", 4)

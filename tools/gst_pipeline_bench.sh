@@ -17,26 +17,41 @@ run () {
 line () {   # label, elapsed(20 frames), elapsed(n+20 frames), n (default N)
   echo "$1 | $2 $3 ${4:-$N}" | awk -F'|' '{split($2,v," "); dt=v[2]-v[1]; printf "%-44s %7.1f fps  %8.1f Mpix/s  (%.3f s for %d frames)\n", $1, v[3]/dt, v[3]*3840*2160/dt/1e6, dt, v[3]}'
 }
-# a device-resident PRODUCER (hipbayersrc: frames generated in HBM): nothing crosses PCIe, the converter is what is timed
-run_dev () {   # nframes width height converter
+# a device-resident PRODUCER (hipbayersrc: frames in HBM): nothing crosses PCIe, the converter is what is timed.
+# prefill=8: the source generated its 8 frames when the caps were set and hands them out with NO GPU work per buffer -- the
+# figure is the converter's; without it every frame also costs a generator kernel as long as the converter's own.
+run_dev () {   # nframes width height converter [source properties]
   local t0=$(date +%s.%N)
-  /opt/conda/bin/gst-launch-1.0 -q hipbayersrc num-buffers=$1 ! "video/x-bayer(memory:HIPMemory),format=rggb,width=$2,height=$3,framerate=0/1" \
+  /opt/conda/bin/gst-launch-1.0 -q hipbayersrc $5 num-buffers=$1 ! "video/x-bayer(memory:HIPMemory),format=rggb,width=$2,height=$3,framerate=0/1" \
      ! $4 ! fakesink sync=false >/dev/null 2>&1
   local t1=$(date +%s.%N)
   echo "$t0 $t1" | awk '{print $2-$1}'
 }
 line_dev () {  # label, elapsed(200 frames), elapsed(n+200 frames), n, width, height
-  echo "$1 | $2 $3 $4 $5 $6" | awk -F'|' '{split($2,v," "); dt=v[2]-v[1]; printf "%-52s %8.1f fps  %9.1f Mpix/s  %5.1f %% of 8 TB/s  (%.3f s for %d frames)\n", $1, v[3]/dt, v[3]*v[4]*v[5]/dt/1e6, 5.0*v[3]*v[4]*v[5]/dt/1e9/80, dt, v[3]}'
+  echo "$1 | $2 $3 $4 $5 $6" | awk -F'|' '{split($2,v," "); dt=v[2]-v[1]; printf "%-66s %9.1f fps  %10.1f Mpix/s  %5.1f %% of 8 TB/s  (%.3f s for %d frames)\n", $1, v[3]/dt, v[3]*v[4]*v[5]/dt/1e6, 5.0*v[3]*v[4]*v[5]/dt/1e9/80, dt, v[3]}'
 }
-for geo in "3840 2160 40000" "7680 4320 10000" "1920 1080 40000"; do
+for geo in "3840 2160 100000" "7680 4320 25000" "1920 1080 200000" "3838 2160 100000"; do
   set -- $geo
-  for conv in "hipbayer2rgb" "hipbayer2rgb overlap=true" "hipbayer2rgb batch=4" "hipbayer2rgb batch=16" "hipbayer2rgb batch=16 overlap=true"; do
-    a=$(run_dev 200 $1 $2 "$conv"); b=$(run_dev $(($3+200)) $1 $2 "$conv")
-    line_dev "hipbayersrc $1x$2 ! $conv" $a $b $3 $1 $2
+  for conv in "hipbayer2rgb" "hipbayer2rgb batch=4" "hipbayer2rgb batch=16"; do
+    a=$(run_dev 200 $1 $2 "$conv" prefill=8); b=$(run_dev $(($3+200)) $1 $2 "$conv" prefill=8)
+    line_dev "hipbayersrc prefill=8 $1x$2 ! $conv" $a $b $3 $1 $2
   done
 done
+for geo in "3840 2160 40000" "1920 1080 40000"; do
+  set -- $geo
+  for conv in "hipbayer2rgb" "hipbayer2rgb batch=16" "hipbayer2rgb overlap=true"; do
+    a=$(run_dev 200 $1 $2 "$conv"); b=$(run_dev $(($3+200)) $1 $2 "$conv")
+    line_dev "hipbayersrc (a generator kernel per frame) $1x$2 ! $conv" $a $b $3 $1 $2
+  done
+done
+a=$(run_dev 200 3840 2160 "identity" prefill=8); b=$(run_dev 400200 3840 2160 "identity" prefill=8)
+line_dev "hipbayersrc prefill=8 3840x2160 ! identity (no converter)" $a $b 400000 3840 2160
 a=$(run_dev 200 3840 2160 "identity"); b=$(run_dev 40200 3840 2160 "identity")
-line_dev "hipbayersrc 3840x2160 ! identity (no converter)" $a $b 40000 3840 2160
+line_dev "hipbayersrc 3840x2160 ! identity (generator kernel alone)" $a $b 40000 3840 2160
+a=$(run_dev 200 3840 2160 "hipbayer2rgb ! hiprgb2bayer" prefill=8); b=$(run_dev 60200 3840 2160 "hipbayer2rgb ! hiprgb2bayer" prefill=8)
+line_dev "hipbayersrc prefill=8 3840x2160 ! hipbayer2rgb ! hiprgb2bayer" $a $b 60000 3840 2160
+a=$(run_dev 200 3840 2160 "hipbayer2rgb batch=16 ! hiprgb2bayer batch=16" prefill=8); b=$(run_dev 60200 3840 2160 "hipbayer2rgb batch=16 ! hiprgb2bayer batch=16" prefill=8)
+line_dev "hipbayersrc prefill=8 3840x2160 ! hipbayer2rgb batch=16 ! hiprgb2bayer batch=16" $a $b 60000 3840 2160
 [ -n "$ONLY_DEV" ] && exit 0
 # device-resident output (rank 4 of SURVEY 8(f)): only the 1 B/px mosaic crosses PCIe
 DEV='video/x-raw(memory:HIPMemory),format=BGRx'
