@@ -156,3 +156,84 @@ def test_perf_floor_rgb2bayer_and_the_single_frame_path(gpu_pkg):
             ctx.device_free(p)
     assert one >= 0.50, one
     assert two >= 0.59 and two > one, (one, two)
+
+
+def _pipeline_seconds(tmp, source_props, w, h, nframes, converter):
+    from test_gst_element import GST_LAUNCH, gst_env
+    import time
+    t0 = time.perf_counter()
+    res = subprocess.run([GST_LAUNCH, "-q", "hipbayersrc"] + source_props.split() + ["num-buffers=%d" % nframes, "!",
+                          "video/x-bayer(memory:HIPMemory),format=rggb,width=%d,height=%d,framerate=0/1" % (w, h), "!"]
+                         + converter.split() + ["!", "fakesink", "sync=false"],
+                         capture_output=True, text=True, env=gst_env(tmp), timeout=600)
+    dt = time.perf_counter() - t0
+    assert res.returncode == 0, res.stderr[-2000:]
+    return dt
+
+
+def _pipeline_frac(tmp, source_props, w, h, nframes, converter):
+    """fraction of the 8 TB/s HBM peak the converter's 5 B/px amount to, from the wall time of nframes more frames
+    (start-up, plan measurement and tear-down are in both runs; the stop of the pipeline waits for the queue to drain)"""
+    base = min(_pipeline_seconds(tmp, source_props, w, h, 256, converter) for _ in range(2))
+    full = _pipeline_seconds(tmp, source_props, w, h, 256 + nframes, converter)
+    return 5.0 * w * h * nframes / max(full - base, 1e-6) / 1e9 / 8000.0
+
+
+@pytest.mark.gpu
+def test_perf_floor_of_the_device_resident_pipeline(gpu_pkg, tmp_path):
+    """a floor on the ELEMENT-level figure the device-memory elements exist for.  `hipbayersrc prefill=N
+    ! hipbayer2rgb [batch=16] ! fakesink`: the source hands out prefilled frames with no GPU work per buffer, so the
+    pipeline measures the converter -- one launch per frame (round 5: 17 % of the HBM peak, bound by two hipEventRecords
+    per buffer plus a generator kernel per frame; now kernel-bound at 57-61 %) and one list launch per 16 frames
+    (17 % -> 85-100 % at 4K with 8 prefilled frames, whose re-reads the 256 MB Infinity Cache serves; prefill=64 puts
+    the sources out of its reach).  Floors at about two thirds of the measured figures: they catch per-buffer
+    bookkeeping creeping back, not box noise."""
+    from test_gst_element import needs_gst  # noqa: F401
+    if not os.path.exists(os.path.join(ROOT, "gst-plugins-bad_amd", "libgstmihip.so")):
+        pytest.fail("libgstmihip.so was not built")
+    one = max(_pipeline_frac(tmp_path, "prefill=8", 3840, 2160, 150000, "hipbayer2rgb") for _ in range(2))
+    lst = max(_pipeline_frac(tmp_path, "prefill=64", 3840, 2160, 250000, "hipbayer2rgb batch=16") for _ in range(2))
+    small = max(_pipeline_frac(tmp_path, "prefill=8", 1920, 1080, 800000, "hipbayer2rgb batch=16") for _ in range(2))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "pipeline_floor.json"), "w") as f:
+        json.dump({"4k_frame_per_launch": one, "4k_batch16_prefill64": lst, "1080p_batch16": small}, f)
+    assert one >= 0.45, one              # VERDICT r05 #1 target; kernel-bound is 54-61 %
+    assert lst >= 0.60, lst              # target 65 % was for 8 prefilled frames; this arm re-reads nothing from cache
+    assert small >= 0.30, small          # target 30 %; measured 84 %+
+
+
+_HOST_PATH_WORKER = r"""
+import json, sys
+sys.path.insert(0, %r)
+import bench, __graft_entry__ as g
+pkg = g.load_package()
+bench.host_path_rate(pkg, 0, 24, 3, 0)
+a, b = {}, {}
+plain, _ = bench.host_path_rate(pkg, 0, bench.HOST_PATH_FRAMES, 3, 0, stats=a)
+graph, _ = bench.host_path_rate(pkg, 0, bench.HOST_PATH_FRAMES, 3, pkg.FLAG_HIPGRAPH, stats=b)
+print(json.dumps({"plain": plain, "graph": graph, "plain_stats": a, "graph_stats": b}))
+"""
+
+
+@pytest.mark.gpu
+def test_host_path_default_mode_keeps_up_with_the_graph_mode(gpu_pkg):
+    """the element's DEFAULT host mode (streams + events; hipgraph=false) against the captured-graph
+    mode, 240 4K frames per arm, in five fresh processes.  Two of eight recorded 24-frame runs of rounds 4-5 had the
+    default mode at 5.7-6.0 Gpix/s beside 13.0-13.1 for the graph arm of the same process; 48 fresh processes of round
+    6 (wait policies x launch modes x idle periods, bench.py itself with and without the PMC child) never showed it
+    (profiles/r06_host_path_bimodal.md), so the floor is on the MEDIAN of five: a default mode that has lost the
+    overlap of its three queues fails all five, a box whose link halves for one process does not fail the suite -- the
+    slow process is recorded with its per-tenth completion intervals and the placement of its pinned blocks."""
+    rows = []
+    for _ in range(5):
+        res = subprocess.run([sys.executable, "-c", _HOST_PATH_WORKER % ROOT], capture_output=True, text=True, timeout=300)
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        assert res.returncode == 0 and line, (res.stdout + res.stderr)[-2000:]
+        rows.append(json.loads(line[-1]))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "host_path_floor.json"), "w") as f:
+        json.dump(rows, f)
+    ratios = sorted(r["plain"] / r["graph"] for r in rows)
+    assert ratios[2] >= 0.9, (ratios, [r["plain_stats"]["interval_by_tenth_of_run_us"] for r in rows])
+    # and it is PCIe-bound where it should be: 5 B/px over a Gen5 x16 link is ~0.63 ms per 4K frame
+    assert sorted(r["plain"] for r in rows)[2] >= 9000.0, [r["plain"] for r in rows]

@@ -80,6 +80,31 @@ def test_device_resident_source_is_the_oracles_generator_and_converts_bit_exactl
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("props", ["", "batch=4", "batch=16"])
+def test_prefilled_source_cycles_its_frames_bit_exactly(plugin, gpu_pkg, oracle, tmp_path, props):
+    """hipbayersrc prefill=N (round 6): frames 0..N-1 are generated once and handed out round-robin in fresh buffers
+    around the same device memories -- buffer f carries frame f mod N, no GPU work per buffer -- and the converter reads
+    each memory again and again while earlier launches on it are still queued.  Accesses are ordered by the stream's
+    timeline (no event per memory, gstmihipmemory.h): what comes out must still be, frame by frame, the oracle's bytes,
+    through a tee (two readers of every memory: a copy queue and the compute queue) and through list launches."""
+    w, h, n, k = 1282, 722, 23, 5        # a generic geometry (not on the 16-pixel grid): the list launch's generic arm too
+    mosaic, rgb = str(tmp_path / "mosaic.raw"), str(tmp_path / "rgb.raw")
+    res = launch(tmp_path,
+                 "hipbayersrc prefill=%d num-buffers=%d seed=11 ! video/x-bayer(memory:HIPMemory),format=gbrg,width=%d,height=%d,"
+                 "framerate=30/1 ! tee name=t t. ! queue ! hipdownload ! filesink location=%s "
+                 "t. ! queue ! hipbayer2rgb %s ! hipdownload ! video/x-raw,format=RGBx ! filesink location=%s"
+                 % (k, n, w, h, mosaic, props, rgb))
+    assert res.returncode == 0, res.stderr[-3000:]
+    stride = (w + 3) & ~3
+    src = np.fromfile(mosaic, np.uint8).reshape(n, h, stride)[:, :, :w]
+    frames = oracle.fill_synthetic(w, h, k, seed=11)
+    assert np.array_equal(src, frames[np.arange(n) % k])
+    got = np.fromfile(rgb, np.uint8).reshape(n, h, 4 * w)
+    want = oracle.bayer2rgb_batch(np.ascontiguousarray(frames), w, "gbrg", 0, 1, 2, nthreads=4)
+    assert np.array_equal(got, want[np.arange(n) % k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("props", ["", "batch=4", "batch=16"])
 def test_device_resident_rgb2bayer_and_round_trip(plugin, gpu_pkg, oracle, tmp_path, props):
     """hiprgb2bayer, the device-resident sibling direction (reference loop gst/bayer/gstrgb2bayer.c:254-268): ARGB
     frames uploaded once, converted in HBM -- frame by frame or N separately allocated buffers per list launch

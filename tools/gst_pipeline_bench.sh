@@ -30,11 +30,23 @@ run_dev () {   # nframes width height converter [source properties]
 line_dev () {  # label, elapsed(200 frames), elapsed(n+200 frames), n, width, height
   echo "$1 | $2 $3 $4 $5 $6" | awk -F'|' '{split($2,v," "); dt=v[2]-v[1]; printf "%-66s %9.1f fps  %10.1f Mpix/s  %5.1f %% of 8 TB/s  (%.3f s for %d frames)\n", $1, v[3]/dt, v[3]*v[4]*v[5]/dt/1e6, 5.0*v[3]*v[4]*v[5]/dt/1e9/80, dt, v[3]}'
 }
-for geo in "3840 2160 100000" "7680 4320 25000" "1920 1080 200000" "3838 2160 100000"; do
+# frame counts: >= 1.5 s per run, so that the +-50 ms of process start-up in the difference of two runs stay below 3 %
+for geo in "3840 2160 200000 400000" "7680 4320 80000 100000" "1920 1080 500000 1500000" "3838 2160 200000 300000"; do
   set -- $geo
   for conv in "hipbayer2rgb" "hipbayer2rgb batch=4" "hipbayer2rgb batch=16"; do
-    a=$(run_dev 200 $1 $2 "$conv" prefill=8); b=$(run_dev $(($3+200)) $1 $2 "$conv" prefill=8)
-    line_dev "hipbayersrc prefill=8 $1x$2 ! $conv" $a $b $3 $1 $2
+    n=$3; [ "$conv" = "hipbayer2rgb batch=16" ] && n=$4
+    a=$(run_dev 200 $1 $2 "$conv" prefill=8); b=$(run_dev $(($n+200)) $1 $2 "$conv" prefill=8)
+    line_dev "hipbayersrc prefill=8 $1x$2 ! $conv" $a $b $n $1 $2
+  done
+done
+# prefill=64: 64 distinct sources (531 MB at 4K), out of the reach of the 256 MB Infinity Cache that serves the
+# re-reads of 8 prefilled frames -- the figure HBM alone carries
+for geo in "3840 2160 200000 400000" "1920 1080 500000 1500000"; do
+  set -- $geo
+  for conv in "hipbayer2rgb" "hipbayer2rgb batch=16"; do
+    n=$3; [ "$conv" = "hipbayer2rgb batch=16" ] && n=$4
+    a=$(run_dev 200 $1 $2 "$conv" prefill=64); b=$(run_dev $(($n+200)) $1 $2 "$conv" prefill=64)
+    line_dev "hipbayersrc prefill=64 $1x$2 ! $conv" $a $b $n $1 $2
   done
 done
 for geo in "3840 2160 40000" "1920 1080 40000"; do
@@ -44,14 +56,14 @@ for geo in "3840 2160 40000" "1920 1080 40000"; do
     line_dev "hipbayersrc (a generator kernel per frame) $1x$2 ! $conv" $a $b $3 $1 $2
   done
 done
-a=$(run_dev 200 3840 2160 "identity" prefill=8); b=$(run_dev 400200 3840 2160 "identity" prefill=8)
-line_dev "hipbayersrc prefill=8 3840x2160 ! identity (no converter)" $a $b 400000 3840 2160
+a=$(run_dev 200 3840 2160 "identity" prefill=8); b=$(run_dev 4000200 3840 2160 "identity" prefill=8)
+line_dev "hipbayersrc prefill=8 3840x2160 ! identity (no converter)" $a $b 4000000 3840 2160
 a=$(run_dev 200 3840 2160 "identity"); b=$(run_dev 40200 3840 2160 "identity")
 line_dev "hipbayersrc 3840x2160 ! identity (generator kernel alone)" $a $b 40000 3840 2160
-a=$(run_dev 200 3840 2160 "hipbayer2rgb ! hiprgb2bayer" prefill=8); b=$(run_dev 60200 3840 2160 "hipbayer2rgb ! hiprgb2bayer" prefill=8)
-line_dev "hipbayersrc prefill=8 3840x2160 ! hipbayer2rgb ! hiprgb2bayer" $a $b 60000 3840 2160
-a=$(run_dev 200 3840 2160 "hipbayer2rgb batch=16 ! hiprgb2bayer batch=16" prefill=8); b=$(run_dev 60200 3840 2160 "hipbayer2rgb batch=16 ! hiprgb2bayer batch=16" prefill=8)
-line_dev "hipbayersrc prefill=8 3840x2160 ! hipbayer2rgb batch=16 ! hiprgb2bayer batch=16" $a $b 60000 3840 2160
+a=$(run_dev 200 3840 2160 "hipbayer2rgb ! hiprgb2bayer" prefill=8); b=$(run_dev 120200 3840 2160 "hipbayer2rgb ! hiprgb2bayer" prefill=8)
+line_dev "hipbayersrc prefill=8 3840x2160 ! hipbayer2rgb ! hiprgb2bayer" $a $b 120000 3840 2160
+a=$(run_dev 200 3840 2160 "hipbayer2rgb batch=16 ! hiprgb2bayer batch=16" prefill=8); b=$(run_dev 160200 3840 2160 "hipbayer2rgb batch=16 ! hiprgb2bayer batch=16" prefill=8)
+line_dev "hipbayersrc prefill=8 3840x2160 ! hipbayer2rgb batch=16 ! hiprgb2bayer batch=16" $a $b 160000 3840 2160
 [ -n "$ONLY_DEV" ] && exit 0
 # device-resident output (rank 4 of SURVEY 8(f)): only the 1 B/px mosaic crosses PCIe
 DEV='video/x-raw(memory:HIPMemory),format=BGRx'

@@ -43,8 +43,17 @@ def worker(a):
             d = np.ctypeslib.as_array(ctypes.cast(pd, ctypes.POINTER(ctypes.c_uint8)), (ctx.dst_bytes,))
             s[:] = 0x55
             bufs.append((ps, pd, s, d))
+        # where everything lives: the card's NUMA node, the node of every pinned block, the CPU this thread runs on
+        L.mibayer_host_numa_node.argtypes = [ctypes.c_void_p]
+        placement = {"device_node": L.mibayer_device_numa_node(0),
+                     "src_nodes": [L.mibayer_host_numa_node(b[0]) for b in bufs],
+                     "dst_nodes": [L.mibayer_host_numa_node(b[1]) for b in bufs],
+                     "cpu": os.sched_getcpu() if hasattr(os, "sched_getcpu") else -1}
         out = {}
         for phase, n in (("warm", 2 * a.inflight + a.warm), ("timed", a.frames)):
+            if phase == "timed" and a.idle > 0:
+                # the GPU sits idle, as it does in bench.py while the PMC child or the CPU baseline runs
+                time.sleep(a.idle)
             before = ctx.host_stats()
             t_submit, t_done = {}, []
             t0 = time.perf_counter()
@@ -77,7 +86,10 @@ def worker(a):
                    "wait_cpu_us": round((after["wait_cpu_ms"] - before["wait_cpu_ms"]) * 1e3 / n, 1),
                    "submit_cpu_us": round((after["submit_cpu_ms"] - before["submit_cpu_ms"]) * 1e3 / n, 1),
                    # the slow state, if it shows, as a time line: mean gap of each tenth of the run
-                   "gap_by_decile_us": [round(float(x.mean()), 0) for x in np.array_split(gaps, 10)]}
+                   "gap_by_decile_us": [round(float(x.mean()), 0) for x in np.array_split(gaps, 10)],
+                   "idle_s": a.idle, "placement": placement,
+                   # the first 48 frames in groups of 6: a slow start after an idle period shows here
+                   "first_gaps_us": [round(float(x.mean()), 0) for x in np.array_split(gaps[:48], 8)]}
         for ps, pd, _, _ in bufs:
             L.mibayer_host_free(ps)
             L.mibayer_host_free(pd)
@@ -93,6 +105,7 @@ def main():
     ap.add_argument("--frames", type=int, default=240)
     ap.add_argument("--warm", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--idle", type=float, default=0.0, help="seconds the GPU idles between the warm-up and the timed frames")
     ap.add_argument("--arms", default="events:auto,graph:auto,events:spin,events:nap,graph:spin")
     a = ap.parse_args()
     if a.worker:
@@ -102,7 +115,8 @@ def main():
         for arm in a.arms.split(","):
             mode, policy = arm.split(":")
             res = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", "--mode", mode, "--policy", policy,
-                                  "--inflight", str(a.inflight), "--frames", str(a.frames), "--warm", str(a.warm)],
+                                  "--inflight", str(a.inflight), "--frames", str(a.frames), "--warm", str(a.warm),
+                                  "--idle", str(a.idle)],
                                  capture_output=True, text=True, timeout=300)
             line = [l for l in res.stdout.splitlines() if l.startswith("{")]
             if not line:
@@ -112,10 +126,10 @@ def main():
             r["rep"] = rep
             rows.append(r)
             print("%-12s rep %d  %8.1f Mpix/s  %7.1f us/frame  gap p50 %7.1f p99 %7.1f max %8.1f  latency p50 %7.1f max %8.1f  "
-                  "polls %7.1f naps %5.2f  wait wall %7.1f cpu %6.1f  deciles %s"
+                  "polls %7.1f naps %5.2f  wait wall %7.1f cpu %6.1f  deciles %s  first48 %s  placement %s"
                   % (arm, rep, r["mpix_s"], r["us_per_frame"], r["gap_us"]["p50"], r["gap_us"]["p99"], r["gap_us"]["max"],
                      r["latency_us"]["p50"], r["latency_us"]["max"], r["polls_per_frame"], r["naps_per_frame"],
-                     r["wait_wall_us"], r["wait_cpu_us"], r["gap_by_decile_us"]), flush=True)
+                     r["wait_wall_us"], r["wait_cpu_us"], r["gap_by_decile_us"], r["first_gaps_us"], json.dumps(r["placement"])), flush=True)
     print("== by arm: min / median / max Mpix/s over %d fresh processes" % a.reps)
     for arm in a.arms.split(","):
         mode, policy = arm.split(":")
