@@ -429,6 +429,8 @@ class Context:
 
     def stall(self, ms):
         """Drill (csrc/mibayer_hooks.h): occupy the context's compute queue for `ms` milliseconds."""
+        if not hasattr(lib(), "mibayer_internal_stall"):
+            raise MibayerErrorNoLib("the stall drill is exported by the lab build only (make lab; MIBAYER_LIB_PATH)")
         fn = lib().mibayer_internal_stall
         fn.restype, fn.argtypes = ctypes.c_int, [_vp, ctypes.c_int]
         _check(fn(self._h, ms), "mibayer_internal_stall")
@@ -509,6 +511,11 @@ class Context:
         v, b, a = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _check(lib().mibayer_get_plan(self._h, ctypes.byref(v), ctypes.byref(b), ctypes.byref(a)), "mibayer_get_plan")
         return v.value, b.value, a.value
+
+    def variant_name_for(self, nframes):
+        """The kernel variant launches of `nframes` frames run (`variant_name` describes the batch-class plan
+        only; a context that launches frame by frame -- the host path, stream mode -- runs the frame-class plan)."""
+        return variant_names()[self.get_plan_for(nframes)[0]]
 
     def get_plan_for(self, nframes):
         """(variant id, band override, store alignment, source) of the launch class an nframes-frame launch falls into"""

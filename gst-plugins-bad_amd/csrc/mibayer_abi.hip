@@ -1680,6 +1680,14 @@ static int enqueue_frame_banded (mibayer_ctx *c, Slot &s, const uint8_t *src,
   const int nb = c->host_bands;
   const int per = (tiles_y + nb - 1) / nb;
   int uploaded = 0;             /* source rows already queued for upload */
+  /* the band count follows the plan (choose_host_bands after every plan change) and may have grown since the slot was
+   * made: the events a band needs are made when it first needs them (free_slot destroys all kMaxHostBands) */
+  for (int b = 0; b < nb; b++) {
+    if (!s.ev_band_in[b])
+      HIP_TRY (hipEventCreateWithFlags (&s.ev_band_in[b], hipEventDisableTiming));
+    if (!s.ev_band_kernel[b])
+      HIP_TRY (hipEventCreateWithFlags (&s.ev_band_kernel[b], hipEventDisableTiming));
+  }
   for (int b = 0; b < nb; b++) {
     const int t0 = b * per;
     const int t1 = t0 + per < tiles_y ? t0 + per : tiles_y;

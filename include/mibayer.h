@@ -63,6 +63,40 @@ extern "C" {
  * mibayer_set_plan / mibayer_copy_plan pin every class. */
 #define MIBAYER_ABI_VERSION 5
 
+/* MIBAYER ABI GROUPS -- which of the entry points are the drop-in and which are not.  The ABI is
+ * FROZEN at version 5: round 6 added nothing.  A maintainer who replaces gst_bayer2rgb_process needs `core` only
+ * (INTEGRATION.md section 2 uses create / process_host / destroy / strerror); everything else serves a named
+ * consumer and can be ignored by anybody who is not that consumer.  The dynamic symbol table of libmibayer.so is
+ * exactly this list (linker version script generated from this header; tests/test_abi.py checks both).
+ *
+ * group core: the boundary SURVEY.md section 8(b) proposed -- context, one frame host->host (synchronous and queued),
+ *   a device-resident batch, pinned host memory
+ *     mibayer_abi_version mibayer_device_count mibayer_strerror mibayer_last_hip_error mibayer_create mibayer_destroy
+ *     mibayer_get_cfg mibayer_process_host mibayer_submit mibayer_wait mibayer_pending mibayer_process_device
+ *     mibayer_sync mibayer_host_alloc mibayer_host_free
+ * group sharding: frames round-robin over the GPUs of a node, with failover (north_star; bayer2rgb devices=...)
+ *     mibayer_pool_create mibayer_pool_destroy mibayer_pool_capacity mibayer_pool_pending mibayer_pool_submit
+ *     mibayer_pool_wait mibayer_pool_alive mibayer_pool_take_failure mibayer_pool_reclaim mibayer_pool_lost
+ * group device-memory: what plugin `mihip` (memory:HIPMemory elements) and bench.py are built on --
+ *   device allocations, copies, streams and events without a context, list launches, the synthetic-frame generator
+ *     mibayer_process_device_list mibayer_ctx_stream mibayer_ctx_frame_queue mibayer_device_alloc mibayer_device_free
+ *     mibayer_copy_to_device mibayer_copy_from_device mibayer_dev_alloc mibayer_dev_free mibayer_dev_upload
+ *     mibayer_dev_download mibayer_dev_stream_create mibayer_dev_stream_destroy mibayer_dev_upload_async
+ *     mibayer_dev_download_async mibayer_dev_event_query mibayer_dev_event_create mibayer_dev_event_destroy
+ *     mibayer_dev_event_record mibayer_dev_event_wait mibayer_dev_stream_wait_event mibayer_host_alloc_near
+ *     mibayer_host_is_pinned mibayer_device_numa_node mibayer_host_numa_node mibayer_fill_synthetic
+ * group tuning: launch plans (measured / cached / set), wait policy and deadlines -- every one of them has a default
+ *     mibayer_autotune mibayer_autotune_list mibayer_copy_plan mibayer_get_plan mibayer_set_plan mibayer_get_plan_for
+ *     mibayer_set_plan_for mibayer_plan_source mibayer_plan_from_cache mibayer_plan_cache_clear mibayer_time_device
+ *     mibayer_set_wait_timeout mibayer_set_wait_spin mibayer_pool_set_wait_timeout mibayer_pool_set_wait_spin
+ * group diagnostics: what tests, bench.py and the drills read -- never needed to convert a frame
+ *     mibayer_is_lab_build mibayer_device_pci_bus_id mibayer_get_host_stats mibayer_pool_get_host_stats
+ *     mibayer_pool_inject_fault mibayer_pool_inject_stall mibayer_deferred_frees mibayer_wedged_contexts
+ *     mibayer_variant_count mibayer_variant_name mibayer_auto_variant mibayer_frame_class_variant
+ *     mibayer_known_width_plan mibayer_ctx_variant_name mibayer_plan_selectors mibayer_launch_geometry
+ *     mibayer_block_to_tile
+ * END OF MIBAYER ABI GROUPS */
+
 /* Bayer order; numbering identical to the reference's anonymous enum
  * GST_BAYER_2_RGB_FORMAT_*, gstbayer2rgb.c:95-101. */
 typedef enum mibayer_pattern {
@@ -336,7 +370,13 @@ void *mibayer_ctx_stream (mibayer_ctx *ctx);
  * `overlap` property is therefore off by default).  Ordinary HIP streams share a small pool of hardware queues and serialise
  * behind each other again; these do not.  The queues are not ordered against each other or against
  * mibayer_ctx_stream(): order consumers with events (mibayer_dev_event_record / mibayer_dev_stream_wait_event) or with
- * mibayer_sync(), which covers every frame queue this context launched on. */
+ * mibayer_sync(), which covers every frame queue this context launched on.
+ * One exception to "not ordered" (ADVICE r05): hipExtStreamCreateWithCUMask takes no flags, so these are BLOCKING
+ * streams in the runtime's sense -- they synchronise implicitly with HIP's legacy NULL stream, in both directions,
+ * unlike every other stream of this library (hipStreamNonBlocking), and unlike the plain non-blocking streams that
+ * stand in for them when the CU-mask call fails.  A process that launches on the NULL stream (or on a framework's
+ * "default stream" that is the NULL stream) serialises frame-queue launches against it: drive the frame queues from
+ * processes whose other work is on explicit streams, as the elements and tools/single_frame_bench.py do. */
 #define MIBAYER_FRAME_QUEUES 4
 void *mibayer_ctx_frame_queue (mibayer_ctx *ctx, int k);
 /* Waits (with the context's deadline) for what THIS context has in flight: its

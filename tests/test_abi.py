@@ -26,6 +26,40 @@ def test_header_symbols_all_exported(pkg):
     assert sorted(pkg.ABI) == syms, "python harness and header disagree"
 
 
+def exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_the_dynamic_symbol_table_is_exactly_the_header(pkg):
+    """what libmibayer.so exports IS include/mibayer.h -- no C++ internals (_ZN7mibayer...), no kernel
+    handles, no pool seam (csrc/mibayer_hooks.h: mibayer_internal_*).  The list is generated from the header into a
+    linker version script (Makefile); the lab build adds the seam (drills, tools) and nothing else."""
+    syms = declared_symbols()
+    assert exported(pkg.LIB_PATH) == syms
+    hooks = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "gst-plugins-bad_amd", "csrc", "mibayer_hooks.h")).read(), flags=re.S)
+    seam = sorted(set(re.findall(r"\b(mibayer_internal_[a-z0-9_]+)\s*\(", hooks)))
+    assert len(seam) == 6
+    if os.path.exists(pkg.LAB_LIB_PATH):
+        assert exported(pkg.LAB_LIB_PATH) == sorted(syms + seam)
+    # the header says which entry points are the drop-in and which are tuning / diagnostics: every function is in
+    # exactly one group, and the core is the boundary SURVEY.md section 8(b) proposed
+    groups = header_groups()
+    assert sorted(sum(groups.values(), [])) == syms
+    assert set(groups["core"]) >= {"mibayer_create", "mibayer_destroy", "mibayer_process_host", "mibayer_submit",
+                                   "mibayer_wait", "mibayer_process_device", "mibayer_host_alloc", "mibayer_host_free",
+                                   "mibayer_device_count", "mibayer_strerror"}
+    assert len(groups["core"]) <= 16, groups["core"]
+
+
+def header_groups():
+    """{group: [function, ...]} from the `MIBAYER ABI GROUPS` comment of include/mibayer.h"""
+    text = open(os.path.join(ROOT, "include", "mibayer.h")).read()
+    block = text[text.index("MIBAYER ABI GROUPS"):text.index("END OF MIBAYER ABI GROUPS")]
+    parts = re.split(r"\* group ([a-z-]+):", block)
+    return {name: sorted(set(re.findall(r"\b(mibayer_[a-z0-9_]+)\b", body))) for name, body in zip(parts[1::2], parts[2::2])}
+
+
 def test_version_strerror_variants(pkg):
     L = pkg.lib()
     assert L.mibayer_abi_version() == 5

@@ -1401,7 +1401,9 @@ def test_wait_deadline_on_a_stalled_device(gpu_pkg):
     bit-exactly again."""
     # in a process of its own: a context that is still wedged when the process ends leaves its ring to the wedge
     # registry, which the other tests of this run should not inherit
-    res = subprocess.run([sys.executable, "-c", WAIT_DEADLINE_SCRIPT, ROOT], capture_output=True, text=True, timeout=120)
+    # (the stall drill is part of the pool's seam, csrc/mibayer_hooks.h: exported by the lab build only)
+    res = subprocess.run([sys.executable, "-c", WAIT_DEADLINE_SCRIPT, ROOT], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, MIBAYER_LIB_PATH=gpu_pkg.LAB_LIB_PATH))
     assert res.returncode == 0 and "wait deadline drill ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
 
 
@@ -1499,15 +1501,15 @@ def test_pool_never_hangs_on_a_shard_that_stops_answering(gpu_pkg):
     assert res.returncode == 0 and "pool stall drill ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
 
 
-def test_destroying_a_context_does_not_wait_for_its_neighbours_on_the_shared_queues(gpu_pkg, oracle):
+def test_destroying_a_context_does_not_wait_for_its_neighbours_on_the_shared_queues(gpu_lab_pkg, oracle):
     """Two contexts on one device share its three queues.  While one of them has a long batch (here: a 400 ms
     stall + a 64-frame batch) on the compute queue, destroying -- or syncing -- the other returns at once: it waits
     for its own frames' events only and hands its device frames to the per-device cache instead of hipFree (which
     drains the device).  The batch still comes out bit-exact."""
     import time
     w, h, n = 1920, 1080, 64
-    a = gpu_pkg.Context(w, h, "rggb", "BGRx")
-    b = gpu_pkg.Context(w, h, "bggr", "RGBx")
+    a = gpu_lab_pkg.Context(w, h, "rggb", "BGRx")
+    b = gpu_lab_pkg.Context(w, h, "bggr", "RGBx")
     one = oracle.fill_synthetic(w, h, 1, seed=93)[0]
     assert np.array_equal(b.process_host(one), oracle.bayer2rgb(one, w, "bggr", 0, 1, 2))     # b owns a ring now
     d_src = a.device_alloc(n * a.src_bytes)

@@ -56,14 +56,18 @@ def worker(a):
                 time.sleep(a.idle)
             before = ctx.host_stats()
             t_submit, t_done = {}, []
+            submit_wall, wait_wall = [], []
             t0 = time.perf_counter()
             for i in range(n):
                 if ctx.pending() == a.inflight:
+                    tw = time.perf_counter()
                     tag = ctx.wait()
                     now = time.perf_counter()
+                    wait_wall.append(now - tw)
                     t_done.append((now, now - t_submit[tag]))
                 t_submit[i + 1] = time.perf_counter()
                 ctx.submit(bufs[i % a.inflight][2], bufs[i % a.inflight][3], tag=i + 1)
+                submit_wall.append(time.perf_counter() - t_submit[i + 1])
             while ctx.pending():
                 tag = ctx.wait()
                 now = time.perf_counter()
@@ -88,6 +92,10 @@ def worker(a):
                    # the slow state, if it shows, as a time line: mean gap of each tenth of the run
                    "gap_by_decile_us": [round(float(x.mean()), 0) for x in np.array_split(gaps, 10)],
                    "idle_s": a.idle, "placement": placement,
+                   # which call a stall sits in: the longest mibayer_submit and the longest mibayer_wait of the run
+                   "submit_wall_us": {"p50": round(float(np.percentile(submit_wall, 50)) * 1e6, 1),
+                                      "max": round(max(submit_wall) * 1e6, 1), "argmax": int(np.argmax(submit_wall))},
+                   "wait_wall_max_us": {"max": round(max(wait_wall) * 1e6, 1), "argmax": int(np.argmax(wait_wall))},
                    # the first 48 frames in groups of 6: a slow start after an idle period shows here
                    "first_gaps_us": [round(float(x.mean()), 0) for x in np.array_split(gaps[:48], 8)]}
         for ps, pd, _, _ in bufs:
@@ -126,10 +134,10 @@ def main():
             r["rep"] = rep
             rows.append(r)
             print("%-12s rep %d  %8.1f Mpix/s  %7.1f us/frame  gap p50 %7.1f p99 %7.1f max %8.1f  latency p50 %7.1f max %8.1f  "
-                  "polls %7.1f naps %5.2f  wait wall %7.1f cpu %6.1f  deciles %s  first48 %s  placement %s"
+                  "polls %7.1f naps %5.2f  wait wall %7.1f cpu %6.1f  deciles %s  first48 %s  placement %s  submit wall %s  longest wait %s"
                   % (arm, rep, r["mpix_s"], r["us_per_frame"], r["gap_us"]["p50"], r["gap_us"]["p99"], r["gap_us"]["max"],
                      r["latency_us"]["p50"], r["latency_us"]["max"], r["polls_per_frame"], r["naps_per_frame"],
-                     r["wait_wall_us"], r["wait_cpu_us"], r["gap_by_decile_us"], r["first_gaps_us"], json.dumps(r["placement"])), flush=True)
+                     r["wait_wall_us"], r["wait_cpu_us"], r["gap_by_decile_us"], r["first_gaps_us"], json.dumps(r["placement"]), json.dumps(r["submit_wall_us"]), json.dumps(r["wait_wall_max_us"])), flush=True)
     print("== by arm: min / median / max Mpix/s over %d fresh processes" % a.reps)
     for arm in a.arms.split(","):
         mode, policy = arm.split(":")

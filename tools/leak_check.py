@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import __graft_entry__ as entry  # noqa: E402
 
-pkg = entry.load_package()
+pkg = entry.load_package(lab=True)      # the wedge drill (Context.stall) is part of the pool's seam: lab build only
 L = pkg.lib()
 hip = ctypes.CDLL("libamdhip64.so.7")       # already loaded by libmibayer.so: same runtime
 
