@@ -1168,6 +1168,20 @@ extern "C" int mibayer_create (const mibayer_cfg *cfg, mibayer_ctx **out)
   if (f.variant == 0 && !c->inverse && !c->rows_off_sector)
     c->plan[PLAN_FRAME] = Plan { &variant (frame_class_variant (f.width, f.height, c->num_cus * 4)), INT32_MIN, 0,
       MIBAYER_PLAN_DEFAULT };
+  /* ... and for wide rows at an 8-byte phase (width % 4 == 2: 3838, 2046, 1366 px) the batch class's answer -- write-back
+   * stores, one chunk of tile rows per XCD, where the L2 puts the pieces of the straddling stores together -- is the
+   * wrong one for a launch of one or two rounds of workgroups: nothing stays in an L2 long enough to be merged, and a
+   * chunk per XCD of a 270-tile-row grid leaves XCDs unevenly loaded.  Round 6 sweep (tools/csrc/frame_plan_sweep.c,
+   * profiles/r06_single_frame.md): the streaming-store shape with the fewest rounds in its default block order, and
+   * for the 256- and 512-px-tile shapes the store arm whose wave-stores start on 128-byte boundaries -- 3838x2160
+   * 39.2 -> 48.4 % of HBM peak per frame, 7678x4320 58.6 -> 62.1 % with the arm, 2046x1080 22.3 -> 25.1 %, 1366x768
+   * 13.2 -> 14.5 % (the last two are launch-issue-bound; 1024-px tiles gain nothing from the arm).
+   * Rows that are 16-byte aligned keep the hybrid-store plan (4056x3040: 57.2 % against 53.0 % for streaming stores). */
+  if (f.variant == 0 && !c->inverse && c->rows_off_sector && f.dst_stride % 16 != 0 && f.dst_stride % 8 == 0
+      && f.width > pb.var->tile_w) {
+    const int shape = frame_class_variant (f.width, f.height, c->num_cus * 4);
+    c->plan[PLAN_FRAME] = Plan { &variant (shape), INT32_MIN, shape >= 2 ? 128 : 0, MIBAYER_PLAN_DEFAULT };
+  }
   /* a plan measured earlier in this process for this geometry and launch class on this device (mibayer_autotune)
    * replaces the default */
   (void) plan_cache_load (c);

@@ -1592,3 +1592,43 @@ def test_bench_two_ranks_stream_mode():
     want = 3840 * 2160 * 1000 / (j["ms_per_step"] * 1000 * 1e-3) / 1e6
     assert abs(j["value"] - want) / want < 0.01
     assert j["roofline"]["bound"] == "pcie" and 0 < j["roofline"]["frac"] < 1.2
+
+
+@pytest.mark.gpu
+def test_frame_class_plan_of_rows_at_an_8_byte_phase(gpu_pkg, oracle):
+    """Round 6: one frame per launch of a geometry whose output rows sit at an 8-byte phase
+    (width % 4 == 2) no longer takes the batch class's write-back / chunk-per-XCD plan: the streaming-store shape with
+    the fewest rounds, and with 256-px tiles the store arm whose wave-stores start on 128-byte boundaries (3838x2160:
+    39 -> 48 % of HBM peak per frame).  Batch launches keep their plan; rows that are 16-byte aligned keep the
+    hybrid-store plan.  Bit-exact in either class, frame by frame and through a list launch."""
+    names = gpu_pkg.variant_names()
+    for (w, h, frame_plan) in ((3838, 2160, ("lds_1x8_r4_dpp_nt", 128)), (2046, 1080, ("lds_4x2_r4_dpp_nt", 0)),
+                               (1366, 768, ("lds_4x2_r4_dpp_nt", 0))):
+        with gpu_pkg.Context(w, h, "gbrg", "xRGB") as ctx:
+            v1, b1, a1, src1 = ctx.get_plan_for(1)
+            vb = ctx.get_plan_for(4096)[0]
+            if ctx.launch_geometry(1)["grid_blocks"] and gpu_pkg.lib().mibayer_frame_class_variant(w, h, 256) == \
+                    names.index(frame_plan[0]):       # a 256-CU device: the rule uses the device's own CU count
+                assert (names[v1], a1) == frame_plan and b1 == -2 ** 31, (w, names[v1], b1, a1)
+            assert names[vb].endswith("_dpp"), names[vb]              # the batch class: write-back twin, untouched
+            n = 3
+            stride = (w + 3) & ~3
+            src = np.random.default_rng(w).integers(0, 256, (n, h, stride), dtype=np.uint8)
+            want = oracle.bayer2rgb_batch(src, w, "gbrg", 1, 2, 3, nthreads=3)
+            srcs = [ctx.device_alloc(ctx.src_bytes) for _ in range(n)]
+            dsts = [ctx.device_alloc(ctx.dst_bytes) for _ in range(n)]
+            for f in range(n):
+                ctx.to_device(srcs[f], src[f])
+                ctx.process_device(srcs[f], dsts[f], 1)
+            ctx.sync()
+            for f in range(n):
+                assert np.array_equal(ctx.from_device(dsts[f], ctx.dst_bytes).reshape(want[f].shape), want[f]), (w, f)
+                ctx.to_device(dsts[f], np.zeros(64, np.uint8))
+            ctx.process_device_list(srcs, dsts)
+            ctx.sync()
+            for f in range(n):
+                assert np.array_equal(ctx.from_device(dsts[f], ctx.dst_bytes).reshape(want[f].shape), want[f]), (w, f)
+            for p in srcs + dsts:
+                ctx.device_free(p)
+    with gpu_pkg.Context(4056, 3040, "rggb", "BGRx") as ctx:          # 16-byte aligned rows: hybrid stores, band 1
+        assert names[ctx.get_plan_for(1)[0]].endswith("_hy") and ctx.get_plan_for(1)[1:3] == (1, 0)

@@ -25,6 +25,14 @@ timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 2> $O/bench.err | gre
 PLAN=$(python -c "import json; print(json.load(open('$O/bench.json'))['config']['plan'])" 2>/dev/null)
 step "rocprofv3 --kernel-trace --stats of the same command, pinned to the plan that line ran ($PLAN)"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-host-path --no-traffic ${PLAN:+--plan $PLAN} 2>&1 | grep -v "^W20" | tail -1 | cut -c1-300)
+# ... and of EVERY production plan the autotune can return at 4K x 64 (the driver's box picks its own, and
+# whichever it picks, profiles/ must hold THAT kernel's average): the two that have won on some box so far, each pinned
+step "rocprofv3 --kernel-trace --stats, one pass per production plan"
+for plan in lds_4x2_r4_dpp_nt:1:0 lds_1x8_r4_dpp_nt:-1:0 lds_2x4_r4_dpp_nt:1:0; do
+  name=$(echo $plan | tr ':-' '_m'); mkdir -p $O/stats_$name
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$name -o $TAG -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-host-path --no-traffic --plan $plan 2>&1 | grep '^{' | tail -1 > $O/stats_$name/bench_line.json)
+  echo "$plan: $(cut -c1-160 $O/stats_$name/bench_line.json)"
+done
 step "one launch per frame: C caller, list launches, kernel traces"
 gcc -O2 -Wall -I include tools/csrc/frame_launch_bench.c -o /tmp/frame_launch_bench -Lgst-plugins-bad_amd -lmibayer -Wl,-rpath,$R/gst-plugins-bad_amd
 (for g in "3840 2160" "1920 1080" "7680 4320" "2592 1944" "4056 3040" "3838 2160"; do timeout 60 /tmp/frame_launch_bench $g; done; timeout 60 /tmp/frame_launch_bench 3840 2160 inverse) > $O/frame_launch_c.log 2>&1; grep -c "queue" $O/frame_launch_c.log
@@ -46,9 +54,13 @@ step "default vs measured vs cached plan"
 timeout 300 python tools/common_geometries.py > $O/common_geometries.log 2>&1; tail -17 $O/common_geometries.log | cut -c1-200
 step "leaks (contexts, pools, wedge registry; GStreamer leak tracer)"
 (timeout 300 python tools/leak_check.py 2>&1 | tail -4; timeout 300 bash tools/gst_leaks.sh 2>&1 | tail -14) > $O/leaks.log; tail -4 $O/leaks.log | cut -c1-160
+step "device-resident pipeline: where the time goes (HIP calls per frame, kernel busy time, CPU samples)"
+timeout 600 bash tools/element_host_profile.sh $TAG > $O/element_host.log 2>&1; grep -c "^==" $O/element_host.log
+step "host path: default mode vs graph mode, fresh processes"
+timeout 400 python tools/host_path_bimodal.py --reps 4 --arms events:auto,graph:auto,events:spin > $O/host_path_bimodal.log 2>&1; tail -4 $O/host_path_bimodal.log
 if [ -z "$QUICK" ]; then
   step "element-level fps"
-  timeout 400 bash tools/gst_pipeline_bench.sh 2000 > $O/gst_pipeline_bench.log 2>&1; tail -20 $O/gst_pipeline_bench.log
+  timeout 900 bash tools/gst_pipeline_bench.sh 2000 > $O/gst_pipeline_bench.log 2>&1; tail -20 $O/gst_pipeline_bench.log
   step "parity fuzz soak"
   MIBAYER_FUZZ_SEED=404 MIBAYER_FUZZ_CASES=1200 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k randomised 2>&1 | tail -3 | tee $O/fuzz_soak.log
   MIBAYER_LIB_PATH=$R/gst-plugins-bad_amd/libmibayer_lab.so MIBAYER_FUZZ_SEED=405 MIBAYER_FUZZ_CASES=1200 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k randomised 2>&1 | tail -3 | tee -a $O/fuzz_soak.log

@@ -97,6 +97,39 @@ if stats:
                  "profiled runs clock ~2 % lower than unprofiled ones, MI355X_MICROARCH.md \"DVFS\")")
     lines.append("")
 
+# one --stats pass per production plan: whichever plan the driver's box measures, its kernel's average is on file
+per_plan = sorted(glob.glob(os.path.join(src, "stats_lds_*")))
+if per_plan:
+    lines += ["## `rocprofv3 --kernel-trace --stats`, one pass per production plan (`bench.py --gpus 1 --steps 20 --warmup 5 "
+              "--no-cpu --no-host-path --no-traffic --plan <plan>`)", "",
+              "Every plan `mibayer_autotune` has returned for 4K x 64 on some box, each pinned: the driver's box measures its own "
+              "plan, and the kernel behind its `roofline` is one of these rows.  Timed = the 20 dispatches of the timed region; "
+              "GB/s = 2 654 208 000 B / avg; the bench line is the same process's own HIP-event figure.", "",
+              "| plan | kernel | calls | avg ns (all calls) | timed avg ns | timed min | timed max | GB/s (timed) | frac of 8 TB/s | "
+              "bench line kernel_ms | bench line frac |", "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
+    for d in per_plan:
+        st = glob.glob(os.path.join(d, "*kernel_stats.csv"))
+        tr = glob.glob(os.path.join(d, "*kernel_trace.csv"))
+        if not st or not tr:
+            continue
+        plan = os.path.basename(d)[len("stats_"):]
+        rows = [r for r in csv.DictReader(open(st[0])) if "bayer2rgb" in r["Name"]]
+        top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        trace = [r for r in csv.DictReader(open(tr[0])) if "bayer2rgb" in r["Kernel_Name"]]
+        trace.sort(key=lambda r: int(r["Start_Timestamp"]))
+        timed = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace[-21:-1]]
+        avg = sum(timed) / len(timed)
+        try:
+            bl = json.loads(open(os.path.join(d, "bench_line.json")).read().strip().splitlines()[-1])["roofline"]
+            bl = ("%.4f" % bl["kernel_ms"], "%.4f" % bl["frac"])
+        except Exception:
+            bl = ("?", "?")
+        lines.append("| `%s` | `%s` | %s | %.0f | %.0f | %d | %d | %.0f | %.4f | %s | %s |" % (
+            plan, top["Name"].replace("void mibayer::", "").replace("(mibayer::KParams)", ""), top["Calls"],
+            float(top["AverageNs"]), avg, min(timed), max(timed), (ALG_R + ALG_W) / avg, (ALG_R + ALG_W) / avg / 8000.0, bl[0], bl[1]))
+        shutil.copy(st[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, plan)))
+    lines.append("")
+
 fetch_p, write_p = counter_means("pmc_probe_FETCH_SIZE"), counter_means("pmc_probe_WRITE_SIZE")
 plans = {}
 for plan in ("band1", "chunk", "identity"):
