@@ -48,6 +48,8 @@ step "stream mode (configs[4])"
 timeout 300 python bench.py --mode stream 2>> $O/bench.err | grep '^{' | tail -1 > $O/stream_mode.json
 step "eight ranks sharing the one GPU (functional: per_gpu, control-plane fields)"
 timeout 400 python bench.py --gpus 8 --share-gpu --backend gloo --steps 5 --warmup 2 --no-cpu --no-host-path 2>> $O/bench.err | grep '^{' | tail -1 > $O/eight_ranks_one_gpu.json
+step "eight ranks on the one GPU over RCCL (expected to be refused or to fall back: the error path of the N > 1 flow, executed once before a real node does)"
+(timeout 300 python bench.py --gpus 8 --share-gpu --backend nccl --steps 5 --warmup 2 --no-cpu --no-host-path --no-traffic 2>&1 | grep -v "^W20\|^\*\*\*" | tail -25) > $O/eight_ranks_one_gpu_rccl.log 2>&1; grep -c . $O/eight_ranks_one_gpu_rccl.log
 step "host CPU per frame"
 timeout 300 bash tools/host_cpu_bench.sh 1500 > $O/host_cpu.log 2>&1; tail -16 $O/host_cpu.log | cut -c1-150
 step "default vs measured vs cached plan"
