@@ -10,8 +10,10 @@ TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/${TAG}_element_host
 mkdir -p $O
-export GST_PLUGIN_SYSTEM_PATH_1_0=/opt/conda/lib/gstreamer-1.0 GST_PLUGIN_PATH_1_0=$R/gst-plugins-bad_amd \
-       GST_PLUGIN_SCANNER=/opt/conda/libexec/gstreamer-1.0/gst-plugin-scanner GST_REGISTRY=/tmp/gst_bench.reg
+# EHP_PLUGDIR: another build of the plugins (the before / after table of profiles/r06_element_host.md was taken with the
+# round-5 binaries in tools/_r05/); EHP_ARMS=generated: only the arms a build without `prefill` can run
+export GST_PLUGIN_SYSTEM_PATH_1_0=/opt/conda/lib/gstreamer-1.0 GST_PLUGIN_PATH_1_0=${EHP_PLUGDIR:-$R/gst-plugins-bad_amd} \
+       GST_PLUGIN_SCANNER=/opt/conda/libexec/gstreamer-1.0/gst-plugin-scanner GST_REGISTRY=/tmp/gst_bench_${TAG}.reg
 /opt/conda/bin/gst-inspect-1.0 hipbayer2rgb >/dev/null 2>&1
 gcc -O2 -fPIC -shared -o /tmp/libcpu_sampler.so $R/tools/csrc/cpu_sampler.c -ldl
 REP=$O/report.txt
@@ -33,8 +35,10 @@ arm () {        # label src-props width height nframes converter
   local name=$(echo "$label" | tr ' =' '__')
   echo "=================================================================" >> $REP
   echo "== $label: $(pipeline "$sp" $w $h $n "$conv")" >> $REP
-  local a=$(timed "$(pipeline "$sp" $w $h 200 "$conv")") b=$(timed "$(pipeline "$sp" $w $h $((n+200)) "$conv")")
-  echo "$a $b $n $w $h" | awk '{dt=$2-$1; printf "untraced: %.1f fps = %.2f us per frame = %.1f %% of 8 TB/s (5 B/px)\n", $3/dt, dt/$3*1e6, 5.0*$3*$4*$5/dt/1e9/80}' >> $REP
+  # untraced: the difference of two runs, the long one >= 1.5 s so that +-50 ms of process start-up stay below 3 %
+  local m=$((5*n))
+  local a=$(timed "$(pipeline "$sp" $w $h 200 "$conv")") b=$(timed "$(pipeline "$sp" $w $h $((m+200)) "$conv")")
+  echo "$a $b $m $w $h" | awk '{dt=$2-$1; printf "untraced: %.1f fps = %.2f us per frame = %.1f %% of 8 TB/s (5 B/px)\n", $3/dt, dt/$3*1e6, 5.0*$3*$4*$5/dt/1e9/80}' >> $REP
   # (2) HIP API + kernel statistics
   rm -rf $O/trace_$name
   timeout 600 rocprofv3 --hip-trace --kernel-trace --stats --output-format csv -d $O/trace_$name -o t -- \
@@ -76,10 +80,18 @@ EOF
   sed -n '/^## threads/,/^## self/p' $O/samples_$name.txt | grep tid >> $REP
 }
 
+if [ "$EHP_ARMS" = "generated" ]; then
+  arm "4K generated batch=1" ""          3840 2160 40000 "hipbayer2rgb"
+  arm "4K generated batch=16" ""         3840 2160 40000 "hipbayer2rgb batch=16"
+  arm "1080p generated batch=1" ""       1920 1080 60000 "hipbayer2rgb"
+  arm "1080p generated batch=16" ""      1920 1080 60000 "hipbayer2rgb batch=16"
+  cat $REP
+  exit 0
+fi
 arm "4K prefill batch=1"   "prefill=8" 3840 2160 60000 "hipbayer2rgb"
 arm "4K prefill batch=16"  "prefill=8" 3840 2160 60000 "hipbayer2rgb batch=16"
 arm "4K generated batch=1" ""          3840 2160 40000 "hipbayer2rgb"
 arm "1080p prefill batch=16" "prefill=8" 1920 1080 120000 "hipbayer2rgb batch=16"
 arm "1080p prefill batch=1" "prefill=8" 1920 1080 120000 "hipbayer2rgb"
-arm "4K prefill identity (source + GStreamer alone)" "prefill=8" 3840 2160 200000 "identity"
+arm "4K prefill identity (source + GStreamer alone)" "prefill=8" 3840 2160 1000000 "identity"
 cat $REP

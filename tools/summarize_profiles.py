@@ -112,7 +112,8 @@ if per_plan:
         tr = glob.glob(os.path.join(d, "*kernel_trace.csv"))
         if not st or not tr:
             continue
-        plan = os.path.basename(d)[len("stats_"):]
+        vname, band, align = os.path.basename(d)[len("stats_"):].rsplit("_", 2)
+        plan = "%s:%s:%s" % (vname, band.replace("m", "-"), align)
         rows = [r for r in csv.DictReader(open(st[0])) if "bayer2rgb" in r["Name"]]
         top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
         trace = [r for r in csv.DictReader(open(tr[0])) if "bayer2rgb" in r["Kernel_Name"]]
@@ -127,7 +128,7 @@ if per_plan:
         lines.append("| `%s` | `%s` | %s | %.0f | %.0f | %d | %d | %.0f | %.4f | %s | %s |" % (
             plan, top["Name"].replace("void mibayer::", "").replace("(mibayer::KParams)", ""), top["Calls"],
             float(top["AverageNs"]), avg, min(timed), max(timed), (ALG_R + ALG_W) / avg, (ALG_R + ALG_W) / avg / 8000.0, bl[0], bl[1]))
-        shutil.copy(st[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, plan)))
+        shutil.copy(st[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, os.path.basename(d)[len("stats_"):])))
     lines.append("")
 
 fetch_p, write_p = counter_means("pmc_probe_FETCH_SIZE"), counter_means("pmc_probe_WRITE_SIZE")
