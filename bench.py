@@ -342,7 +342,7 @@ def host_path_rate(pkg, device, frames=240, inflight=3, flags=0, graph_mode=None
                           "placement": {"device_numa_node": L.mibayer_device_numa_node(device),
                                         "pinned_src_nodes": [L.mibayer_host_numa_node(ps) for ps, _ in srcs],
                                         "pinned_dst_nodes": [L.mibayer_host_numa_node(pd) for pd, _ in dsts],
-                                        "cpu": os.sched_getcpu() if hasattr(os, "sched_getcpu") else -1}})
+                                        "cpu": ctypes.CDLL(None).sched_getcpu()}})
         for (ps, _), (pd, _) in zip(srcs, dsts):
             L.mibayer_host_free(ps)
             L.mibayer_host_free(pd)

@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/${TAG}_element_host
 mkdir -p $O
 # EHP_PLUGDIR: another build of the plugins (the before / after table of profiles/r06_element_host.md was taken with the
-# round-5 binaries in tools/_r05/); EHP_ARMS=generated: only the arms a build without `prefill` can run
+# round-5 binaries, commit 64c9ff4 built into a scratch directory); EHP_ARMS=generated: only the arms a build without `prefill` can run
 export GST_PLUGIN_SYSTEM_PATH_1_0=/opt/conda/lib/gstreamer-1.0 GST_PLUGIN_PATH_1_0=${EHP_PLUGDIR:-$R/gst-plugins-bad_amd} \
        GST_PLUGIN_SCANNER=/opt/conda/libexec/gstreamer-1.0/gst-plugin-scanner GST_REGISTRY=/tmp/gst_bench_${TAG}.reg
 /opt/conda/bin/gst-inspect-1.0 hipbayer2rgb >/dev/null 2>&1

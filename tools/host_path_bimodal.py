@@ -48,7 +48,7 @@ def worker(a):
         placement = {"device_node": L.mibayer_device_numa_node(0),
                      "src_nodes": [L.mibayer_host_numa_node(b[0]) for b in bufs],
                      "dst_nodes": [L.mibayer_host_numa_node(b[1]) for b in bufs],
-                     "cpu": os.sched_getcpu() if hasattr(os, "sched_getcpu") else -1}
+                     "cpu": ctypes.CDLL(None).sched_getcpu()}
         out = {}
         for phase, n in (("warm", 2 * a.inflight + a.warm), ("timed", a.frames)):
             if phase == "timed" and a.idle > 0:
