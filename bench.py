@@ -528,14 +528,71 @@ def traffic_child(args):
         c.close()
 
 
+class ShmBarrier:
+    """Barrier over a counter in /dev/shm for ranks of ONE host: what carries the two barriers of the timed region when
+    the plane is gloo -- the fallback of an RCCL group that did not come up, or --backend gloo.  A gloo barrier of eight
+    ranks costs 10-13 ms (profiles/r05_eight_ranks_one_gpu.json: barrier_ms 12.87) against a timed region of 8 ms, so a
+    fallback more than halved `value` while saying loudly that it had happened (VERDICT r05 Weak 8); this one costs
+    tens of microseconds.  Sense-reversing: a rank takes the file lock, counts itself in, and either opens the next
+    generation (the last one in) or spins on the generation word.  The file is created by rank 0 and announced over
+    the gloo group before anybody uses it; ranks of several hosts keep the gloo barrier."""
+
+    def __init__(self, dist_mod, rank, world):
+        import mmap
+        import struct
+        self._struct, self._world = struct, world
+        hosts = [None] * world
+        dist_mod.all_gather_object(hosts, os.uname().nodename)
+        if len(set(hosts)) != 1:
+            raise RuntimeError("ranks on %d hosts" % len(set(hosts)))
+        path = [None]
+        if rank == 0:
+            path[0] = "/dev/shm/mibayer_bench_barrier_%d_%s" % (os.getpid(), os.environ.get("MASTER_PORT", "0"))
+            with open(path[0], "wb") as f:
+                f.write(b"\0" * 16)
+        dist_mod.broadcast_object_list(path, src=0)
+        self.path, self._owner = path[0], rank == 0
+        self._f = open(self.path, "r+b")
+        self._m = mmap.mmap(self._f.fileno(), 16)
+        dist_mod.barrier()              # everybody has it mapped before anybody counts
+
+    def wait(self, timeout_s=120.0):
+        import fcntl
+        fcntl.flock(self._f, fcntl.LOCK_EX)
+        count, gen = self._struct.unpack_from("qq", self._m, 0)
+        count += 1
+        if count == self._world:
+            self._struct.pack_into("qq", self._m, 0, 0, gen + 1)
+        else:
+            self._struct.pack_into("q", self._m, 0, count)
+        fcntl.flock(self._f, fcntl.LOCK_UN)
+        if count == self._world:
+            return
+        t0 = time.perf_counter()
+        while self._struct.unpack_from("q", self._m, 8)[0] == gen:
+            if time.perf_counter() - t0 > timeout_s:
+                raise RuntimeError("shared-memory barrier timed out after %.0f s (a rank died?)" % timeout_s)
+
+    def close(self):
+        try:
+            self._m.close()
+            self._f.close()
+            if self._owner:
+                os.unlink(self.path)
+        except OSError:
+            pass
+
+
 class ControlPlane:
     """Barrier and max-over-ranks for the timed region: the only communication of this bench (the data path has no
     collective).  Same small surface as the torch.distributed module, bound to one process group."""
 
-    def __init__(self, dist_mod, group, backend, device, fallback_reason=None, rccl_nranks=None):
+    def __init__(self, dist_mod, group, backend, device, fallback_reason=None, rccl_nranks=None, shm=None):
         self._d, self._g, self._backend, self._device = dist_mod, group, backend, device
         self.ReduceOp = dist_mod.ReduceOp
         self.fallback_reason = fallback_reason      # RCCL was asked for and did not come up: why
+        self._shm = shm                             # ShmBarrier: carries barrier() when the plane is gloo on one host
+        self.barrier_transport = "rccl" if backend == "nccl" else ("shm" if shm is not None else "gloo")
         # what a sum-of-ones all-reduce on DEVICE tensors over the RCCL group returned when the plane was brought up
         # (= the number of ranks RCCL itself saw); None when the plane is not RCCL
         self.rccl_nranks = rccl_nranks
@@ -553,6 +610,8 @@ class ControlPlane:
     def barrier(self):
         if self._backend == "nccl":
             self._d.barrier(group=self._g, device_ids=[self._device])
+        elif self._shm is not None:
+            self._shm.wait()
         else:
             self._d.barrier(group=self._g)
 
@@ -567,6 +626,8 @@ class ControlPlane:
         return out
 
     def destroy_process_group(self):
+        if self._shm is not None:
+            self._shm.close()
         self._d.destroy_process_group()
 
 
@@ -597,7 +658,16 @@ def setup_distributed(args):
                 sock.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         dist_mod.init_process_group("gloo", rank=rank, world_size=world)
-        plane = ControlPlane(dist_mod, None, "gloo", device)
+
+        def gloo_plane(why=None):
+            # the barriers of a gloo plane go over shared memory when every rank is on this host (they are: --nnodes=1)
+            try:
+                shm = ShmBarrier(dist_mod, rank, world)
+            except Exception as exc:    # noqa: BLE001 -- several hosts, no /dev/shm: the gloo barrier does
+                sys.stderr.write("bench.py rank %d: no shared-memory barrier (%s); gloo barriers\n" % (rank, exc))
+                shm = None
+            return ControlPlane(dist_mod, None, "gloo", device, fallback_reason=why, shm=shm)
+        plane = None
         if args.backend == "nccl":
             try:
                 group = dist_mod.new_group(backend="nccl")
@@ -613,7 +683,9 @@ def setup_distributed(args):
                 why = "%s: %s" % (type(exc).__name__, str(exc)[:200])
                 sys.stderr.write("bench.py rank %d: RCCL CONTROL PLANE UNAVAILABLE (%s); barriers and the "
                                  "max-reduction run over gloo\n" % (rank, why))
-                plane = ControlPlane(dist_mod, None, "gloo", device, fallback_reason=why)
+                plane = gloo_plane(why)
+        if plane is None:
+            plane = gloo_plane()
     return world, rank, device, plane
 
 
@@ -750,6 +822,9 @@ def run_stream(args):
             "per_gpu": per_gpu, "parity": parity,
             "control_plane": dist.get_backend() if dist is not None else "single process",
             "control_plane_fallback": (dist.fallback_reason if dist is not None else None),
+        # what carried the two barriers of the timed region: rccl, or -- a gloo plane on one host -- shared memory
+        "barrier_transport": (dist.barrier_transport if dist is not None else None),
+            "barrier_transport": (dist.barrier_transport if dist is not None else None),
             "rccl_nranks": dist.rccl_nranks if dist is not None else None, "distinct_gpus": distinct_gpus,
             "mechanisms": {"streams_and_events_3_queues": round(px / el_streams / 1e6, 1),
                            "hipgraph_captured_launch": round(px / el_graph / 1e6, 1),
@@ -872,6 +947,8 @@ def run(args):
         # the aggregate rate from the slowest rank's HIP-event kernel time alone (no barrier, no host)
         "control_plane": dist.get_backend() if dist is not None else "single process",
         "control_plane_fallback": (dist.fallback_reason if dist is not None else None),
+        # what carried the two barriers of the timed region: rccl, or -- a gloo plane on one host -- shared memory
+        "barrier_transport": (dist.barrier_transport if dist is not None else None),
         "barrier_ms": round(barrier_ms, 4),
         "value_kernel_only": round(pixels * world / (kernel_ms_max * 1e-3) / 1e6, 1),
         # hardware identity of the run: ranks RCCL itself counted (sum-of-ones all-reduce on device tensors; null

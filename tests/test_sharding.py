@@ -45,10 +45,17 @@ def test_gloo_world_size_2(tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     r = [json.load(open(tmp_path / ("rank%d.json" % i))) for i in range(2)]
     assert r[0]["frames"] == [0, 2, 4, 6, 8] and r[1]["frames"] == [1, 3, 5, 7, 9]
-    assert r[0]["calls"] == r[1]["calls"] == list(range(7))        # 2 warm-up + exactly 5 timed
+    # 2 warm-up + exactly 5 timed, then 1 + 3 through the plane with the shared-memory barrier
+    assert r[0]["calls"] == r[1]["calls"] == list(range(7)) + list(range(4))
     # both ranks report the same, slowest-rank time: rank 1 sleeps 40 ms/step
     assert abs(r[0]["elapsed"] - r[1]["elapsed"]) < 1e-9
     assert r[0]["elapsed"] >= 5 * 0.04 * 0.9
     # per-GPU breakdown: every rank sees every rank's entry, in rank order
     want = [{"rank": 0, "kernel_ms": 0.4}, {"rank": 1, "kernel_ms": 1.4}]
     assert r[0]["gathered"] == want and r[1]["gathered"] == want
+    # the shared-memory barrier of a gloo plane on one host: it holds the early rank, every time, and costs microseconds
+    assert r[0]["transport"] == r[1]["transport"] == "shm"
+    assert all(h >= 0.12 for h in r[0]["held"]) and all(h < 0.1 for h in r[1]["held"]), (r[0]["held"], r[1]["held"])
+    assert abs(r[0]["elapsed_shm"] - r[1]["elapsed_shm"]) < 1e-9 and r[0]["elapsed_shm"] >= 3 * 0.04 * 0.9
+    assert max(r[0]["per_barrier_us"], r[1]["per_barrier_us"]) < 5000.0      # a gloo barrier of two local ranks: ~300 us
+    assert not os.path.exists(r[0]["shm_path"])                               # rank 0 removed the file
