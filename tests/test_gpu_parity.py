@@ -1603,7 +1603,8 @@ def test_frame_class_plan_of_rows_at_an_8_byte_phase(gpu_pkg, oracle):
     hybrid-store plan.  Bit-exact in either class, frame by frame and through a list launch."""
     names = gpu_pkg.variant_names()
     for (w, h, frame_plan) in ((3838, 2160, ("lds_1x8_r4_dpp_nt", 128)), (2046, 1080, ("lds_4x2_r4_dpp_nt", 0)),
-                               (1366, 768, ("lds_4x2_r4_dpp_nt", 0))):
+                               (1366, 768, ("lds_4x2_r4_dpp_nt", 0)), (7678, 4320, ("lds_2x4_r4_dpp_nt", 128)),
+                               (3838, 2158, ("lds_1x8_r4_dpp_nt", 128))):
         with gpu_pkg.Context(w, h, "gbrg", "xRGB") as ctx:
             v1, b1, a1, src1 = ctx.get_plan_for(1)
             vb = ctx.get_plan_for(4096)[0]

@@ -239,3 +239,23 @@ def test_autotune_property_and_the_process_plan_cache(plugin, gpu_pkg, oracle, t
     assert cached and all("<second>" in ln for ln in cached), log[-3000:]
     plan = measured[0].split("plan measured on")[1].split(":", 1)[1].split("source=")[0].strip()
     assert plan and all(plan in ln for ln in cached), (plan, cached)
+
+
+@pytest.mark.gpu
+def test_autotune_measures_the_launch_class_it_issues_even_when_the_other_is_cached(plugin, gpu_pkg, tmp_path):
+    """the plan cache is keyed by launch class and `mibayer_plan_from_cache` reports a hit for EITHER
+    class.  Two converters of ONE 4K geometry in one process: the first launches frame by frame (`autotune=true`: it
+    measures the frame class on its first frame), the second `batch=16` (132 Mpixel per launch: the batch class, measured
+    by default from `batch >= 4`).  The second finds the FRAME-class plan in the cache -- and must still measure its own
+    class on its first full batch (round 5 returned early: its `plan` said `default` for ever)."""
+    w, h, n = 3840, 2160, 40
+    res = launch(tmp_path,
+                 "hipbayersrc prefill=2 num-buffers=%d ! video/x-bayer(memory:HIPMemory),format=rggb,width=%d,height=%d,"
+                 "framerate=0/1 ! hipbayer2rgb autotune=true name=first ! video/x-raw(memory:HIPMemory),format=ARGB "
+                 "! hiprgb2bayer ! video/x-bayer(memory:HIPMemory),format=rggb ! hipbayer2rgb batch=16 name=second "
+                 "! fakesink" % (n, w, h), debug="mihip:4")
+    assert res.returncode == 0, res.stderr[-3000:]
+    measured = [ln for ln in res.stderr.splitlines() if "plan measured on" in ln]
+    assert any("<first>" in ln and "measured on 1 frame(s)" in ln for ln in measured), res.stderr[-3000:]
+    assert any("<second>" in ln and "measured on 16 frame(s)" in ln for ln in measured), res.stderr[-3000:]
+    assert len(measured) == 2, measured
