@@ -16,6 +16,9 @@ for p in \
   "videotestsrc num-buffers=40 ! $B ! hipupload async=true ! hipbayer2rgb batch=4 ! hipdownload ! fakesink" \
   "videotestsrc num-buffers=40 ! $B ! hipupload async=false ! hipbayer2rgb batch=16 ! fakesink" \
   "videotestsrc num-buffers=40 ! $B ! hipupload ! hipbayer2rgb ! hipdownload async=false ! fakesink" \
+  "hipbayersrc num-buffers=40 ! hipbayer2rgb ! hipdownload ! fakesink" \
+  "hipbayersrc prefill=4 num-buffers=40 ! hipbayer2rgb batch=4 ! fakesink" \
+  "hipbayersrc prefill=3 num-buffers=40 ! tee name=t t. ! queue ! hipbayer2rgb ! hipdownload ! fakesink t. ! queue ! hipbayer2rgb batch=4 ! hiprgb2bayer ! fakesink" \
   "FAULT videotestsrc num-buffers=40 ! $B ! bayer2rgb inflight=2 devices=0,0,0 ! fakesink" \
   "videotestsrc num-buffers=40 ! $B ! bayer2rgb inflight=2 devices=0,0,0 pinned-pool=false ! fakesink"; do
   fault=""
