@@ -780,6 +780,7 @@ typedef struct
   mibayer_ctx *ctx;             /* created at the first buffer, on the device its memory lives on */
   gint ctx_device;              /* the device the context was created on */
   GstMiHipTimeline *tl;         /* the timeline of the context's stream: every launch marks its buffers on it */
+  gpointer tl_stream;           /* ... and the stream it was looked up for (hb2r_ctx_timeline) */
   GstBufferPool *out_pool;      /* output frames, on the same device */
   gint out_pool_device;
   /* batch mode (property "batch" > 1): input / output buffer pairs waiting for ONE launch over all of
@@ -1113,7 +1114,8 @@ hb2r_ensure_ctx (GstMiHipBayer2RGB * self, gint device)
     return FALSE;
   }
   self->ctx_device = device;
-  self->tl = gst_mi_hip_timeline_for (device, mibayer_ctx_stream (self->ctx));
+  self->tl_stream = mibayer_ctx_stream (self->ctx);
+  self->tl = gst_mi_hip_timeline_for (device, self->tl_stream);
   self->tuned = FALSE;
   hb2r_note_plan (self);
   return TRUE;
@@ -1267,6 +1269,19 @@ hb2r_map_pair (GstMiHipBayer2RGB * self, GstBuffer * inbuf, GstBuffer * outbuf,
  * never meet, and pays for waking an idle hardware queue per frame (6050 fps on the context's stream against 4900 fps
  * dealt over the frame queues, profiles/r05_gst_pipeline_overlap_ab.log).  The launch that settles the plan (it may run
  * mibayer_autotune_list on the context's stream) stays on the context's stream. */
+/* The timeline of the context's stream.  Looked up once per context; a context whose device call failed moves to
+ * queues of its own (csrc: mibayer_internal_private_queues), so the stream is compared, not assumed. */
+static GstMiHipTimeline *
+hb2r_ctx_timeline (GstMiHipBayer2RGB * self, gpointer ctx_stream)
+{
+  if (G_UNLIKELY (ctx_stream != self->tl_stream || self->tl == NULL)) {
+    gst_mi_hip_timeline_unref (self->tl);
+    self->tl_stream = ctx_stream;
+    self->tl = gst_mi_hip_timeline_for (self->ctx_device, ctx_stream);
+  }
+  return self->tl;
+}
+
 static gpointer
 hb2r_next_stream (GstMiHipBayer2RGB * self)
 {
@@ -1323,7 +1338,7 @@ hb2r_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
    * The next user either orders its own stream after that access or -- any plain map, hipdownload, a CPU map --
    * waits for it on the host; the fence is recorded then, by them. */
   stream = hb2r_next_stream (self);
-  tl = stream == mibayer_ctx_stream (self->ctx) ? self->tl : NULL;
+  tl = stream == mibayer_ctx_stream (self->ctx) ? hb2r_ctx_timeline (self, stream) : NULL;
   if (!(tl ? gst_mi_hip_memory_order_after_tl ((GstMiHipMemory *) in_mem, tl)
           && gst_mi_hip_memory_order_after_tl ((GstMiHipMemory *) out_mem, tl)
           : gst_mi_hip_memory_order_after ((GstMiHipMemory *) in_mem, stream)
@@ -1622,6 +1637,7 @@ gst_mi_hip_bayer2rgb_init (GstMiHipBayer2RGB * self)
   self->ctx = NULL;
   self->ctx_device = 0;
   self->tl = NULL;
+  self->tl_stream = NULL;
   self->out_pool = NULL;
   self->out_pool_device = 0;
   self->batch = 1;
