@@ -1509,34 +1509,34 @@ __device__ __forceinline__ uint32_t fmix32 (uint32_t z)
   return z;
 }
 
-/* byte(f,y,x) = fmix32((f*H*W + y*W + x) * 2654435761 + seed*0x9E3779B9) & 0xff;
- * one thread writes one dword (4 columns); padding columns are 0. */
+/* byte(f,y,x) = fmix32((f*H*W + y*W + x) * 2654435761 + seed*0x9E3779B9) & 0xff; padding columns are 0.
+ * Grid (x: 16-column groups, y: rows, z: frames): no division anywhere -- the round-1 form decoded a flat index with two
+ * 64-bit divisions per dword and took 9.2-10.8 us per 4K frame (0.9 TB/s of stores), as long as the demosaic of that
+ * frame (profiles/r06_element_host.md); a thread now writes four dwords of one row, 64 dwords apart. */
 __global__ void __launch_bounds__ (256)
 fill_synthetic_kernel (uint8_t *buf, int width, int height, int stride,
-    unsigned long long frame_bytes, uint32_t first_frame, int nframes,
-    uint32_t seed)
+    unsigned long long frame_bytes, uint32_t first_frame, uint32_t frame0, int y_base, uint32_t seed)
 {
-  const int dwords_per_row = stride >> 2;
-  const unsigned long long per_frame = (unsigned long long) dwords_per_row
-      * height;
-  const unsigned long long total = per_frame * nframes;
-  for (unsigned long long i = blockIdx.x * (unsigned long long) blockDim.x
-      + threadIdx.x; i < total;
-      i += (unsigned long long) gridDim.x * blockDim.x) {
-    const unsigned long long f = i / per_frame;
-    const unsigned long long rem = i - f * per_frame;
-    const int y = (int) (rem / dwords_per_row);
-    const int x = (int) (rem - (unsigned long long) y * dwords_per_row) * 4;
-    const uint32_t base = (first_frame + (uint32_t) f) * (uint32_t) height
-        * (uint32_t) width + (uint32_t) y * (uint32_t) width + (uint32_t) x;
+  const int y = y_base + (int) (blockIdx.y * blockDim.y + threadIdx.y);
+  const uint32_t f = frame0 + blockIdx.z;
+  if (y >= height)
+    return;
+  const uint32_t row_base = (first_frame + f) * (uint32_t) height * (uint32_t) width + (uint32_t) y * (uint32_t) width;
+  const uint32_t salt = seed * 0x9E3779B9u;
+  uint32_t *row = (uint32_t *) (buf + (unsigned long long) f * frame_bytes + (size_t) y * stride);
+  /* four dwords per thread, 64 dwords apart: every wave-store is 256 contiguous bytes */
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    const int xd = (int) blockIdx.x * 256 + d * 64 + (int) threadIdx.x;        /* dword in the row */
+    const int x = xd * 4;
+    if (x >= stride)
+      break;
     uint32_t v = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 4; k++)
       if (x + k < width)
-        v |= (fmix32 ((base + k) * 2654435761u + seed * 0x9E3779B9u) & 0xffu)
-            << (8 * k);
-    }
-    *(uint32_t *) (buf + f * frame_bytes + (size_t) y * stride + x) = v;
+        v |= (fmix32 ((row_base + (uint32_t) (x + k)) * 2654435761u + salt) & 0xffu) << (8 * k);
+    row[xd] = v;
   }
 }
 
@@ -1544,17 +1544,23 @@ hipError_t launch_fill_synthetic (uint8_t *d_buf, int width, int height,
     int stride, unsigned long long frame_bytes, uint32_t first_frame,
     int nframes, uint32_t seed, hipStream_t stream)
 {
-  const unsigned long long total = (unsigned long long) (stride >> 2) * height
-      * nframes;
-  unsigned long long blocks = (total + 255) / 256;
-  if (blocks > 256ull * 32)
-    blocks = 256ull * 32;
-  if (blocks == 0)
+  if (nframes <= 0 || height <= 0 || stride <= 0)
     return hipSuccess;
-  hipLaunchKernelGGL (fill_synthetic_kernel, dim3 ((unsigned) blocks),
-      dim3 (256), 0, stream, d_buf, width, height, stride, frame_bytes,
-      first_frame, nframes, seed);
-  return hipGetLastError ();
+  const dim3 block (64, 4);
+  const unsigned gx = (unsigned) (((stride + 15) / 16 + 63) / 64);
+  /* rows and frames in chunks the grid's y / z limits (65535) allow */
+  for (int y0 = 0; y0 < height; y0 += 65535 * 4) {
+    const int rows = height - y0 < 65535 * 4 ? height - y0 : 65535 * 4;
+    for (int f0 = 0; f0 < nframes; f0 += 65535) {
+      const int nf = nframes - f0 < 65535 ? nframes - f0 : 65535;
+      hipLaunchKernelGGL (fill_synthetic_kernel, dim3 (gx, (unsigned) ((rows + 3) / 4), (unsigned) nf), block, 0, stream,
+          d_buf, width, height, stride, frame_bytes, first_frame, (uint32_t) f0, y0, seed);
+      const hipError_t e = hipGetLastError ();
+      if (e != hipSuccess)
+        return e;
+    }
+  }
+  return hipSuccess;
 }
 
 }  /* namespace mibayer */
