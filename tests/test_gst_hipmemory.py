@@ -259,3 +259,28 @@ def test_autotune_measures_the_launch_class_it_issues_even_when_the_other_is_cac
     assert any("<first>" in ln and "measured on 1 frame(s)" in ln for ln in measured), res.stderr[-3000:]
     assert any("<second>" in ln and "measured on 16 frame(s)" in ln for ln in measured), res.stderr[-3000:]
     assert len(measured) == 2, measured
+
+
+@pytest.mark.gpu
+def test_three_streaming_threads_read_the_same_prefilled_memories(plugin, gpu_pkg, oracle, tmp_path):
+    """Three branches behind a tee, each on a streaming thread of its own (queue): a downloader on its copy queue and two
+    converters (one launch per frame; list launches of four) on the device's compute queue all read the SAME three
+    prefilled device memories again and again while the others' accesses are still queued -- the per-memory access list
+    and the timelines' counters are written from three threads.  Every branch must deliver the oracle's bytes."""
+    w, h, n, k = 1920, 1080, 61, 3
+    mosaic, a, b = (str(tmp_path / f) for f in ("mosaic.raw", "a.raw", "b.raw"))
+    res = launch(tmp_path,
+                 "hipbayersrc prefill=%d num-buffers=%d seed=13 ! video/x-bayer(memory:HIPMemory),format=bggr,width=%d,height=%d,"
+                 "framerate=0/1 ! tee name=t "
+                 "t. ! queue ! hipdownload ! filesink location=%s "
+                 "t. ! queue ! hipbayer2rgb ! hipdownload ! video/x-raw,format=BGRx ! filesink location=%s "
+                 "t. ! queue ! hipbayer2rgb batch=4 ! hipdownload ! video/x-raw,format=xRGB ! filesink location=%s"
+                 % (k, n, w, h, mosaic, a, b))
+    assert res.returncode == 0, res.stderr[-3000:]
+    frames = oracle.fill_synthetic(w, h, k, seed=13)
+    idx = np.arange(n) % k
+    assert np.array_equal(np.fromfile(mosaic, np.uint8).reshape(n, h, w), frames[idx])
+    want_a = oracle.bayer2rgb_batch(frames, w, "bggr", 2, 1, 0, nthreads=3)
+    want_b = oracle.bayer2rgb_batch(frames, w, "bggr", 1, 2, 3, nthreads=3)
+    assert np.array_equal(np.fromfile(a, np.uint8).reshape(n, h, 4 * w), want_a[idx])
+    assert np.array_equal(np.fromfile(b, np.uint8).reshape(n, h, 4 * w), want_b[idx])

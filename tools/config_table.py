@@ -33,7 +33,7 @@ for name, w, h, n, pat, fmt, seed in CONFIGS:
         t = statistics.median(ts)
         px = w * h * n
         print("| %s | %d×%d × %d | %.2f GB | %s, band %d | %.4f | %.0f | %.1f | %.1f |" % (
-            name, w, h, n, 5 * px / 1e9, c.variant_name, g["band"], t, px / t / 1e3, 5 * px / t / 1e6,
+            name, w, h, n, 5 * px / 1e9, c.variant_name_for(n), g["band"], t, px / t / 1e3, 5 * px / t / 1e6,
             5 * px / t / 1e6 / 80), flush=True)
         c.device_free(d_src)
         c.device_free(d_dst)

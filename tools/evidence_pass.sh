@@ -52,6 +52,8 @@ step "eight ranks on the one GPU over RCCL (expected to be refused or to fall ba
 (timeout 300 python bench.py --gpus 8 --share-gpu --backend nccl --steps 5 --warmup 2 --no-cpu --no-host-path --no-traffic 2>&1 | grep -v "^W20\|^\*\*\*" | tail -25) > $O/eight_ranks_one_gpu_rccl.log 2>&1; grep -c . $O/eight_ranks_one_gpu_rccl.log
 step "host CPU per frame"
 timeout 300 bash tools/host_cpu_bench.sh 1500 > $O/host_cpu.log 2>&1; tail -16 $O/host_cpu.log | cut -c1-150
+step "every BASELINE geometry, device-resident"
+timeout 400 python tools/config_table.py > $O/configs.md 2>&1; tail -8 $O/configs.md | cut -c1-200
 step "default vs measured vs cached plan"
 timeout 300 python tools/common_geometries.py > $O/common_geometries.log 2>&1; tail -17 $O/common_geometries.log | cut -c1-200
 step "leaks (contexts, pools, wedge registry; GStreamer leak tracer)"
