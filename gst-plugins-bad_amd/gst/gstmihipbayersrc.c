@@ -77,6 +77,15 @@ hbs_drop (GstMiHipBayerSrc * self)
 {
   guint i;
 
+  /* nothing marked on the context's stream asks it for a fence after the context has gone (gstmihipmemory.h): wait for
+   * what the context queued and tell the timeline, BEFORE the memories go (their release then finds every access
+   * complete and makes no runtime call) and before the context does */
+  if (self->ctx != NULL && self->tl != NULL) {
+    const guint64 upto = gst_mi_hip_timeline_submitted (self->tl);
+
+    if (mibayer_sync (self->ctx) == MIBAYER_OK)
+      gst_mi_hip_timeline_settle (self->tl, upto);
+  }
   for (i = 0; i < self->n_prefilled; i++)
     gst_memory_unref (self->prefilled[i]);      /* (a consumer may still hold it: freed with the last reference) */
   self->n_prefilled = 0;
@@ -85,16 +94,9 @@ hbs_drop (GstMiHipBayerSrc * self)
     gst_object_unref (self->pool);
     self->pool = NULL;
   }
+  gst_mi_hip_timeline_unref (self->tl);
+  self->tl = NULL;
   if (self->ctx) {
-    /* nothing marked on the context's stream asks it for a fence after the context has gone (gstmihipmemory.h) */
-    if (self->tl != NULL) {
-      const guint64 upto = gst_mi_hip_timeline_submitted (self->tl);
-
-      if (mibayer_sync (self->ctx) == MIBAYER_OK)
-        gst_mi_hip_timeline_settle (self->tl, upto);
-      gst_mi_hip_timeline_unref (self->tl);
-      self->tl = NULL;
-    }
     mibayer_destroy (self->ctx);
     self->ctx = NULL;
   }
