@@ -279,6 +279,58 @@ def parity_spot_check(pkg, ctxs, d_src, d_dst, rank, world, stream):
     return "bit-exact vs oracle on frames %d and %d of the batch (rggb->%s)" % (0, BATCH - 1, FORMAT)
 
 
+def sched_snapshot():
+    """Where a stall of the host path could come from on the HOST side: per thread of this process the time spent
+    runnable but not running (/proc/self/task/*/schedstat, second field, ns), the cgroup's CFS-quota throttling
+    (cpu.stat) and the system's CPU pressure (/proc/pressure/cpu `some total`, us).  Best effort: {} where /proc says
+    nothing."""
+    snap = {"threads": {}, "throttled_ms": None, "psi_some_ms": None}
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                with open("/proc/self/task/%s/schedstat" % tid) as f:
+                    run_ns, wait_ns = f.read().split()[:2]
+                with open("/proc/self/task/%s/comm" % tid) as f:
+                    comm = f.read().strip()
+                snap["threads"][tid] = (int(wait_ns), comm)
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        pass
+    for path, key, scale in (("/sys/fs/cgroup/cpu.stat", "throttled_usec", 1e-3),
+                             ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time", 1e-6)):
+        try:
+            with open(path) as f:
+                for ln in f:
+                    if ln.split()[0] == key:
+                        snap["throttled_ms"] = int(ln.split()[1]) * scale
+        except (OSError, IndexError, ValueError):
+            pass
+    try:
+        with open("/proc/pressure/cpu") as f:
+            for ln in f:
+                if ln.startswith("some"):
+                    snap["psi_some_ms"] = int(ln.split("total=")[1]) * 1e-3
+    except (OSError, IndexError, ValueError):
+        pass
+    return snap
+
+
+def sched_delta(before, after):
+    """What changed between two sched_snapshot()s: the thread that waited longest for a CPU (ms, name), CFS throttling
+    and CPU pressure during the interval."""
+    worst, who = 0.0, None
+    for tid, (wait_ns, comm) in after["threads"].items():
+        d = (wait_ns - before["threads"].get(tid, (0, comm))[0]) * 1e-6
+        if d > worst:
+            worst, who = d, comm
+
+    def diff(key):
+        return None if after[key] is None or before[key] is None else round(after[key] - before[key], 2)
+    return {"max_thread_runqueue_wait_ms": round(worst, 2), "thread": who, "threads": len(after["threads"]),
+            "cgroup_throttled_ms": diff("throttled_ms"), "cpu_pressure_some_ms": diff("psi_some_ms")}
+
+
 def host_path_rate(pkg, device, frames=240, inflight=3, flags=0, graph_mode=None, stats=None):
     """PCIe-inclusive rate of the host path (hipHostMalloc-pinned buffers, async ring).  flags=FLAG_HIPGRAPH: the
     compute-queue segment of every slot (wait for the upload -> kernel -> signal the download) is a captured graph,
@@ -310,6 +362,7 @@ def host_path_rate(pkg, device, frames=240, inflight=3, flags=0, graph_mode=None
         for phase in ("warm", "timed"):
             n = 2 * inflight if phase == "warm" else frames
             before = ctx.host_stats()
+            sched0 = sched_snapshot()
             t_submit, t_done = {}, []
             t0 = time.perf_counter()
             for i in range(n):
@@ -324,6 +377,7 @@ def host_path_rate(pkg, device, frames=240, inflight=3, flags=0, graph_mode=None
                 now = time.perf_counter()
                 t_done.append((now, now - t_submit[tag]))
             el = time.perf_counter() - t0
+            sched1 = sched_snapshot()
         if stats is not None:
             after = ctx.host_stats()
             gaps = np.diff(np.array([t for t, _ in t_done])) * 1e6
@@ -339,6 +393,9 @@ def host_path_rate(pkg, device, frames=240, inflight=3, flags=0, graph_mode=None
                                                      "p99": round(float(np.percentile(gaps, 99)), 1),
                                                      "max": round(float(gaps.max()), 1)},
                           "interval_by_tenth_of_run_us": [round(float(x.mean())) for x in np.array_split(gaps, 10)],
+                          # host side of a stall: did a thread of this process (the HSA runtime's signal thread, say)
+                          # wait for a CPU, was the cgroup throttled, was the machine short of CPUs
+                          "sched": sched_delta(sched0, sched1),
                           "placement": {"device_numa_node": L.mibayer_device_numa_node(device),
                                         "pinned_src_nodes": [L.mibayer_host_numa_node(ps) for ps, _ in srcs],
                                         "pinned_dst_nodes": [L.mibayer_host_numa_node(pd) for pd, _ in dsts],
@@ -362,7 +419,8 @@ def host_path_note(pkg, device):
             "hipgraph_captured_launch": round(graph, 1), "hipgraph_whole_chain_per_slot": round(chain, 1),
             "frames_per_arm": HOST_PATH_FRAMES,
             "host_cpu": cpu,
-            "hipgraph_arm": {k: gcpu[k] for k in ("latency_us", "completion_interval_us", "interval_by_tenth_of_run_us")},
+            "hipgraph_arm": {k: gcpu[k] for k in ("latency_us", "completion_interval_us", "interval_by_tenth_of_run_us",
+                                                  "sched")},
             "note": "host->host incl. H2D + D2H over PCIe, hipHostMalloc-pinned buffers, 3 frames in flight, %d 4K "
                     "frames per arm; bound by PCIe (5 B/pixel over a Gen5 x16 link), not HBM; never `value`; host_cpu = "
                     "CPU time of the submitting / waiting thread per frame, latency (submit -> wait returns) and "
@@ -978,6 +1036,16 @@ def run(args):
     # `traffic` is a measurement of THIS run or null: PMC counters need a rocprofv3 wrapper around the process, so
     # the unwrapped bench line says null and carries the last profiled figure under its own name, with the
     # plan, the box and the build it was taken on (tools/summarize_profiles.py writes the file)
+    # The host-path note runs BEFORE the traffic pass (round 6).  For some tens of milliseconds after a process that
+    # collected PMC counters has left the GPU, whatever runs there can lose ONE interval of 18.5-19.9 ms in which the
+    # device completes nothing (caught six times in profiles/r06_host_path_bimodal.md, never without the PMC child, never
+    # in host scheduling: no thread of this process waited for a CPU meanwhile) -- that, inside a 15-ms arm right behind
+    # the child, was the "5.7 Gpix/s" of the default host mode in two records of rounds 4-5.  --host-path-after-traffic
+    # restores the old order (the reproducer).
+    if rank == 0 and world == 1 and not args.no_host_path and not args.host_path_after_traffic:
+        for c in ctxs.values():
+            c.sync()
+        result["host_path"] = host_path_note(pkg, local_rank)
     if rank == 0 and world == 1 and not args.no_traffic:
         # measured in THIS run: a profiled child of this very script, same batch, same plan, after the timed region
         torch.cuda.synchronize()
@@ -999,7 +1067,7 @@ def run(args):
                     plan_source=PLAN_SOURCES[ctx0.get_plan_for(BATCH)[3]], parity=parity)
         result["per_gpu"] = dist.gather_objects(mine)
     if rank == 0 and world == 1:
-        if not args.no_host_path:
+        if not args.no_host_path and args.host_path_after_traffic:
             for c in ctxs.values():
                 c.sync()
             result["host_path"] = host_path_note(pkg, local_rank)
@@ -1023,6 +1091,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--host-path-after-traffic", action="store_true",
+                    help="reproducer: run the host-path note behind the PMC child, as rounds 1-5 did")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--plan", default=None, metavar="VARIANT:BAND:ALIGN",
                     help="pin the launch plan (as config.plan of an earlier line reports it) instead of measuring it")

@@ -54,6 +54,17 @@ def worker(a):
             if phase == "timed" and a.idle > 0:
                 # the GPU sits idle, as it does in bench.py while the PMC child or the CPU baseline runs
                 time.sleep(a.idle)
+            if phase == "timed" and a.foreign:
+                # ANOTHER process uses the GPU meanwhile (what bench.py's PMC child is): does this process pay for getting
+                # its hardware queues back when it resumes?
+                subprocess.run([sys.executable, "-c",
+                                "import sys; sys.path.insert(0, %r)\n"
+                                "import __graft_entry__ as g\n"
+                                "p = g.load_package()\n"
+                                "c = p.Context(3840, 2160, 'rggb', 'BGRx')\n"
+                                "s = c.device_alloc(64 * c.src_bytes); d = c.device_alloc(64 * c.dst_bytes)\n"
+                                "[c.time_device(s, d, 64, warmup=1, reps=200) for _ in range(%d)]\n" % (ROOT, a.foreign)],
+                               timeout=120)
             before = ctx.host_stats()
             t_submit, t_done = {}, []
             submit_wall, wait_wall = [], []
@@ -114,6 +125,8 @@ def main():
     ap.add_argument("--warm", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--idle", type=float, default=0.0, help="seconds the GPU idles between the warm-up and the timed frames")
+    ap.add_argument("--foreign", type=int, default=0,
+                    help="N > 0: another process runs N x 200 batch launches on the GPU between the warm-up and the timed frames")
     ap.add_argument("--arms", default="events:auto,graph:auto,events:spin,events:nap,graph:spin")
     a = ap.parse_args()
     if a.worker:
@@ -124,7 +137,7 @@ def main():
             mode, policy = arm.split(":")
             res = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", "--mode", mode, "--policy", policy,
                                   "--inflight", str(a.inflight), "--frames", str(a.frames), "--warm", str(a.warm),
-                                  "--idle", str(a.idle)],
+                                  "--idle", str(a.idle), "--foreign", str(a.foreign)],
                                  capture_output=True, text=True, timeout=300)
             line = [l for l in res.stdout.splitlines() if l.startswith("{")]
             if not line:
