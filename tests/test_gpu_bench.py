@@ -219,11 +219,12 @@ print(json.dumps({"plain": plain, "graph": graph, "plain_stats": a, "graph_stats
 def test_host_path_default_mode_keeps_up_with_the_graph_mode(gpu_pkg):
     """the element's DEFAULT host mode (streams + events; hipgraph=false) against the captured-graph
     mode, 240 4K frames per arm, in five fresh processes.  Two of eight recorded 24-frame runs of rounds 4-5 had the
-    default mode at 5.7-6.0 Gpix/s beside 13.0-13.1 for the graph arm of the same process; 48 fresh processes of round
-    6 (wait policies x launch modes x idle periods, bench.py itself with and without the PMC child) never showed it
-    (profiles/r06_host_path_bimodal.md), so the floor is on the MEDIAN of five: a default mode that has lost the
-    overlap of its three queues fails all five, a box whose link halves for one process does not fail the suite -- the
-    slow process is recorded with its per-tenth completion intervals and the placement of its pinned blocks."""
+    default mode at 5.7-6.0 Gpix/s beside 13.0-13.1 for the graph arm of the same process: that was ONE ~19 ms stall the
+    GPU takes within ~150 ms after bench.py's own PMC child leaves it, inside a 15-ms arm (profiles/
+    r06_host_path_bimodal.md: 8 of 12 runs with the note behind the child, 0 of 12 with it in front, where it runs
+    now).  No profiler precedes these processes; the floor is on the MEDIAN of five all the same: a default mode that has
+    lost the overlap of its three queues fails all five, a box that stalls one process does not fail the suite -- the
+    slow process is recorded with its per-tenth completion intervals, placement and scheduler deltas."""
     rows = []
     for _ in range(5):
         res = subprocess.run([sys.executable, "-c", _HOST_PATH_WORKER % ROOT], capture_output=True, text=True, timeout=300)
