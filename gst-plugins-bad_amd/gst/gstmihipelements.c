@@ -1210,7 +1210,7 @@ hb2r_prepare_output_buffer (GstBaseTransform * trans, GstBuffer * inbuf,
 /* The C ABI takes bare device pointers: a frame that lives on another GPU, or a
  * buffer smaller than the negotiated frame, would fault on the device.  Maps both
  * memories for device access (no host wait: the caller orders its launch after
- * their last-access events). */
+ * their queued accesses: gstmihipmemory.h). */
 static gboolean
 hb2r_map_pair (GstMiHipBayer2RGB * self, GstBuffer * inbuf, GstBuffer * outbuf,
     GstMemory ** in_mem, GstMemory ** out_mem, GstMapInfo * in_map,
@@ -1254,7 +1254,7 @@ hb2r_map_pair (GstMiHipBayer2RGB * self, GstBuffer * inbuf, GstBuffer * outbuf,
 }
 
 /* The compute stream of the next launch.  Frames (and list launches) are independent and every buffer is handed over
- * by its own "last access" event, so consecutive launches may go round-robin over the device's frame queues (hardware
+ * by its own queued accesses (gstmihipmemory.h), so consecutive launches may go round-robin over the device's frame queues (hardware
  * queues of their own): a one-frame launch is a single round of workgroups, and on the other queues the ramp-up of the
  * next launches overlaps the drain of launch n (one 4K frame per launch: 54 -> 66 % of HBM peak, rgb2bayer 55 -> 77 %;
  * list launches of 4: 65 -> 74 %, of 16: 78 -> 81 %; profiles/r05_single_frame.md) -- property `overlap`, OFF BY

@@ -562,7 +562,7 @@ gst_mi_hip_pool_alloc_buffer (GstBufferPool * pool, GstBuffer ** buffer,
 /* A buffer that comes back to the pool carries a frame nobody will look at again: the next user defines the
  * contents afresh.  Without this, every WRITE-only CPU map of a recycled buffer first downloaded the stale frame
  * (a whole frame over PCIe and a host sync) only to have it overwritten.  GPU work still queued on the memory
- * stays ordered: the "last access" event is not touched. */
+ * stays ordered: the memory's queued accesses are not touched. */
 static void
 gst_mi_hip_pool_reset_buffer (GstBufferPool * pool, GstBuffer * buffer)
 {
