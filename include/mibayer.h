@@ -525,9 +525,10 @@ int mibayer_dev_download_async (int device, void *dst, const void *d_src,
 int mibayer_dev_event_query (int device, void *event);
 
 /* Context-free events, for stream-ordered hand-over of a device buffer from one
- * user to the next without a host round trip (GstMiHipMemory carries one as
- * its "last access" marker): record after the work that touches the buffer,
- * make the next user's stream wait for it -- or block the host on it. */
+ * user to the next without a host round trip: record after the work that touches
+ * the buffer, make the next user's stream wait for it -- or block the host on it.
+ * (Plugin `mihip` records them lazily: one per stream when somebody has to wait
+ * across queues or on the host, not one per buffer -- gst/gstmihipmemory.h.) */
 void *mibayer_dev_event_create (int device);
 void mibayer_dev_event_destroy (int device, void *event);
 int mibayer_dev_event_record (int device, void *event,
