@@ -103,6 +103,7 @@ def worker(a):
                    # the slow state, if it shows, as a time line: mean gap of each tenth of the run
                    "gap_by_decile_us": [round(float(x.mean()), 0) for x in np.array_split(gaps, 10)],
                    "idle_s": a.idle, "placement": placement,
+                   "stalls_over_2ms": [round(float(g)) for g in gaps[gaps > 2000.0]][:20],
                    # which call a stall sits in: the longest mibayer_submit and the longest mibayer_wait of the run
                    "submit_wall_us": {"p50": round(float(np.percentile(submit_wall, 50)) * 1e6, 1),
                                       "max": round(max(submit_wall) * 1e6, 1), "argmax": int(np.argmax(submit_wall))},
@@ -147,10 +148,10 @@ def main():
             r["rep"] = rep
             rows.append(r)
             print("%-12s rep %d  %8.1f Mpix/s  %7.1f us/frame  gap p50 %7.1f p99 %7.1f max %8.1f  latency p50 %7.1f max %8.1f  "
-                  "polls %7.1f naps %5.2f  wait wall %7.1f cpu %6.1f  deciles %s  first48 %s  placement %s  submit wall %s  longest wait %s"
+                  "polls %7.1f naps %5.2f  wait wall %7.1f cpu %6.1f  deciles %s  first48 %s  placement %s  submit wall %s  longest wait %s  stalls>2ms %s"
                   % (arm, rep, r["mpix_s"], r["us_per_frame"], r["gap_us"]["p50"], r["gap_us"]["p99"], r["gap_us"]["max"],
                      r["latency_us"]["p50"], r["latency_us"]["max"], r["polls_per_frame"], r["naps_per_frame"],
-                     r["wait_wall_us"], r["wait_cpu_us"], r["gap_by_decile_us"], r["first_gaps_us"], json.dumps(r["placement"]), json.dumps(r["submit_wall_us"]), json.dumps(r["wait_wall_max_us"])), flush=True)
+                     r["wait_wall_us"], r["wait_cpu_us"], r["gap_by_decile_us"], r["first_gaps_us"], json.dumps(r["placement"]), json.dumps(r["submit_wall_us"]), json.dumps(r["wait_wall_max_us"]), r["stalls_over_2ms"]), flush=True)
     print("== by arm: min / median / max Mpix/s over %d fresh processes" % a.reps)
     for arm in a.arms.split(","):
         mode, policy = arm.split(":")
