@@ -237,4 +237,6 @@ def test_host_path_default_mode_keeps_up_with_the_graph_mode(gpu_pkg):
     ratios = sorted(r["plain"] / r["graph"] for r in rows)
     assert ratios[2] >= 0.9, (ratios, [r["plain_stats"]["interval_by_tenth_of_run_us"] for r in rows])
     # and it is PCIe-bound where it should be: 5 B/px over a Gen5 x16 link is ~0.63 ms per 4K frame
-    assert sorted(r["plain"] for r in rows)[2] >= 9000.0, [r["plain"] for r in rows]
+    # (8 Gpix/s: a process that starts right behind another one's GPU work runs its copies 15-35 % slower for a while,
+    # profiles/r06_host_path_bimodal.md; anything below that is not a PCIe Gen5 link doing three things at once)
+    assert sorted(r["plain"] for r in rows)[2] >= 8000.0, [r["plain"] for r in rows]
